@@ -1,0 +1,82 @@
+"""Synthetic test / bench cases built from the portable generator (weights.py).
+
+The golden generator (tools/gen_golden.py, dev container) and the tests (GPU box) must feed
+byte-identical inputs to the reference, the oracle and the HIP path; they all call these helpers.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import spec as S
+from . import weights as W
+
+
+def small_config() -> S.ModelConfig:
+    """16 nodes, window 4, depths (2,1): the smallest net with a shifted, masked block."""
+    return S.ModelConfig(max_node_num=16, c_adj=3, c_node=5, depths=(2, 1), num_heads=(3, 6),
+                         window_size=4, self_condition=True)
+
+
+def nosc_config() -> S.ModelConfig:
+    """No self-conditioning, one adjacency and one node channel (exercises the squeezed layouts)."""
+    return S.ModelConfig(max_node_num=8, c_adj=1, c_node=1, depths=(1, 1), num_heads=(3, 6),
+                         window_size=4, self_condition=False)
+
+
+CONFIGS = {"tiny": S.tiny_config, "small": small_config, "nosc": nosc_config,
+           "vg": S.vg_config, "coco": S.coco_config}
+
+# ragged numbers of valid nodes per sample used by the forward / precond goldens
+VALID = {"tiny": [8, 5], "small": [16, 9], "nosc": [8, 3], "vg": [30, 11], "coco": [20, 40]}
+
+FWD_C_NOISE = np.array([0.35, -1.2], dtype=np.float32)
+PRECOND_SIGMAS = (80.0, 1.5, 0.002)
+
+
+def case_inputs(cfg: S.ModelConfig, batch: int, valid, seed: int, tag: str, sigma_scale: float = 1.0):
+    """flags, adj, node, sc_adj, sc_node (all masked like the sampler would hand them over)."""
+    n = cfg.max_node_num
+    flags = W.synth_flags(batch, n, valid)
+    adj = W.mask_adj(W.normal(seed, f"{tag}/adj", (batch, cfg.c_adj, n, n)) * np.float32(sigma_scale), flags)
+    node = W.mask_node(W.normal(seed, f"{tag}/node", (batch, n, cfg.c_node)) * np.float32(sigma_scale), flags)
+    sc_adj = W.mask_adj(W.normal(seed, f"{tag}/sc_adj", (batch, cfg.c_adj, n, n)), flags)
+    sc_node = W.mask_node(W.normal(seed, f"{tag}/sc_node", (batch, n, cfg.c_node)), flags)
+    return flags, adj, node, sc_adj, sc_node
+
+
+def fwd_case(name: str):
+    cfg = CONFIGS[name]()
+    return (cfg,) + case_inputs(cfg, 2, VALID[name], 1, f"fwd/{name}")
+
+
+def precond_case(name: str, si: int):
+    cfg = CONFIGS[name]()
+    sigma = PRECOND_SIGMAS[si]
+    return (cfg, sigma) + case_inputs(cfg, 2, VALID[name], 2, f"pre/{name}/{si}",
+                                      sigma_scale=float(np.sqrt(sigma ** 2 + 0.25)))
+
+
+def sampler_case(cfg: S.ModelConfig, T: int, B: int, valid, seed: int, tag: str, solver: str = "heun"):
+    """flags, init_adj, init_node, noise_adj [T,B,..], noise_node [T,B,..], coin draws in (0,1)."""
+    n = cfg.max_node_num
+    flags = W.synth_flags(B, n, valid)
+    init_adj = W.mask_adj(W.normal(seed, f"{tag}/init_adj", (B, cfg.c_adj, n, n)), flags)
+    init_node = W.mask_node(W.normal(seed, f"{tag}/init_node", (B, n, cfg.c_node)), flags)
+    noise_adj = np.stack([W.normal(seed, f"{tag}/churn_adj/{i}", (B, cfg.c_adj, n, n)) for i in range(T)])
+    noise_node = np.stack([W.normal(seed, f"{tag}/churn_node/{i}", (B, n, cfg.c_node)) for i in range(T)])
+    ncalls = T if solver == "euler" else 2 * T - 1
+    return flags, init_adj, init_node, noise_adj, noise_node, W.coins(seed, tag, ncalls)
+
+
+def gt_case(cfg: S.ModelConfig, B: int, valid, seed: int = 3):
+    """+-1 'bits' ground truth for the sanity-check (known-answer) sampler run."""
+    n = cfg.max_node_num
+    flags = W.synth_flags(B, n, valid)
+    gt_adj = W.mask_adj(np.sign(W.normal(seed, "smp/gt/adj", (B, cfg.c_adj, n, n))).astype(np.float32), flags)
+    gt_node = W.mask_node(np.sign(W.normal(seed, "smp/gt/node", (B, n, cfg.c_node))).astype(np.float32), flags)
+    return gt_adj, gt_node
+
+
+# (name in sampler.npz, T, solver, S_churn)
+SAMPLER_RUNS = (("t8_heun", 8, "heun", 40.0), ("t50_heun", 50, "heun", 40.0), ("t8_euler", 8, "euler", 0.0))
+SAMPLER_VALID = [8, 5, 3, 8]

@@ -1,0 +1,667 @@
+/*
+ * dsg_ref.c -- ORACLE (test infrastructure, NOT the product).
+ *
+ * Plain-C fp32 restatement of the DiffuseSG sampling hot path:
+ *   denoiser forward  R/model/diffusesg/diffusesg.py:765-830 (DiffuseSG.forward)
+ *   preconditioning   R/model/precond/precond.py:65-110      (NodeAdjPrecond.forward)
+ *   reverse loop      R/runner/mcmc_sampler/edm.py:291-445   (NodeAdjEDMSampler.sample)
+ * (R/ = /root/reference/DiffuseSG/).  Every function cites the lines it follows.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks this file against vectors
+ * produced by the reference's own Python modules (tools/gen_golden.py -> tests/golden/).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / reported CPU baseline.  The product
+ * (diffusesg_amd/, libdsg.so) never links, loads or calls it.
+ *
+ * Layouts (same as the reference): adj [B,C_adj,N,N], node [B,N,C_node], flags [B,N] u8,
+ * activations token-major [T,C] per sample with token t = i*res + j.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NOISE_EMB 512
+#define MAX_LAYERS 8
+#define LN_EPS 1e-5f
+/* The preconditioning and sampler arithmetic mirrors torch's op-by-op fp32 rounding (each
+ * elementwise op rounds once).  A fused multiply-add would, e.g., turn t_hat^2 - t_cur^2 into a
+ * non-zero rounding residue when t_hat == t_cur, injecting churn noise the reference does not. */
+#define NO_FMA __attribute__((optimize("-ffp-contract=off")))
+
+typedef struct {
+    char key[128];
+    float *data;     /* as given: [out,in] for linears */
+    float *tr;       /* lazily built [in,out] copy for the GEMM inner loop */
+    int64_t numel;
+} wentry;
+
+typedef struct {
+    char name[64];
+    float *dst;
+    int64_t cap;
+} tap_t;
+
+typedef struct dsgref {
+    int N, c_adj, c_node, E, L, depths[MAX_LAYERS], heads[MAX_LAYERS], ws, mlp_ratio, self_cond;
+    wentry *w;
+    int nw, capw;
+    tap_t taps[64];
+    int ntaps;
+    int cur_sample, cur_B;
+    char err[256];
+    long nfe; /* network forwards executed (all samples of a batch count once) */
+} dsgref;
+
+/* ------------------------------------------------------------------------------------------ */
+/* handle + weights                                                                            */
+
+dsgref *dsgref_create(const int32_t *c) {
+    /* c = [N, c_adj, c_node, E, L, depths[8], heads[8], window, mlp_ratio, self_cond] */
+    dsgref *h = (dsgref *)calloc(1, sizeof(dsgref));
+    h->N = c[0]; h->c_adj = c[1]; h->c_node = c[2]; h->E = c[3]; h->L = c[4];
+    for (int i = 0; i < MAX_LAYERS; i++) { h->depths[i] = c[5 + i]; h->heads[i] = c[13 + i]; }
+    h->ws = c[21]; h->mlp_ratio = c[22]; h->self_cond = c[23];
+    return h;
+}
+
+void dsgref_destroy(dsgref *h) {
+    if (!h) return;
+    for (int i = 0; i < h->nw; i++) { free(h->w[i].data); free(h->w[i].tr); }
+    free(h->w);
+    free(h);
+}
+
+const char *dsgref_last_error(dsgref *h) { return h->err; }
+long dsgref_nfe(dsgref *h) { return h->nfe; }
+
+int dsgref_set_weight(dsgref *h, const char *key, const float *data, int64_t numel) {
+    for (int i = 0; i < h->nw; i++)
+        if (!strcmp(h->w[i].key, key)) {
+            free(h->w[i].data); free(h->w[i].tr); h->w[i].tr = NULL;
+            h->w[i].data = (float *)malloc(sizeof(float) * numel);
+            memcpy(h->w[i].data, data, sizeof(float) * numel);
+            h->w[i].numel = numel;
+            return 0;
+        }
+    if (h->nw == h->capw) {
+        h->capw = h->capw ? 2 * h->capw : 256;
+        h->w = (wentry *)realloc(h->w, sizeof(wentry) * h->capw);
+    }
+    wentry *e = &h->w[h->nw++];
+    memset(e, 0, sizeof(*e));
+    snprintf(e->key, sizeof(e->key), "%s", key);
+    e->data = (float *)malloc(sizeof(float) * numel);
+    memcpy(e->data, data, sizeof(float) * numel);
+    e->numel = numel;
+    return 0;
+}
+
+static wentry *W(dsgref *h, const char *fmt, const char *prefix) {
+    char key[192];
+    snprintf(key, sizeof(key), fmt, prefix);
+    for (int i = 0; i < h->nw; i++)
+        if (!strcmp(h->w[i].key, key)) return &h->w[i];
+    snprintf(h->err, sizeof(h->err), "missing weight %s", key);
+    fprintf(stderr, "dsg_ref: missing weight %s\n", key);
+    abort();
+}
+
+int dsgref_tap(dsgref *h, const char *name, float *dst, int64_t cap) {
+    if (h->ntaps >= 64) return -1;
+    snprintf(h->taps[h->ntaps].name, 64, "%s", name);
+    h->taps[h->ntaps].dst = dst;
+    h->taps[h->ntaps].cap = cap;
+    h->ntaps++;
+    return 0;
+}
+void dsgref_clear_taps(dsgref *h) { h->ntaps = 0; }
+
+/* copy one sample's stage output [numel] into slot cur_sample of a registered tap */
+static void tap(dsgref *h, const char *name, const float *src, int64_t numel) {
+    for (int i = 0; i < h->ntaps; i++)
+        if (!strcmp(h->taps[i].name, name)) {
+            int64_t off = (int64_t)h->cur_sample * numel;
+            if (off + numel <= h->taps[i].cap) memcpy(h->taps[i].dst + off, src, sizeof(float) * numel);
+        }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* primitive ops                                                                               */
+
+static inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
+static inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); } /* exact erf GELU, nn.GELU default */
+
+/* y[M,N] = x[M,K] @ W[N,K]^T + b   (torch.nn.functional.linear; diffusesg.py:14-16 etc.) */
+static void linear(wentry *w, const float *bias, const float *x, float *y, int M, int K, int N) {
+    if (!w->tr) {
+        w->tr = (float *)malloc(sizeof(float) * (size_t)K * N);
+        for (int n = 0; n < N; n++)
+            for (int k = 0; k < K; k++) w->tr[(size_t)k * N + n] = w->data[(size_t)n * K + k];
+    }
+    const float *wt = w->tr;
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; m++) {
+        float *yr = y + (size_t)m * N;
+        const float *xr = x + (size_t)m * K;
+        if (bias) memcpy(yr, bias, sizeof(float) * N);
+        else memset(yr, 0, sizeof(float) * N);
+        for (int k = 0; k < K; k++) {
+            const float a = xr[k];
+            const float *wr = wt + (size_t)k * N;
+            for (int n = 0; n < N; n++) yr[n] += a * wr[n];
+        }
+    }
+}
+
+/* y = x @ W (weight already stored [in,out]); used for ConvTranspose2d k=1 (diffusesg.py:706) */
+static void linear_in_out(const float *w_in_out, const float *bias, const float *x, float *y, int M, int K, int N) {
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; m++) {
+        float *yr = y + (size_t)m * N;
+        const float *xr = x + (size_t)m * K;
+        if (bias) memcpy(yr, bias, sizeof(float) * N);
+        else memset(yr, 0, sizeof(float) * N);
+        for (int k = 0; k < K; k++) {
+            const float a = xr[k];
+            const float *wr = w_in_out + (size_t)k * N;
+            for (int n = 0; n < N; n++) yr[n] += a * wr[n];
+        }
+    }
+}
+
+/* nn.LayerNorm over the last dim, eps=1e-5, biased variance */
+static void layer_norm(const float *g, const float *b, const float *x, float *y, int M, int C) {
+#pragma omp parallel for schedule(static)
+    for (int m = 0; m < M; m++) {
+        const float *xr = x + (size_t)m * C;
+        float *yr = y + (size_t)m * C;
+        float mean = 0.f;
+        for (int c = 0; c < C; c++) mean += xr[c];
+        mean /= (float)C;
+        float var = 0.f;
+        for (int c = 0; c < C; c++) { float d = xr[c] - mean; var += d * d; }
+        var /= (float)C;
+        const float rstd = 1.0f / sqrtf(var + LN_EPS);
+        for (int c = 0; c < C; c++) yr[c] = (xr[c] - mean) * rstd * g[c] + b[c];
+    }
+}
+
+/* x = silu(shift + x*(scale+1)), (scale,shift) = chunk(affine(emb)) (diffusesg.py:238-240, 574-576) */
+static void modulate_silu(dsgref *h, const char *prefix, const float *emb, float *x, int T, int C) {
+    float *params = (float *)malloc(sizeof(float) * 2 * C);
+    linear(W(h, "%s.affine.weight", prefix), W(h, "%s.affine.bias", prefix)->data, emb, params, 1, NOISE_EMB, 2 * C);
+    const float *scale = params, *shift = params + C;
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < T; t++)
+        for (int c = 0; c < C; c++) {
+            float *v = &x[(size_t)t * C + c];
+            *v = silu_f(shift[c] + *v * (scale[c] + 1.0f));
+        }
+    free(params);
+}
+
+/* WindowAttention.forward + window_partition/reverse + cyclic shift
+ * (diffusesg.py:108-139, 28-57, 246-271).  xin/xout token-major [res*res, C]. */
+static void window_attention(dsgref *h, const char *prefix, const float *xin, float *xout,
+                             int res, int C, int heads, int ws, int shift) {
+    const int Wt = ws * ws, nwr = res / ws, nW = nwr * nwr, hd = C / heads, T = res * res;
+    const float scale = 1.0f / sqrtf((float)hd); /* head_dim ** -0.5 */
+    float *qkv = (float *)malloc(sizeof(float) * (size_t)T * 3 * C);
+    /* qkv is a per-token linear, so it commutes with the window gather */
+    linear(W(h, "%s.attn.qkv.weight", prefix), W(h, "%s.attn.qkv.bias", prefix)->data, xin, qkv, T, C, 3 * C);
+    const float *table = W(h, "%s.attn.relative_position_bias_table", prefix)->data; /* [(2ws-1)^2, heads] */
+    float *att_out = (float *)malloc(sizeof(float) * (size_t)T * C);
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int w = 0; w < nW; w++)
+        for (int hh = 0; hh < heads; hh++) {
+            int tok[256];
+            int region[256];
+            float s[256];
+            const int wi = w / nwr, wj = w % nwr;
+            for (int p = 0; p < Wt; p++) {
+                const int si = wi * ws + p / ws, sj = wj * ws + p % ws; /* coords in the rolled image */
+                /* torch.roll(x, -shift): rolled[i] = x[(i+shift) % res] (diffusesg.py:248) */
+                tok[p] = ((si + shift) % res) * res + ((sj + shift) % res);
+                /* region id of the rolled coordinate (diffusesg.py:209-221) */
+                const int ri = si < res - ws ? 0 : (si < res - shift ? 1 : 2);
+                const int rj = sj < res - ws ? 0 : (sj < res - shift ? 1 : 2);
+                region[p] = 3 * ri + rj;
+            }
+            for (int p = 0; p < Wt; p++) {
+                const float *q = qkv + (size_t)tok[p] * 3 * C + hh * hd;
+                float mx = -INFINITY;
+                for (int r = 0; r < Wt; r++) {
+                    const float *k = qkv + (size_t)tok[r] * 3 * C + C + hh * hd;
+                    float acc = 0.f;
+                    for (int d = 0; d < hd; d++) acc += (q[d] * scale) * k[d];
+                    const int pi = p / ws, pj = p % ws, qi = r / ws, qj = r % ws;
+                    const int idx = (pi - qi + ws - 1) * (2 * ws - 1) + (pj - qj + ws - 1);
+                    acc += table[(size_t)idx * heads + hh];
+                    if (shift > 0 && region[p] != region[r]) acc += -100.0f;
+                    s[r] = acc;
+                    mx = fmaxf(mx, acc);
+                }
+                float sum = 0.f;
+                for (int r = 0; r < Wt; r++) { s[r] = expf(s[r] - mx); sum += s[r]; }
+                const float inv = 1.0f / sum;
+                float *o = att_out + (size_t)tok[p] * C + hh * hd;
+                for (int d = 0; d < hd; d++) o[d] = 0.f;
+                for (int r = 0; r < Wt; r++) {
+                    const float *v = qkv + (size_t)tok[r] * 3 * C + 2 * C + hh * hd;
+                    const float pr = s[r] * inv;
+                    for (int d = 0; d < hd; d++) o[d] += pr * v[d];
+                }
+            }
+        }
+    /* proj is per token too; un-window + roll back map each token to itself (tok[] used on both sides) */
+    linear(W(h, "%s.attn.proj.weight", prefix), W(h, "%s.attn.proj.bias", prefix)->data, att_out, xout, T, C, C);
+    free(qkv);
+    free(att_out);
+}
+
+/* SwinTransformerBlock.forward (diffusesg.py:232-277), in place on x [T,C] */
+static void swin_block(dsgref *h, const char *prefix, const float *emb, float *x, int res, int C, int heads,
+                       int ws_cfg, int shift_cfg) {
+    const int T = res * res;
+    int ws = ws_cfg, shift = shift_cfg;
+    if (res <= ws_cfg) { ws = res; shift = 0; } /* diffusesg.py:189-192 */
+    modulate_silu(h, prefix, emb, x, T, C);     /* the modulated tensor is also the shortcut (:242) */
+    float *y = (float *)malloc(sizeof(float) * (size_t)T * C);
+    float *a = (float *)malloc(sizeof(float) * (size_t)T * C);
+    layer_norm(W(h, "%s.norm1.weight", prefix)->data, W(h, "%s.norm1.bias", prefix)->data, x, y, T, C);
+    window_attention(h, prefix, y, a, res, C, heads, ws, shift);
+    for (size_t i = 0; i < (size_t)T * C; i++) x[i] += a[i];
+    /* FFN (:275) */
+    layer_norm(W(h, "%s.norm2.weight", prefix)->data, W(h, "%s.norm2.bias", prefix)->data, x, y, T, C);
+    const int Hd = h->mlp_ratio * C;
+    float *hid = (float *)malloc(sizeof(float) * (size_t)T * Hd);
+    linear(W(h, "%s.mlp.fc1.weight", prefix), W(h, "%s.mlp.fc1.bias", prefix)->data, y, hid, T, C, Hd);
+    for (size_t i = 0; i < (size_t)T * Hd; i++) hid[i] = gelu_f(hid[i]);
+    linear(W(h, "%s.mlp.fc2.weight", prefix), W(h, "%s.mlp.fc2.bias", prefix)->data, hid, a, T, Hd, C);
+    for (size_t i = 0; i < (size_t)T * C; i++) x[i] += a[i];
+    free(y); free(a); free(hid);
+}
+
+/* PatchMerging.forward (diffusesg.py:314-335): [res*res,C] -> [(res/2)^2, 2C] */
+static float *patch_merging(dsgref *h, const char *prefix, const float *x, int res, int C) {
+    const int r2 = res / 2, T2 = r2 * r2;
+    float *cat = (float *)malloc(sizeof(float) * (size_t)T2 * 4 * C);
+    for (int i = 0; i < r2; i++)
+        for (int j = 0; j < r2; j++)
+            for (int q = 0; q < 4; q++) {
+                /* x0=(0::2,0::2) x1=(1::2,0::2) x2=(0::2,1::2) x3=(1::2,1::2) */
+                const int di = q & 1, dj = q >> 1;
+                memcpy(cat + ((size_t)(i * r2 + j) * 4 + q) * C,
+                       x + (size_t)((2 * i + di) * res + (2 * j + dj)) * C, sizeof(float) * C);
+            }
+    float *nrm = (float *)malloc(sizeof(float) * (size_t)T2 * 4 * C);
+    layer_norm(W(h, "%s.norm.weight", prefix)->data, W(h, "%s.norm.bias", prefix)->data, cat, nrm, T2, 4 * C);
+    float *out = (float *)malloc(sizeof(float) * (size_t)T2 * 2 * C);
+    linear(W(h, "%s.reduction.weight", prefix), NULL, nrm, out, T2, 4 * C, 2 * C);
+    free(cat); free(nrm);
+    return out;
+}
+
+/* PatchBreakup.forward, skip_connection=True (diffusesg.py:374-403): [res*res,D] -> [(2res)^2, D/4] */
+static float *patch_breakup(dsgref *h, const char *prefix, const float *x, int res, int D) {
+    const int T = res * res, Co = D / 4, R = 2 * res;
+    float *y = (float *)malloc(sizeof(float) * (size_t)T * D);
+    float *n = (float *)malloc(sizeof(float) * (size_t)T * D);
+    linear(W(h, "%s.pre_linear.weight", prefix), NULL, x, y, T, D, D);
+    layer_norm(W(h, "%s.norm.weight", prefix)->data, W(h, "%s.norm.bias", prefix)->data, y, n, T, D);
+    float *sc = (float *)malloc(sizeof(float) * (size_t)4 * T * Co);
+    for (int i = 0; i < res; i++)
+        for (int j = 0; j < res; j++)
+            for (int q = 0; q < 4; q++) {
+                const int di = q & 1, dj = q >> 1; /* x_out[:,0::2,0::2]=x0, [1::2,0::2]=x1, [0::2,1::2]=x2, [1::2,1::2]=x3 */
+                memcpy(sc + (size_t)((2 * i + di) * R + (2 * j + dj)) * Co,
+                       n + ((size_t)(i * res + j) * 4 + q) * Co, sizeof(float) * Co);
+            }
+    float *pn = (float *)malloc(sizeof(float) * (size_t)4 * T * Co);
+    layer_norm(W(h, "%s.post_norm.weight", prefix)->data, W(h, "%s.post_norm.bias", prefix)->data, sc, pn, 4 * T, Co);
+    float *out = (float *)malloc(sizeof(float) * (size_t)4 * T * Co);
+    linear(W(h, "%s.post_linear.weight", prefix), NULL, pn, out, 4 * T, Co, Co);
+    free(y); free(n); free(sc); free(pn);
+    return out;
+}
+
+/* PositionalEmbedding + map_layer0/1 (diffusesg.py:507-513, 768-771) */
+static void noise_embedding(dsgref *h, float c_noise, float *emb /*[512]*/) {
+    const int E = h->E, half = E / 2;
+    float *pe = (float *)malloc(sizeof(float) * E);
+    for (int k = 0; k < half; k++) {
+        const float f = powf(1.0f / 10000.0f, (float)k / (float)half);
+        const float v = c_noise * f;
+        pe[k] = cosf(v);
+        pe[half + k] = sinf(v);
+    }
+    float *t0 = (float *)malloc(sizeof(float) * NOISE_EMB);
+    linear(W(h, "%s", "map_layer0.weight"), W(h, "%s", "map_layer0.bias")->data, pe, t0, 1, E, NOISE_EMB);
+    for (int i = 0; i < NOISE_EMB; i++) t0[i] = silu_f(t0[i]);
+    linear(W(h, "%s", "map_layer1.weight"), W(h, "%s", "map_layer1.bias")->data, t0, emb, 1, NOISE_EMB, NOISE_EMB);
+    for (int i = 0; i < NOISE_EMB; i++) emb[i] = silu_f(emb[i]);
+    free(pe); free(t0);
+}
+
+/* DiffuseSG.forward for ONE sample (diffusesg.py:765-830 with forward_features :739-763) */
+static void forward_one(dsgref *h, const float *adj, const float *node, const uint8_t *flags, float c_noise,
+                        const float *sc_adj, const float *sc_node, float *out_adj, float *out_node) {
+    const int N = h->N, Ca = h->c_adj, Cn = h->c_node, E = h->E, L = h->L, T0 = N * N;
+    float emb[NOISE_EMB];
+    noise_embedding(h, c_noise, emb);
+
+    /* input assembly (:784-802): channel order [sc_adj, adj, sc_node_row, node_row, sc_node_col, node_col] */
+    const int nsc = h->self_cond ? 2 : 1;
+    const int Cin = nsc * (Ca + 2 * Cn);
+    float *in = (float *)calloc((size_t)T0 * Cin, sizeof(float)); /* token-major [T0, Cin] */
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) {
+            float *r = in + (size_t)(i * N + j) * Cin;
+            int c = 0;
+            if (h->self_cond)
+                for (int a = 0; a < Ca; a++) r[c++] = sc_adj ? sc_adj[((size_t)a * N + i) * N + j] : 0.f;
+            for (int a = 0; a < Ca; a++) r[c++] = adj[((size_t)a * N + i) * N + j];
+            const float m = (flags[i] && flags[j]) ? 1.f : 0.f; /* mask_adjs on the node part only (:800) */
+            if (h->self_cond)
+                for (int a = 0; a < Cn; a++) r[c++] = m * (sc_node ? sc_node[(size_t)i * Cn + a] : 0.f);
+            for (int a = 0; a < Cn; a++) r[c++] = m * node[(size_t)i * Cn + a];
+            if (h->self_cond)
+                for (int a = 0; a < Cn; a++) r[c++] = m * (sc_node ? sc_node[(size_t)j * Cn + a] : 0.f);
+            for (int a = 0; a < Cn; a++) r[c++] = m * node[(size_t)j * Cn + a];
+        }
+
+    /* PatchEmbed (:562-577): 1x1 conv + LN + modulate */
+    float *x = (float *)malloc(sizeof(float) * (size_t)T0 * E);
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)T0 * E);
+    linear(W(h, "%s", "patch_embed.proj.weight"), W(h, "%s", "patch_embed.proj.bias")->data, in, tmp, T0, Cin, E);
+    layer_norm(W(h, "%s", "patch_embed.norm.weight")->data, W(h, "%s", "patch_embed.norm.bias")->data, tmp, x, T0, E);
+    modulate_silu(h, "patch_embed", emb, x, T0, E);
+    tap(h, "patch_embed", x, (int64_t)T0 * E);
+    free(in); free(tmp);
+
+    /* encoder (:745-748) */
+    float *skips[MAX_LAYERS];
+    char prefix[128], name[64];
+    int res = N, C = E;
+    for (int l = 0; l < L; l++) {
+        for (int j = 0; j < h->depths[l]; j++) {
+            snprintf(prefix, sizeof(prefix), "down_layers.%d.blocks.%d", l, j);
+            swin_block(h, prefix, emb, x, res, C, h->heads[l], h->ws, (j % 2 == 0) ? 0 : h->ws / 2);
+            snprintf(name, sizeof(name), "down%d.block%d", l, j);
+            tap(h, name, x, (int64_t)res * res * C);
+        }
+        if (l < L - 1) {
+            snprintf(prefix, sizeof(prefix), "down_layers.%d.downsample", l);
+            float *y = patch_merging(h, prefix, x, res, C);
+            free(x);
+            x = y; res /= 2; C *= 2;
+        }
+        snprintf(name, sizeof(name), "down%d", l);
+        tap(h, name, x, (int64_t)res * res * C);
+        skips[l] = (float *)malloc(sizeof(float) * (size_t)res * res * C);
+        memcpy(skips[l], x, sizeof(float) * (size_t)res * res * C);
+    }
+    /* decoder (:751-756): first up layer discards the deepest skip; others cat([x, skip]) then PatchBreakup */
+    for (int i = 0; i < L; i++) {
+        const int lvl = L - 1 - i;
+        if (i > 0) {
+            const int T = res * res;
+            float *cat = (float *)malloc(sizeof(float) * (size_t)T * 2 * C);
+            const float *sk = skips[lvl]; /* skips.pop(): after i pops the top is skips[L-1-i] */
+            for (int t = 0; t < T; t++) {
+                memcpy(cat + (size_t)t * 2 * C, x + (size_t)t * C, sizeof(float) * C);
+                memcpy(cat + (size_t)t * 2 * C + C, sk + (size_t)t * C, sizeof(float) * C);
+            }
+            snprintf(prefix, sizeof(prefix), "up_layers.%d.upsample", i);
+            float *y = patch_breakup(h, prefix, cat, res, 2 * C);
+            free(cat); free(x);
+            x = y; res *= 2; C /= 2;
+            snprintf(name, sizeof(name), "up%d.upsample", i);
+            tap(h, name, x, (int64_t)res * res * C);
+        }
+        for (int j = 0; j < h->depths[lvl]; j++) {
+            snprintf(prefix, sizeof(prefix), "up_layers.%d.blocks.%d", i, j);
+            swin_block(h, prefix, emb, x, res, C, h->heads[lvl], h->ws, (j % 2 == 0) ? 0 : h->ws / 2);
+            snprintf(name, sizeof(name), "up%d.block%d", i, j);
+            tap(h, name, x, (int64_t)res * res * C);
+        }
+    }
+    for (int l = 0; l < L; l++) free(skips[l]);
+
+    /* final norm + read_out (:758-761): ConvTranspose2d(k=1) weight is [in,out]; Conv2d weight is [out,in] */
+    float *y = (float *)malloc(sizeof(float) * (size_t)T0 * E);
+    float *z = (float *)malloc(sizeof(float) * (size_t)T0 * E);
+    layer_norm(W(h, "%s", "norm.weight")->data, W(h, "%s", "norm.bias")->data, x, y, T0, E);
+    linear_in_out(W(h, "%s", "read_out.0.weight")->data, W(h, "%s", "read_out.0.bias")->data, y, z, T0, E, E);
+    linear(W(h, "%s", "read_out.1.weight"), W(h, "%s", "read_out.1.bias")->data, z, y, T0, E, E);
+    linear(W(h, "%s", "read_out.2.weight"), W(h, "%s", "read_out.2.bias")->data, y, z, T0, E, E);
+    float *rep = z; /* shared_rep, token-major [T0,E] */
+    tap(h, "read_out", rep, (int64_t)T0 * E);
+
+    /* adjacency head (:806-809) */
+    float *ha = (float *)malloc(sizeof(float) * (size_t)T0 * E);
+    float *oa = (float *)malloc(sizeof(float) * (size_t)T0 * Ca);
+    linear(W(h, "%s", "readout_adj_mlp.fc1.weight"), W(h, "%s", "readout_adj_mlp.fc1.bias")->data, rep, ha, T0, E, E);
+    for (size_t i = 0; i < (size_t)T0 * E; i++) ha[i] = gelu_f(ha[i]);
+    linear(W(h, "%s", "readout_adj_mlp.fc2.weight"), W(h, "%s", "readout_adj_mlp.fc2.bias")->data, ha, oa, T0, E, Ca);
+    for (int a = 0; a < Ca; a++)
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++) /* mask_adjs (:825) */
+                out_adj[((size_t)a * N + i) * N + j] = (flags[i] && flags[j]) ? oa[(size_t)(i * N + j) * Ca + a] : 0.f;
+
+    /* node head (:812-818): masked mean over j, divided by N (padded size) */
+    float *pool = (float *)calloc((size_t)N * E, sizeof(float));
+    for (int i = 0; i < N; i++) {
+        if (!flags[i]) continue;
+        for (int j = 0; j < N; j++) {
+            if (!flags[j]) continue;
+            const float *r = rep + (size_t)(i * N + j) * E;
+            for (int e = 0; e < E; e++) pool[(size_t)i * E + e] += r[e];
+        }
+    }
+    for (size_t i = 0; i < (size_t)N * E; i++) pool[i] /= (float)N;
+    float *hn = (float *)malloc(sizeof(float) * (size_t)N * E);
+    linear(W(h, "%s", "readout_node_mlp.fc1.weight"), W(h, "%s", "readout_node_mlp.fc1.bias")->data, pool, hn, N, E, E);
+    for (size_t i = 0; i < (size_t)N * E; i++) hn[i] = gelu_f(hn[i]);
+    linear(W(h, "%s", "readout_node_mlp.fc2.weight"), W(h, "%s", "readout_node_mlp.fc2.bias")->data, hn, out_node, N, E, Cn);
+    for (int i = 0; i < N; i++) /* mask_nodes (:822) */
+        if (!flags[i]) for (int c = 0; c < Cn; c++) out_node[(size_t)i * Cn + c] = 0.f;
+
+    free(x); free(y); free(z); free(ha); free(oa); free(pool); free(hn);
+}
+
+/* DiffuseSG.forward for a batch.  sc_* may be NULL (zeros, diffusesg.py:791-793). */
+int dsgref_forward(dsgref *h, int B, const float *adj, const float *node, const uint8_t *flags, const float *c_noise,
+                   const float *sc_adj, const float *sc_node, float *out_adj, float *out_node) {
+    const size_t sa = (size_t)h->c_adj * h->N * h->N, sn = (size_t)h->N * h->c_node;
+    h->cur_B = B;
+    for (int b = 0; b < B; b++) {
+        h->cur_sample = b;
+        forward_one(h, adj + b * sa, node + b * sn, flags + (size_t)b * h->N, c_noise[b],
+                    sc_adj ? sc_adj + b * sa : NULL, sc_node ? sc_node + b * sn : NULL,
+                    out_adj + b * sa, out_node + b * sn);
+    }
+    h->nfe++;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* preconditioning: NodeAdjPrecond.forward (precond.py:65-110) with get_preconditioning_params 'edm'
+ * (objectives/edm.py:122-126).  `coin` = the outcome of `np.random.rand() < 0.5` (precond.py:90). */
+
+static void mask_adj_inplace(const dsgref *h, float *a, const uint8_t *flags) {
+    const int N = h->N;
+    for (int c = 0; c < h->c_adj; c++)
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++)
+                if (!(flags[i] && flags[j])) a[((size_t)c * N + i) * N + j] = 0.f;
+}
+static void mask_node_inplace(const dsgref *h, float *n, const uint8_t *flags) {
+    for (int i = 0; i < h->N; i++)
+        if (!flags[i]) for (int c = 0; c < h->c_node; c++) n[(size_t)i * h->c_node + c] = 0.f;
+}
+
+NO_FMA int dsgref_precond(dsgref *h, int B, const float *adj, const float *node, const uint8_t *flags, const float *sigmas,
+                   const float *sc_adj, const float *sc_node, int coin, float *out_adj, float *out_node) {
+    const int N = h->N;
+    const size_t sa = (size_t)h->c_adj * N * N, sn = (size_t)N * h->c_node;
+    const float sd = 0.5f; /* sigma_data */
+    float *xin = (float *)malloc(sizeof(float) * B * sa), *nin = (float *)malloc(sizeof(float) * B * sn);
+    float *cn = (float *)malloc(sizeof(float) * B);
+    float *fa = (float *)malloc(sizeof(float) * B * sa), *fn = (float *)malloc(sizeof(float) * B * sn);
+    float *sca = NULL, *scn = NULL;
+    for (int b = 0; b < B; b++) {
+        const float s = sigmas[b];
+        const float c_in = 1.0f / sqrtf(sd * sd + s * s);
+        cn[b] = logf(s) / 4.0f;
+        for (size_t i = 0; i < sa; i++) xin[b * sa + i] = c_in * adj[b * sa + i];
+        for (size_t i = 0; i < sn; i++) nin[b * sn + i] = c_in * node[b * sn + i];
+    }
+    const float *use_sca = sc_adj, *use_scn = sc_node;
+    if (h->self_cond && coin) { /* precond.py:90-98: extra forward whose D replaces the self-cond inputs */
+        sca = (float *)malloc(sizeof(float) * B * sa);
+        scn = (float *)malloc(sizeof(float) * B * sn);
+        dsgref_forward(h, B, xin, nin, flags, cn, sc_adj, sc_node, fa, fn);
+        for (int b = 0; b < B; b++) {
+            const float s = sigmas[b];
+            const float c_skip = (sd * sd) / (s * s + sd * sd);
+            const float c_out = s * sd / sqrtf(s * s + sd * sd);
+            for (size_t i = 0; i < sa; i++) sca[b * sa + i] = c_skip * adj[b * sa + i] + c_out * fa[b * sa + i];
+            for (size_t i = 0; i < sn; i++) scn[b * sn + i] = c_skip * node[b * sn + i] + c_out * fn[b * sn + i];
+            mask_adj_inplace(h, sca + b * sa, flags + (size_t)b * N);
+            mask_node_inplace(h, scn + b * sn, flags + (size_t)b * N);
+        }
+        use_sca = sca; use_scn = scn;
+    }
+    dsgref_forward(h, B, xin, nin, flags, cn, use_sca, use_scn, fa, fn);
+    for (int b = 0; b < B; b++) {
+        const float s = sigmas[b];
+        const float c_skip = (sd * sd) / (s * s + sd * sd);
+        const float c_out = s * sd / sqrtf(s * s + sd * sd);
+        for (size_t i = 0; i < sa; i++) out_adj[b * sa + i] = c_skip * adj[b * sa + i] + c_out * fa[b * sa + i];
+        for (size_t i = 0; i < sn; i++) out_node[b * sn + i] = c_skip * node[b * sn + i] + c_out * fn[b * sn + i];
+        mask_adj_inplace(h, out_adj + b * sa, flags + (size_t)b * N);
+        mask_node_inplace(h, out_node + b * sn, flags + (size_t)b * N);
+    }
+    free(xin); free(nin); free(cn); free(fa); free(fn); free(sca); free(scn);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* sampler: NodeAdjEDMSampler.sample (edm.py:291-445), schedule='linear', scaling='none' */
+
+typedef struct {
+    int32_t num_steps;
+    int32_t heun;        /* 1 = 'heun', 0 = 'euler' */
+    float S_churn, S_min, S_max, S_noise;
+    double sigma_min, sigma_max, rho;
+    int32_t max_steps;   /* >0: stop after this many steps (CPU-baseline timing of a bounded sample) */
+} dsgref_sampler_cfg;
+
+/* sigma_steps in fp64 (edm.py:84-88) */
+void dsgref_sigma_steps(const dsgref_sampler_cfg *c, double *out) {
+    const double a = pow(c->sigma_max, 1.0 / c->rho), b = pow(c->sigma_min, 1.0 / c->rho);
+    for (int i = 0; i < c->num_steps; i++) {
+        const double frac = (c->num_steps > 1) ? (double)i / (double)(c->num_steps - 1) : 0.0;
+        out[i] = pow(a + frac * (b - a), c->rho);
+    }
+}
+
+/*
+ * noise_adj [T,B,C_adj,N,N] / noise_node [T,B,N,C_node]: the N(0,1) draws of step i (edm.py:361-364);
+ * coins [n_precond_calls] u8: outcome of the coin of each preconditioned call, in call order;
+ * gt_* non-NULL: sanity-check mode (edm.py:372-377) -- the denoiser output is replaced by gt.
+ */
+NO_FMA int dsgref_sample(dsgref *h, const dsgref_sampler_cfg *c, int B, const uint8_t *flags,
+                  const float *init_adj, const float *init_node, const float *noise_adj, const float *noise_node,
+                  const uint8_t *coins, const float *gt_adj, const float *gt_node, float *out_adj, float *out_node) {
+    const int N = h->N, T = c->num_steps;
+    const size_t sa = (size_t)B * h->c_adj * N * N, sn = (size_t)B * N * h->c_node;
+    const size_t sa1 = sa / B, sn1 = sn / B;
+    double *sig = (double *)malloc(sizeof(double) * T);
+    dsgref_sigma_steps(c, sig);
+    float *t_steps = (float *)malloc(sizeof(float) * (T + 1));
+    for (int i = 0; i < T; i++) t_steps[i] = (float)sig[i]; /* round_sigma = identity; cast f64->f32 (:320-323) */
+    t_steps[T] = 0.f;
+    float *xa = (float *)malloc(sizeof(float) * sa), *xn = (float *)malloc(sizeof(float) * sn);
+    float *ha = (float *)malloc(sizeof(float) * sa), *hn = (float *)malloc(sizeof(float) * sn);
+    float *da = (float *)malloc(sizeof(float) * sa), *dn = (float *)malloc(sizeof(float) * sn);
+    float *d2a = (float *)malloc(sizeof(float) * sa), *d2n = (float *)malloc(sizeof(float) * sn);
+    float *dca = (float *)malloc(sizeof(float) * sa), *dcn = (float *)malloc(sizeof(float) * sn);
+    float *sca = (float *)malloc(sizeof(float) * sa), *scn = (float *)malloc(sizeof(float) * sn);
+    float *sig_b = (float *)malloc(sizeof(float) * B);
+    int have_sc = 0, call = 0;
+    for (size_t i = 0; i < sa; i++) xa[i] = init_adj[i] * t_steps[0]; /* :346-347 */
+    for (size_t i = 0; i < sn; i++) xn[i] = init_node[i] * t_steps[0];
+    const float gamma_on = fminf(c->S_churn / (float)T, sqrtf(2.0f) - 1.0f);
+    const int nsteps = (c->max_steps > 0 && c->max_steps < T) ? c->max_steps : T;
+    for (int i = 0; i < nsteps; i++) {
+        const float t_cur = t_steps[i], t_next = t_steps[i + 1];
+        const float gamma = (c->S_min <= t_cur && t_cur <= c->S_max) ? gamma_on : 0.f; /* :355 */
+        const float t_hat = t_cur + gamma * t_cur;                                      /* :356 */
+        const float nz = sqrtf(fmaxf(t_hat * t_hat - t_cur * t_cur, 0.f)) * c->S_noise; /* :361-364 */
+        for (size_t k = 0; k < sa; k++) ha[k] = xa[k] + nz * (noise_adj ? noise_adj[(size_t)i * sa + k] : 0.f);
+        for (size_t k = 0; k < sn; k++) hn[k] = xn[k] + nz * (noise_node ? noise_node[(size_t)i * sn + k] : 0.f);
+        for (int b = 0; b < B; b++) {
+            mask_adj_inplace(h, ha + b * sa1, flags + (size_t)b * N);
+            mask_node_inplace(h, hn + b * sn1, flags + (size_t)b * N);
+            sig_b[b] = t_hat;
+        }
+        const float hstep = t_next - t_hat; /* :369 */
+        if (gt_adj) { memcpy(da, gt_adj, sizeof(float) * sa); memcpy(dn, gt_node, sizeof(float) * sn); }
+        else dsgref_precond(h, B, ha, hn, flags, sig_b, have_sc ? sca : NULL, have_sc ? scn : NULL,
+                            coins ? coins[call++] : 0, da, dn);
+        for (int b = 0; b < B; b++) {
+            mask_adj_inplace(h, da + b * sa1, flags + (size_t)b * N);
+            mask_node_inplace(h, dn + b * sn1, flags + (size_t)b * N);
+        }
+        const float inv = 1.0f / t_hat; /* sigma_deriv/sigma with sigma(t)=t (:384-385) */
+        for (size_t k = 0; k < sa; k++) dca[k] = inv * ha[k] - inv * da[k];
+        for (size_t k = 0; k < sn; k++) dcn[k] = inv * hn[k] - inv * dn[k];
+        for (int b = 0; b < B; b++) {
+            mask_adj_inplace(h, dca + b * sa1, flags + (size_t)b * N);
+            mask_node_inplace(h, dcn + b * sn1, flags + (size_t)b * N);
+        }
+        const float t_prime = t_hat + hstep; /* alpha = 1 (:391) */
+        if (!c->heun || i == T - 1) {        /* :394-396 */
+            for (size_t k = 0; k < sa; k++) xa[k] = ha[k] + hstep * dca[k];
+            for (size_t k = 0; k < sn; k++) xn[k] = hn[k] + hstep * dcn[k];
+        } else {
+            /* stage 2 re-evaluates at (x_hat, sigma(t_hat)); only the self-cond inputs change (:400-405) */
+            if (!gt_adj) {
+                if (h->self_cond) { memcpy(sca, da, sizeof(float) * sa); memcpy(scn, dn, sizeof(float) * sn); have_sc = 1; }
+                dsgref_precond(h, B, ha, hn, flags, sig_b, have_sc ? sca : NULL, have_sc ? scn : NULL,
+                               coins ? coins[call++] : 0, d2a, d2n);
+            } else { memcpy(d2a, gt_adj, sizeof(float) * sa); memcpy(d2n, gt_node, sizeof(float) * sn); }
+            for (int b = 0; b < B; b++) {
+                mask_adj_inplace(h, d2a + b * sa1, flags + (size_t)b * N);
+                mask_node_inplace(h, d2n + b * sn1, flags + (size_t)b * N);
+            }
+            const float invp = 1.0f / t_prime; /* d_prime uses x_prime and t_prime (:414-417) */
+            for (size_t k = 0; k < sa; k++) {
+                const float xp = ha[k] + hstep * dca[k];
+                const float dp = invp * xp - invp * d2a[k];
+                xa[k] = ha[k] + hstep * (0.5f * dca[k] + 0.5f * dp);
+            }
+            for (size_t k = 0; k < sn; k++) {
+                const float xp = hn[k] + hstep * dcn[k];
+                const float dp = invp * xp - invp * d2n[k];
+                xn[k] = hn[k] + hstep * (0.5f * dcn[k] + 0.5f * dp);
+            }
+            memcpy(da, d2a, sizeof(float) * sa); memcpy(dn, d2n, sizeof(float) * sn);
+        }
+        for (int b = 0; b < B; b++) { /* :421-422 */
+            mask_adj_inplace(h, xa + b * sa1, flags + (size_t)b * N);
+            mask_node_inplace(h, xn + b * sn1, flags + (size_t)b * N);
+        }
+        if (h->self_cond) { memcpy(sca, da, sizeof(float) * sa); memcpy(scn, dn, sizeof(float) * sn); have_sc = 1; } /* :423-424 */
+    }
+    memcpy(out_adj, xa, sizeof(float) * sa);
+    memcpy(out_node, xn, sizeof(float) * sn);
+    free(sig); free(t_steps); free(xa); free(xn); free(ha); free(hn); free(da); free(dn); free(d2a); free(d2n);
+    free(dca); free(dcn); free(sca); free(scn); free(sig_b);
+    return 0;
+}

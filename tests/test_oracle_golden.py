@@ -1,0 +1,110 @@
+"""CPU: the ORACLE (oracle/dsg_ref.c) against the golden vectors produced by the reference's own
+Python modules (tools/gen_golden.py).  This is what pins the oracle (prompt ③)."""
+import numpy as np
+import pytest
+
+from diffusesg_amd import synth as Y
+from diffusesg_amd import weights as W
+from oracle.oracle import Oracle
+from util import FWD_RTOL, assert_close, load
+
+
+def make_oracle(cfg, seed=0):
+    return Oracle(cfg, W.synth_state_dict(cfg, seed))
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "nosc", "vg", "coco"])
+def test_forward_matches_reference(name):
+    cfg, flags, adj, node, sc_adj, sc_node = Y.fwd_case(name)
+    g = load(f"fwd_{name}.npz")
+    orc = make_oracle(cfg)
+    oa, on = orc.forward(adj, node, flags, Y.FWD_C_NOISE)
+    assert_close(oa, g["nosc_adj_out"], FWD_RTOL, f"{name} adj (self-cond None)")
+    assert_close(on, g["nosc_node_out"], FWD_RTOL, f"{name} node (self-cond None)")
+    if cfg.self_condition:
+        oa, on = orc.forward(adj, node, flags, Y.FWD_C_NOISE, sc_adj, sc_node)
+        assert_close(oa, g["sc_adj_out"], FWD_RTOL, f"{name} adj (self-cond)")
+        assert_close(on, g["sc_node_out"], FWD_RTOL, f"{name} node (self-cond)")
+    # padded rows / columns must be exactly zero
+    f = flags.astype(bool)
+    assert np.all(on[~f] == 0)
+    assert np.all(oa.transpose(0, 2, 3, 1)[~f] == 0) and np.all(oa.transpose(0, 3, 2, 1)[~f] == 0)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_forward_intermediates(name):
+    cfg, flags, adj, node, sc_adj, sc_node = Y.fwd_case(name)
+    g = load(f"fwd_{name}.npz")
+    keys = [k[len("inter/"):] for k in g.files if k.startswith("inter/")]
+    taps = {k: int(np.prod(g["inter/" + k].shape[1:])) for k in keys}
+    orc = make_oracle(cfg)
+    _, _, bufs = orc.forward(adj, node, flags, Y.FWD_C_NOISE, sc_adj, sc_node, taps=taps)
+    for k in keys:
+        ref = g["inter/" + k]
+        got = bufs[k].reshape(ref.shape[0], -1)
+        if k == "read_out":  # reference tensor is [B,C,H,W]; the oracle keeps token-major [T,C]
+            ref = ref.transpose(0, 2, 3, 1)
+        assert_close(got, ref.reshape(ref.shape[0], -1), FWD_RTOL, f"{name} {k}")
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "nosc"])
+def test_precond_matches_reference(name):
+    g = load(f"precond_{name}.npz")
+    orc = None
+    for si in range(3):
+        cfg, sigma, flags, adj, node, sc_adj, sc_node = Y.precond_case(name, si)
+        orc = orc or make_oracle(cfg)
+        sig = np.full((2,), sigma, np.float32)
+        for coin in (0, 1):
+            for with_sc in (0, 1):
+                da, dn = orc.precond(adj, node, flags, sig, sc_adj if with_sc else None,
+                                     sc_node if with_sc else None, coin=bool(coin))
+                key = f"s{si}_coin{coin}_sc{with_sc}"
+                assert_close(da, g[key + "_adj"], FWD_RTOL, f"{name} {key} adj")
+                assert_close(dn, g[key + "_node"], FWD_RTOL, f"{name} {key} node")
+
+
+@pytest.mark.parametrize("T", [50, 100, 256, 1000])
+def test_sigma_schedule(T):
+    g = load("sampler.npz")
+    np.testing.assert_allclose(Oracle.sigma_steps(T), g[f"sigma_steps_{T}"], rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("tag,T,solver,churn", Y.SAMPLER_RUNS)
+def test_sampler_trajectory(tag, T, solver, churn):
+    g = load("sampler.npz")
+    cfg = Y.CONFIGS["tiny"]()
+    flags, ia, inn, na, nn, coin_vals = Y.sampler_case(cfg, T, 4, Y.SAMPLER_VALID, 3, f"smp/{tag}", solver)
+    orc = make_oracle(cfg)
+    coins = (coin_vals < 0.5).astype(np.uint8)
+    oa, on = orc.sample(flags, ia, inn, na, nn, coins, num_steps=T, solver=solver, S_churn=churn)
+    # Trajectory tolerance: the per-forward bar compounded over a few steps (T=8) / stated looser bar (T=50)
+    tol = 1e-4 if T <= 8 else 1e-3
+    assert_close(oa, g[f"{tag}_adj"], tol, f"{tag} adj")
+    assert_close(on, g[f"{tag}_node"], tol, f"{tag} node")
+    expected_nfe = int(g[f"{tag}_coins_used"]) + int(coins[: int(g[f"{tag}_coins_used"])].sum())
+    assert orc.nfe == expected_nfe
+
+
+def test_sampler_no_self_cond():
+    g = load("sampler.npz")
+    cfg = Y.CONFIGS["nosc"]()
+    flags, ia, inn, na, nn, _ = Y.sampler_case(cfg, 8, 2, [8, 3], 3, "smp/nosc_t8")
+    orc = make_oracle(cfg)
+    oa, on = orc.sample(flags, ia, inn, na, nn, None, num_steps=8)
+    assert_close(oa, g["nosc_t8_adj"].reshape(oa.shape), 1e-4, "nosc adj")
+    assert_close(on, g["nosc_t8_node"].reshape(on.shape), 1e-4, "nosc node")
+    assert orc.nfe == 15  # no coin without self-conditioning: exactly 2T-1 forwards
+
+
+def test_sampler_known_answer():
+    """sanity-check mode (edm.py:372-377): with the denoiser replaced by GT the loop must return GT."""
+    g = load("sampler.npz")
+    cfg = Y.CONFIGS["tiny"]()
+    flags, ia, inn, na, nn, _ = Y.sampler_case(cfg, 8, 4, Y.SAMPLER_VALID, 3, "smp/gt")
+    gt_adj, gt_node = Y.gt_case(cfg, 4, Y.SAMPLER_VALID)
+    orc = make_oracle(cfg)
+    oa, on = orc.sample(flags, ia, inn, na, nn, None, gt_adj=gt_adj, gt_node=gt_node, num_steps=8)
+    assert np.abs(oa - gt_adj).max() < 1e-6 and np.abs(on - gt_node).max() < 1e-6
+    assert_close(oa, g["gt_adj"], 1e-6, "gt adj vs reference run")
+    assert orc.nfe == 0

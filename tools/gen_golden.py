@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the reference's own Python modules.
+
+DEV-CONTAINER ONLY.  /root/reference does not exist on the GPU box; nothing at run time
+(tests, smoke, bench) imports this script or the reference.  Only the small output
+vectors it writes are committed; every *input* is regenerated on demand from the portable
+generator in diffusesg_amd/weights.py (same seed / stream names as below).
+
+How the reference is imported (disclosed in DESIGN.md §3):
+  * `timm` is not installed in this image and the reference imports three helpers from it
+    (`DropPath`, `to_2tuple`, `trunc_normal_`; R/model/diffusesg/diffusesg.py:5).  None of
+    them touches the arithmetic of a forward pass here: weights are overwritten with the
+    portable generator's, `DropPath` is never instantiated (drop_path_rate=0,
+    R/utils/learning_utils.py:59) and `to_2tuple` only duplicates an int.  A three-symbol
+    in-process module object is registered so the import statement resolves.
+  * Randomness the reference draws internally is pinned, not changed: `torch.randn_like`
+    (churn noise, R/runner/mcmc_sampler/edm.py:361-364) and `numpy.random.rand` (the
+    self-conditioning coin, R/model/precond/precond.py:90) are temporarily replaced by
+    functions that replay portable-generator streams.
+
+Usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/DiffuseSG"
+sys.path.insert(0, REPO)
+
+from diffusesg_amd import spec as S          # noqa: E402
+from diffusesg_amd import weights as W       # noqa: E402
+from diffusesg_amd import synth as Y         # noqa: E402
+
+
+def _import_reference():
+    layers = types.ModuleType("timm.models.layers")
+    layers.to_2tuple = lambda x: tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+    layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    layers.DropPath = torch.nn.Identity
+    timm = types.ModuleType("timm")
+    models = types.ModuleType("timm.models")
+    timm.models, models.layers = models, layers
+    sys.modules.update({"timm": timm, "timm.models": models, "timm.models.layers": layers})
+    sys.path.insert(0, REF)
+    from model.diffusesg.diffusesg import DiffuseSG
+    from model.precond.precond import NodeAdjPrecond
+    from runner.mcmc_sampler.edm import NodeAdjEDMSampler
+    return DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler
+
+
+CONFIGS = Y.CONFIGS
+
+
+def build_ref_net(DiffuseSG, cfg, seed=0):
+    net = DiffuseSG(img_size=cfg.max_node_num, in_chans=cfg.c_adj + 2 * cfg.c_node,
+                    patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths),
+                    num_heads=[3, 6, 12, 24], window_size=cfg.window_size, mlp_ratio=4.,
+                    drop_rate=0., attn_drop_rate=0., drop_path_rate=0.0,
+                    self_condition=cfg.self_condition, symmetric_noise=False,
+                    out_chans_adj=cfg.c_adj, out_chans_node=cfg.c_node)
+    ref_sd = net.state_dict()
+    mine = W.synth_state_dict(cfg, seed)
+    # the layout in diffusesg_amd/spec.py must equal the reference's state_dict exactly
+    assert set(ref_sd.keys()) == set(mine.keys()), (set(ref_sd) ^ set(mine))
+    for k, v in ref_sd.items():
+        assert tuple(v.shape) == tuple(mine[k].shape), (k, v.shape, mine[k].shape)
+        if "relative_position_index" in k or "attn_mask" in k:
+            assert np.array_equal(v.numpy(), mine[k]), k   # constant buffers re-derived in spec.py
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in mine.items()}, strict=True)
+    net.eval()
+    return net
+
+
+case_inputs = Y.case_inputs
+
+
+def squeeze_like_ref(cfg, adj, node):
+    """The reference drops singleton channel dims (edm.py:281-288)."""
+    if cfg.c_adj == 1:
+        adj = adj[:, 0]
+    if cfg.c_node == 1:
+        node = node[..., 0]
+    return adj, node
+
+
+def t(x):
+    return None if x is None else torch.from_numpy(np.ascontiguousarray(x))
+
+
+VALID = Y.VALID
+
+
+def gen_forward(DiffuseSG, out):
+    """G1/G2: full DiffuseSG.forward, with per-module intermediates for the two smallest nets."""
+    for name, mk in CONFIGS.items():
+        cfg = mk()
+        net = build_ref_net(DiffuseSG, cfg)
+        B = 2
+        flags, adj, node, sc_adj, sc_node = case_inputs(cfg, B, VALID[name], 1, f"fwd/{name}")
+        c_noise = Y.FWD_C_NOISE[:B].copy()
+        res = {}
+        inter = {}
+        hooks = []
+        if name in ("tiny", "small"):
+            def mk_hook(key):
+                def h(_m, _i, o):
+                    inter[key] = o.detach().numpy().copy()
+                return h
+            hooks.append(net.patch_embed.register_forward_hook(mk_hook("patch_embed")))
+            for i, l in enumerate(net.down_layers):
+                for j, b in enumerate(l.blocks):
+                    hooks.append(b.register_forward_hook(mk_hook(f"down{i}.block{j}")))
+                hooks.append(l.register_forward_hook(mk_hook(f"down{i}")))
+            for i, l in enumerate(net.up_layers):
+                if l.upsample is not None:
+                    hooks.append(l.upsample.register_forward_hook(mk_hook(f"up{i}.upsample")))
+                for j, b in enumerate(l.blocks):
+                    hooks.append(b.register_forward_hook(mk_hook(f"up{i}.block{j}")))
+            hooks.append(net.read_out.register_forward_hook(mk_hook("read_out")))
+        a_in, n_in = squeeze_like_ref(cfg, adj, node)
+        sa_in, sn_in = squeeze_like_ref(cfg, sc_adj, sc_node)
+        with torch.no_grad():
+            if cfg.self_condition:
+                oa, on = net(t(a_in.copy()), t(n_in.copy()), t(flags), t(c_noise), t(sa_in.copy()), t(sn_in.copy()))
+                res["sc_adj_out"], res["sc_node_out"] = oa.numpy(), on.numpy()
+                for k, v in inter.items():
+                    res["inter/" + k] = v
+                inter.clear()
+            for h in hooks:
+                h.remove()
+            oa, on = net(t(a_in.copy()), t(n_in.copy()), t(flags), t(c_noise), None, None)
+            res["nosc_adj_out"], res["nosc_node_out"] = oa.numpy(), on.numpy()
+        res["c_noise"] = c_noise
+        res["valid"] = np.array(VALID[name])
+        np.savez_compressed(os.path.join(out, f"fwd_{name}.npz"), **res)
+        print(f"fwd_{name}: adj {res['nosc_adj_out'].shape} max|adj| "
+              f"{np.abs(res['nosc_adj_out']).max():.3f} params {S.num_parameters(cfg):,}")
+
+
+class _Replay:
+    def __init__(self, items):
+        self.items, self.i = list(items), 0
+
+    def pop(self):
+        v = self.items[self.i]
+        self.i += 1
+        return v
+
+
+def gen_precond(DiffuseSG, NodeAdjPrecond, out):
+    """G3: NodeAdjPrecond.forward at three sigmas, coin forced both ways."""
+    import model.precond.precond as P
+    for name in ("tiny", "small", "nosc"):
+        cfg = CONFIGS[name]()
+        net = build_ref_net(DiffuseSG, cfg)
+        pre = NodeAdjPrecond("edm", net, cfg.self_condition, symmetric_noise=False).eval()
+        res = {}
+        for si, sigma in enumerate((80.0, 1.5, 0.002)):
+            B = 2
+            flags, adj, node, sc_adj, sc_node = case_inputs(cfg, B, VALID[name], 2, f"pre/{name}/{si}",
+                                                            sigma_scale=float(np.sqrt(sigma ** 2 + 0.25)))
+            a_in, n_in = squeeze_like_ref(cfg, adj, node)
+            sa_in, sn_in = squeeze_like_ref(cfg, sc_adj, sc_node)
+            sig = np.full((B,), sigma, dtype=np.float32)
+            for coin in (0.9, 0.1):
+                for with_sc in (False, True):
+                    real = np.random.rand
+                    P.np.random.rand = lambda: coin
+                    try:
+                        with torch.no_grad():
+                            da, dn = pre(t(a_in.copy()), t(n_in.copy()), t(flags), t(sig),
+                                         t(sa_in.copy()) if with_sc else None,
+                                         t(sn_in.copy()) if with_sc else None)
+                    finally:
+                        P.np.random.rand = real
+                    key = f"s{si}_coin{int(coin < 0.5)}_sc{int(with_sc)}"
+                    res[key + "_adj"], res[key + "_node"] = da.numpy(), dn.numpy()
+        np.savez_compressed(os.path.join(out, f"precond_{name}.npz"), **res)
+        print(f"precond_{name}: {len(res)} arrays")
+
+
+def run_ref_sampler(NodeAdjEDMSampler, NodeAdjPrecond, DiffuseSG, cfg, *, T, B, valid, seed, tag,
+                    solver="heun", S_churn=40, gt=None, weight_seed=0):
+    import model.precond.precond as P
+    n = cfg.max_node_num
+    net = build_ref_net(DiffuseSG, cfg, weight_seed)
+    pre = NodeAdjPrecond("edm", net, cfg.self_condition, symmetric_noise=False).eval()
+    smp = NodeAdjEDMSampler(num_steps=T, solver=solver, S_churn=S_churn,
+                            clip_samples=True, clip_samples_min=-1.0, clip_samples_max=1.0,
+                            clip_samples_scope="x_0", dev="cpu", objective="edm",
+                            self_condition=cfg.self_condition, symmetric_noise=False)
+    flags, init_adj, init_node, noise_adj, noise_node, coin_vals = Y.sampler_case(cfg, T, B, valid, seed, tag, solver)
+    noise = []
+    for i in range(T):   # draw order inside one step: adjacency first, then nodes (edm.py:361-364)
+        noise.append(noise_adj[i])
+        noise.append(noise_node[i])
+    rn = _Replay(noise)
+    rc = _Replay(coin_vals)
+    ia, inn = squeeze_like_ref(cfg, init_adj, init_node)
+
+    def fake_randn_like(x, **kw):
+        v = rn.pop()
+        v = v.reshape(tuple(x.shape))
+        return torch.from_numpy(v.copy()).to(x.dtype)
+
+    real_rl, real_rand = torch.randn_like, P.np.random.rand
+    torch.randn_like = fake_randn_like
+    P.np.random.rand = lambda: float(rc.pop())
+    try:
+        kw = {}
+        if gt is not None:
+            ga, gn = squeeze_like_ref(cfg, gt[0], gt[1])
+            kw = dict(sanity_check_gt_adjs=t(ga.copy()), sanity_check_gt_nodes=t(gn.copy()))
+        adjs, nodes = smp.sample(pre, t(flags), init_adjs=t(ia.copy()), init_nodes=t(inn.copy()),
+                                 flag_node_multi_channel=True, flag_adj_multi_channel=True,
+                                 num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj, **kw)
+    finally:
+        torch.randn_like, P.np.random.rand = real_rl, real_rand
+    sigma_steps = smp.sigma_steps.numpy().copy()
+    return adjs.numpy(), nodes.numpy(), sigma_steps, rc.i
+
+
+def gen_sampler(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, out):
+    """G4/G5: short trajectories with replayed noise + coins, the known-answer run, sigma tables."""
+    res = {}
+    cfg = S.tiny_config()
+    for (tag, T, solver, churn) in Y.SAMPLER_RUNS:
+        a, nd, sig, used = run_ref_sampler(NodeAdjEDMSampler, NodeAdjPrecond, DiffuseSG, cfg, T=T, B=4,
+                                           valid=Y.SAMPLER_VALID, seed=3, tag=f"smp/{tag}", solver=solver,
+                                           S_churn=churn)
+        res[f"{tag}_adj"], res[f"{tag}_node"], res[f"{tag}_sigma_steps"] = a, nd, sig
+        res[f"{tag}_coins_used"] = np.array(used)
+        print(f"sampler {tag}: max|adj| {np.abs(a).max():.3f} coins used {used}")
+    # nosc config (no self-conditioning => no coin, no extra forward)
+    cfg2 = Y.nosc_config()
+    a, nd, sig, used = run_ref_sampler(NodeAdjEDMSampler, NodeAdjPrecond, DiffuseSG, cfg2, T=8, B=2,
+                                       valid=[8, 3], seed=3, tag="smp/nosc_t8")
+    res["nosc_t8_adj"], res["nosc_t8_node"] = a, nd
+    # known-answer test (R/runner/mcmc_sampler/edm.py:372-377): GT replaces the denoiser
+    B, n = 4, cfg.max_node_num
+    gt_adj, gt_node = Y.gt_case(cfg, B, Y.SAMPLER_VALID)
+    a, nd, _, _ = run_ref_sampler(NodeAdjEDMSampler, NodeAdjPrecond, DiffuseSG, cfg, T=8, B=B,
+                                  valid=Y.SAMPLER_VALID, seed=3, tag="smp/gt", gt=(gt_adj, gt_node))
+    res["gt_adj"], res["gt_node"] = a, nd
+    print("sanity-check run: max|out-GT| adj %.3e node %.3e" % (np.abs(a - gt_adj).max(), np.abs(nd - gt_node).max()))
+    for T in (50, 100, 256, 1000):
+        smp = NodeAdjEDMSampler(num_steps=T, clip_samples=True, clip_samples_min=-1.0, clip_samples_max=1.0,
+                                clip_samples_scope="x_0", dev="cpu", self_condition=True, symmetric_noise=False)
+        res[f"sigma_steps_{T}"] = smp.sigma_steps.numpy().copy()
+    np.savez_compressed(os.path.join(out, "sampler.npz"), **res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler = _import_reference()
+    if args.only in ("", "fwd"):
+        gen_forward(DiffuseSG, args.out)
+    if args.only in ("", "precond"):
+        gen_precond(DiffuseSG, NodeAdjPrecond, args.out)
+    if args.only in ("", "sampler"):
+        gen_sampler(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, args.out)
+
+
+if __name__ == "__main__":
+    main()
