@@ -1,0 +1,866 @@
+// dsg_api.cpp -- host side of libdsg.so: weight registry, the static launch plan of one network
+// forward, preconditioning, and the EDM reverse loop.  Implements include/dsg.h.
+//
+// Reference mapping (R/ = DiffuseSG/):
+//   forward plan      R/model/diffusesg/diffusesg.py:739-830
+//   preconditioning   R/model/precond/precond.py:65-110, R/runner/objectives/edm.py:122-126
+//   reverse loop      R/runner/mcmc_sampler/edm.py:291-445
+#include "../../include/dsg.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace dsg;
+
+#define NOISE_EMB 512
+
+namespace {
+
+struct DevTensor {
+    float *p = nullptr;
+    std::vector<int64_t> shape;
+    int64_t numel = 0;
+};
+
+struct WSpec {
+    std::string key;
+    std::vector<int64_t> shape;
+    bool is_index = false;  // relative_position_index: int64 constant, validated and dropped
+    bool is_mask = false;   // attn_mask: fp32 constant, accepted and dropped (re-derived)
+};
+
+struct BlockPlan {
+    std::string prefix;
+    int lvl, C, res, ws, shift, heads;
+    int aff_off;        // offset of this block's (scale,shift) in the concatenated affine output
+    float *biasT = nullptr;  // [nWt][heads][Wp][Wp]
+};
+
+struct Workspace {
+    int B = 0;
+    size_t bytes = 0;
+    std::vector<void *> allocs;
+    // network forward (fixed addresses: the captured graph reads/writes these)
+    float *in_adj, *in_node, *sc_adj, *sc_node, *c_noise, *f_adj, *f_node;
+    uint8_t *flags;
+    int *has_sc;
+    float *pe, *emb0, *emb, *aff, *tok_in, *x, *y, *qkv, *att, *hid, *stats, *pool, *hn;
+    float *skips[DSG_MAX_LAYERS];
+    // sampler state
+    float *x_adj, *x_node, *xh_adj, *xh_node, *sig;
+    float *d_adj[3], *d_node[3];
+    hipGraphExec_t graph = nullptr;
+    hipStream_t cap_stream = nullptr;
+};
+
+struct Tap { std::string name; float *dst; int64_t cap; };
+
+}  // namespace
+
+struct dsg_handle_s {
+    dsg_config cfg;
+    int N, Ca, Cn, E, L, Cin, Kp;
+    std::vector<WSpec> specs;
+    std::map<std::string, DevTensor> w;
+    bool finalized = false;
+    std::string err;
+    // derived
+    std::vector<BlockPlan> down[DSG_MAX_LAYERS], up[DSG_MAX_LAYERS];
+    float *aff_w = nullptr, *aff_b = nullptr;  // concatenated affine linears [aff_n, 512]
+    int aff_n = 0, pe_aff_off = 0;
+    float *pe_w = nullptr;      // patch_embed.proj padded to [E, Kp]
+    float *ro0_w = nullptr;     // read_out.0 transposed to [out,in]
+    std::vector<void *> derived_allocs;
+    std::map<int, std::unique_ptr<Workspace>> ws;
+    std::vector<Tap> taps;
+    dsg_sample_stats last_stats{};
+};
+
+namespace {
+
+int fail(dsg_handle h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(h, DSG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int level_window(const dsg_config &c, int lvl) {
+    const int r = c.max_node_num >> lvl;
+    return r <= c.window_size ? r : c.window_size;
+}
+int block_shift(const dsg_config &c, int lvl, int j) {
+    const int r = c.max_node_num >> lvl;
+    if (r <= c.window_size) return 0;
+    return (j % 2 == 0) ? 0 : c.window_size / 2;
+}
+
+void add_block_specs(std::vector<WSpec> &s, const std::string &p, int C, int heads, int ws, int res, int shift, int mr) {
+    const int64_t W = (int64_t)ws * ws;
+    s.push_back({p + ".affine.weight", {2 * C, NOISE_EMB}});
+    s.push_back({p + ".affine.bias", {2 * C}});
+    s.push_back({p + ".norm1.weight", {C}});
+    s.push_back({p + ".norm1.bias", {C}});
+    s.push_back({p + ".attn.relative_position_bias_table", {(2 * ws - 1) * (2 * ws - 1), heads}});
+    s.push_back({p + ".attn.relative_position_index", {W, W}, true, false});
+    s.push_back({p + ".attn.qkv.weight", {3 * C, C}});
+    s.push_back({p + ".attn.qkv.bias", {3 * C}});
+    s.push_back({p + ".attn.proj.weight", {C, C}});
+    s.push_back({p + ".attn.proj.bias", {C}});
+    s.push_back({p + ".norm2.weight", {C}});
+    s.push_back({p + ".norm2.bias", {C}});
+    s.push_back({p + ".mlp.fc1.weight", {mr * C, C}});
+    s.push_back({p + ".mlp.fc1.bias", {mr * C}});
+    s.push_back({p + ".mlp.fc2.weight", {C, mr * C}});
+    s.push_back({p + ".mlp.fc2.bias", {C}});
+    if (shift > 0) {
+        const int64_t nW = (int64_t)(res / ws) * (res / ws);
+        s.push_back({p + ".attn_mask", {nW, W, W}, false, true});
+    }
+}
+
+// The key list of DiffuseSG(...).state_dict() (diffusesg.py:587-720), same derivation as diffusesg_amd/spec.py
+void build_specs(dsg_handle h) {
+    const dsg_config &c = h->cfg;
+    const int E = c.embed_dim, L = c.num_layers, mr = c.mlp_ratio;
+    auto &s = h->specs;
+    s.push_back({"patch_embed.affine.weight", {2 * E, NOISE_EMB}});
+    s.push_back({"patch_embed.affine.bias", {2 * E}});
+    s.push_back({"patch_embed.proj.weight", {E, h->Cin, 1, 1}});
+    s.push_back({"patch_embed.proj.bias", {E}});
+    s.push_back({"patch_embed.norm.weight", {E}});
+    s.push_back({"patch_embed.norm.bias", {E}});
+    for (int l = 0; l < L; l++) {
+        const int C = E << l, res = c.max_node_num >> l, ws = level_window(c, l);
+        for (int j = 0; j < c.depths[l]; j++)
+            add_block_specs(s, "down_layers." + std::to_string(l) + ".blocks." + std::to_string(j), C, c.num_heads[l], ws, res,
+                            block_shift(c, l, j), mr);
+        if (l < L - 1) {
+            const std::string p = "down_layers." + std::to_string(l) + ".downsample";
+            s.push_back({p + ".reduction.weight", {2 * C, 4 * C}});
+            s.push_back({p + ".norm.weight", {4 * C}});
+            s.push_back({p + ".norm.bias", {4 * C}});
+        }
+    }
+    for (int i = 0; i < L; i++) {
+        const int l = L - 1 - i;
+        const int C = E << l, res = c.max_node_num >> l, ws = level_window(c, l);
+        if (i > 0) {
+            const int D = 4 * C;
+            const std::string p = "up_layers." + std::to_string(i) + ".upsample";
+            s.push_back({p + ".pre_linear.weight", {D, D}});
+            s.push_back({p + ".norm.weight", {D}});
+            s.push_back({p + ".norm.bias", {D}});
+            s.push_back({p + ".post_linear.weight", {D / 4, D / 4}});
+            s.push_back({p + ".post_norm.weight", {D / 4}});
+            s.push_back({p + ".post_norm.bias", {D / 4}});
+        }
+        for (int j = 0; j < c.depths[l]; j++)
+            add_block_specs(s, "up_layers." + std::to_string(i) + ".blocks." + std::to_string(j), C, c.num_heads[l], ws, res,
+                            block_shift(c, l, j), mr);
+    }
+    for (int k = 0; k < 3; k++) {
+        s.push_back({"read_out." + std::to_string(k) + ".weight", {E, E, 1, 1}});
+        s.push_back({"read_out." + std::to_string(k) + ".bias", {E}});
+    }
+    s.push_back({"map_layer0.weight", {NOISE_EMB, E}});
+    s.push_back({"map_layer0.bias", {NOISE_EMB}});
+    s.push_back({"map_layer1.weight", {NOISE_EMB, NOISE_EMB}});
+    s.push_back({"map_layer1.bias", {NOISE_EMB}});
+    s.push_back({"norm.weight", {E}});
+    s.push_back({"norm.bias", {E}});
+    s.push_back({"readout_adj_mlp.fc1.weight", {E, E}});
+    s.push_back({"readout_adj_mlp.fc1.bias", {E}});
+    s.push_back({"readout_adj_mlp.fc2.weight", {c.c_adj, E}});
+    s.push_back({"readout_adj_mlp.fc2.bias", {c.c_adj}});
+    s.push_back({"readout_node_mlp.fc1.weight", {E, E}});
+    s.push_back({"readout_node_mlp.fc1.bias", {E}});
+    s.push_back({"readout_node_mlp.fc2.weight", {c.c_node, E}});
+    s.push_back({"readout_node_mlp.fc2.bias", {c.c_node}});
+}
+
+std::string strip_prefix(const char *key) {
+    std::string k(key);
+    if (k.rfind("module.", 0) == 0) k = k.substr(7);   // DDP wrapper (sampling_utils.py:47-53)
+    if (k.rfind("model.", 0) == 0) k = k.substr(6);    // Precond.model (precond.py:15)
+    return k;
+}
+
+const float *WT(dsg_handle h, const std::string &key) { return h->w.at(key).p; }
+
+int dev_alloc(dsg_handle h, std::vector<void *> &pool, void **p, size_t bytes) {
+    HIP_TRY(h, hipMalloc(p, bytes ? bytes : 16));
+    pool.push_back(*p);
+    return 0;
+}
+
+// dense, key-major (transposed) bias+mask table of one block: [nWt][heads][Wp][Wp], entry [key][query]
+// bias: relative_position_bias_table[index[query][key]][head] (diffusesg.py:121-124)
+// mask: 0 / -100 between different shift regions (diffusesg.py:207-226); padded key slots: -1e30
+int build_bias_table(dsg_handle h, BlockPlan &bp) {
+    const int ws = bp.ws, W = ws * ws, Wp = ((W + 31) / 32) * 32, heads = bp.heads, res = bp.res, shift = bp.shift;
+    const int nwr = res / ws, nWt = shift > 0 ? nwr * nwr : 1;
+    const DevTensor &tab = h->w.at(bp.prefix + ".attn.relative_position_bias_table");
+    std::vector<float> table(tab.numel);
+    HIP_TRY(h, hipMemcpy(table.data(), tab.p, sizeof(float) * tab.numel, hipMemcpyDeviceToHost));
+    std::vector<float> out((size_t)nWt * heads * Wp * Wp, 0.f);
+    for (int w = 0; w < nWt; w++) {
+        const int wi = w / nwr, wj = w % nwr;
+        std::vector<int> region(W, 0);
+        if (shift > 0)
+            for (int p = 0; p < W; p++) {
+                const int si = wi * ws + p / ws, sj = wj * ws + p % ws;
+                const int ri = si < res - ws ? 0 : (si < res - shift ? 1 : 2);
+                const int rj = sj < res - ws ? 0 : (sj < res - shift ? 1 : 2);
+                region[p] = 3 * ri + rj;
+            }
+        for (int hd = 0; hd < heads; hd++) {
+            float *o = out.data() + ((size_t)w * heads + hd) * Wp * Wp;
+            for (int key = 0; key < Wp; key++)
+                for (int q = 0; q < Wp; q++) {
+                    float v;
+                    if (key >= W) v = -1.0e30f;
+                    else if (q >= W) v = 0.f;
+                    else {
+                        const int qi = q / ws, qj = q % ws, ki = key / ws, kj = key % ws;
+                        const int idx = (qi - ki + ws - 1) * (2 * ws - 1) + (qj - kj + ws - 1);
+                        v = table[(size_t)idx * heads + hd];
+                        if (shift > 0 && region[q] != region[key]) v += -100.0f;
+                    }
+                    o[(size_t)key * Wp + q] = v;
+                }
+        }
+    }
+    void *p;
+    if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * out.size())) return rc;
+    HIP_TRY(h, hipMemcpy(p, out.data(), sizeof(float) * out.size(), hipMemcpyHostToDevice));
+    bp.biasT = (float *)p;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *dsg_version(void) { return "dsg-gfx950 0.1 (fp32 MFMA)"; }
+
+int dsg_create(const dsg_config *cfg, dsg_handle *out) {
+    if (!cfg || !out) return DSG_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return DSG_ERR_HIP;  // no CPU fallback
+    auto h = new dsg_handle_s();
+    h->cfg = *cfg;
+    h->N = cfg->max_node_num; h->Ca = cfg->c_adj; h->Cn = cfg->c_node; h->E = cfg->embed_dim; h->L = cfg->num_layers;
+    auto bad = [&](const char *m) { delete h; (void)m; return DSG_ERR_INVALID; };
+    if (h->L < 1 || h->L > DSG_MAX_LAYERS) return bad("num_layers");
+    if (h->E % 32 != 0 || h->E < 64) return bad("embed_dim must be a multiple of 32");
+    if (cfg->mlp_ratio < 1 || h->N < 1 || h->Ca < 1 || h->Cn < 1) return bad("sizes");
+    if (h->N % (1 << (h->L - 1)) != 0) return bad("max_node_num not divisible by 2^(L-1)");
+    for (int l = 0; l < h->L; l++) {
+        const int C = h->E << l, res = h->N >> l, ws = level_window(*cfg, l);
+        if (cfg->num_heads[l] * 32 != C) return bad("head_dim must be 32");
+        if (res % ws != 0) return bad("resolution not divisible by window");
+        if (ws * ws > 128) return bad("window larger than 128 tokens");
+        if (C > 1536 || (l < h->L - 1 && 4 * C > 1536)) return bad("row wider than 1536 channels");
+    }
+    h->Cin = (cfg->self_condition ? 2 : 1) * (h->Ca + 2 * h->Cn);
+    h->Kp = ((h->Cin + 31) / 32) * 32;
+    build_specs(h);
+    *out = h;
+    return DSG_OK;
+}
+
+void dsg_destroy(dsg_handle h) {
+    if (!h) return;
+    for (auto &kv : h->w) (void)hipFree(kv.second.p);
+    for (void *p : h->derived_allocs) (void)hipFree(p);
+    for (auto &kv : h->ws) {
+        if (kv.second->graph) (void)hipGraphExecDestroy(kv.second->graph);
+        if (kv.second->cap_stream) (void)hipStreamDestroy(kv.second->cap_stream);
+        for (void *p : kv.second->allocs) (void)hipFree(p);
+    }
+    delete h;
+}
+
+const char *dsg_last_error(dsg_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int dsg_num_weight_keys(dsg_handle h) { return h ? (int)h->specs.size() : 0; }
+const char *dsg_weight_key(dsg_handle h, int32_t i) {
+    if (!h || i < 0 || i >= (int)h->specs.size()) return nullptr;
+    return h->specs[i].key.c_str();
+}
+
+int dsg_set_weight(dsg_handle h, const char *key, const void *data, const int64_t *shape, int32_t ndim, int32_t is_device) {
+    if (!h || !key || !data) return DSG_ERR_INVALID;
+    const std::string k = strip_prefix(key);
+    const WSpec *sp = nullptr;
+    for (auto &s : h->specs) if (s.key == k) { sp = &s; break; }
+    if (!sp) return fail(h, DSG_ERR_WEIGHTS, "unexpected key '%s'", key);
+    if ((int)sp->shape.size() != ndim) return fail(h, DSG_ERR_WEIGHTS, "rank mismatch for '%s'", key);
+    int64_t numel = 1;
+    for (int i = 0; i < ndim; i++) {
+        if (shape[i] != sp->shape[i]) return fail(h, DSG_ERR_WEIGHTS, "shape mismatch for '%s' (dim %d: %lld vs %lld)", key, i,
+                                                  (long long)shape[i], (long long)sp->shape[i]);
+        numel *= shape[i];
+    }
+    DevTensor &t = h->w[k];
+    if (sp->is_index || sp->is_mask) {  // constant buffers: re-derived by the library, only registered as present
+        t.numel = numel; t.shape = sp->shape;
+        return DSG_OK;
+    }
+    if (!t.p) HIP_TRY(h, hipMalloc((void **)&t.p, sizeof(float) * numel));
+    HIP_TRY(h, hipMemcpy(t.p, data, sizeof(float) * numel, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    t.numel = numel; t.shape = sp->shape;
+    h->finalized = false;
+    return DSG_OK;
+}
+
+int dsg_finalize_weights(dsg_handle h) {
+    if (!h) return DSG_ERR_INVALID;
+    for (auto &s : h->specs)
+        if (!h->w.count(s.key)) return fail(h, DSG_ERR_WEIGHTS, "missing key '%s' (strict load)", s.key.c_str());
+    for (void *p : h->derived_allocs) (void)hipFree(p);
+    h->derived_allocs.clear();
+    for (int l = 0; l < DSG_MAX_LAYERS; l++) { h->down[l].clear(); h->up[l].clear(); }
+    const dsg_config &c = h->cfg;
+    const int E = h->E, L = h->L;
+    // block plans + concatenated affine (all (scale,shift) linears of the net in one [aff_n,512] GEMM)
+    std::vector<std::string> aff_prefixes;
+    int off = 0;
+    h->pe_aff_off = off; aff_prefixes.push_back("patch_embed"); off += 2 * E;
+    auto mk = [&](const std::string &p, int l, int j) {
+        BlockPlan b;
+        b.prefix = p; b.lvl = l; b.C = E << l; b.res = c.max_node_num >> l; b.ws = level_window(c, l);
+        b.shift = block_shift(c, l, j); b.heads = c.num_heads[l]; b.aff_off = off;
+        aff_prefixes.push_back(p); off += 2 * b.C;
+        return b;
+    };
+    for (int l = 0; l < L; l++)
+        for (int j = 0; j < c.depths[l]; j++)
+            h->down[l].push_back(mk("down_layers." + std::to_string(l) + ".blocks." + std::to_string(j), l, j));
+    for (int i = 0; i < L; i++)
+        for (int j = 0; j < c.depths[L - 1 - i]; j++)
+            h->up[i].push_back(mk("up_layers." + std::to_string(i) + ".blocks." + std::to_string(j), L - 1 - i, j));
+    h->aff_n = off;
+    void *p;
+    if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * (size_t)off * NOISE_EMB)) return rc;
+    h->aff_w = (float *)p;
+    if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * (size_t)off)) return rc;
+    h->aff_b = (float *)p;
+    {
+        size_t o = 0;
+        for (auto &pre : aff_prefixes) {
+            const DevTensor &w = h->w.at(pre + ".affine.weight"), &b = h->w.at(pre + ".affine.bias");
+            HIP_TRY(h, hipMemcpy(h->aff_w + o * NOISE_EMB, w.p, sizeof(float) * w.numel, hipMemcpyDeviceToDevice));
+            HIP_TRY(h, hipMemcpy(h->aff_b + o, b.p, sizeof(float) * b.numel, hipMemcpyDeviceToDevice));
+            o += b.numel;
+        }
+    }
+    for (int l = 0; l < L; l++) {
+        for (auto &b : h->down[l]) if (int rc = build_bias_table(h, b)) return rc;
+        for (auto &b : h->up[l]) if (int rc = build_bias_table(h, b)) return rc;
+    }
+    // patch_embed.proj [E,Cin,1,1] -> [E,Kp] zero padded
+    {
+        std::vector<float> src((size_t)E * h->Cin), dst((size_t)E * h->Kp, 0.f);
+        HIP_TRY(h, hipMemcpy(src.data(), WT(h, "patch_embed.proj.weight"), sizeof(float) * src.size(), hipMemcpyDeviceToHost));
+        for (int e = 0; e < E; e++)
+            for (int k = 0; k < h->Cin; k++) dst[(size_t)e * h->Kp + k] = src[(size_t)e * h->Cin + k];
+        if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * dst.size())) return rc;
+        h->pe_w = (float *)p;
+        HIP_TRY(h, hipMemcpy(h->pe_w, dst.data(), sizeof(float) * dst.size(), hipMemcpyHostToDevice));
+    }
+    // read_out.0 is a ConvTranspose2d: weight [in,out,1,1] (diffusesg.py:706) -> [out,in]
+    {
+        std::vector<float> src((size_t)E * E), dst((size_t)E * E);
+        HIP_TRY(h, hipMemcpy(src.data(), WT(h, "read_out.0.weight"), sizeof(float) * src.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < E; i++)
+            for (int o = 0; o < E; o++) dst[(size_t)o * E + i] = src[(size_t)i * E + o];
+        if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * dst.size())) return rc;
+        h->ro0_w = (float *)p;
+        HIP_TRY(h, hipMemcpy(h->ro0_w, dst.data(), sizeof(float) * dst.size(), hipMemcpyHostToDevice));
+    }
+    // captured graphs bake weight pointers: drop them
+    for (auto &kv : h->ws)
+        if (kv.second->graph) { (void)hipGraphExecDestroy(kv.second->graph); kv.second->graph = nullptr; }
+    h->finalized = true;
+    return DSG_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+size_t per_sample_floats(dsg_handle h, std::vector<size_t> *parts = nullptr) {
+    const size_t T0 = (size_t)h->N * h->N, E = h->E;
+    const size_t sa = (size_t)h->Ca * h->N * h->N, sn = (size_t)h->N * h->Cn;
+    std::vector<size_t> v = {
+        sa, sn, sa, sn, sa, sn,                  // in, sc, f
+        (size_t)E, NOISE_EMB, NOISE_EMB, (size_t)h->aff_n,   // pe, emb0, emb, aff
+        T0 * h->Kp,                              // tok_in
+        T0 * E, T0 * E,                          // x, y
+        3 * T0 * E, T0 * E,                      // qkv, att
+        (size_t)h->cfg.mlp_ratio * T0 * E,       // hid
+        2 * T0,                                  // stats
+        (size_t)h->N * E, (size_t)h->N * E,      // pool, hn
+        sa, sn, sa, sn, 3 * sa, 3 * sn,          // sampler x, xhat, d[3]
+    };
+    size_t tot = 0;
+    for (auto s : v) tot += s;
+    for (int l = 0; l < h->L; l++) tot += (T0 * E) >> (l + 1 < h->L ? l + 1 : l);
+    if (parts) *parts = v;
+    return tot;
+}
+
+int get_workspace(dsg_handle h, int B, Workspace **out) {
+    auto it = h->ws.find(B);
+    if (it != h->ws.end()) { *out = it->second.get(); return 0; }
+    auto w = std::make_unique<Workspace>();
+    w->B = B;
+    const size_t T0 = (size_t)h->N * h->N, E = h->E;
+    const size_t sa = (size_t)B * h->Ca * h->N * h->N, sn = (size_t)B * h->N * h->Cn;
+    auto A = [&](float **p, size_t n) -> int {
+        void *q;
+        if (int rc = dev_alloc(h, w->allocs, &q, sizeof(float) * n)) return rc;
+        *p = (float *)q; w->bytes += sizeof(float) * n;
+        return 0;
+    };
+#define ALLOC(ptr, n) do { if (int rc = A(&(ptr), (n))) return rc; } while (0)
+    ALLOC(w->in_adj, sa); ALLOC(w->in_node, sn); ALLOC(w->sc_adj, sa); ALLOC(w->sc_node, sn);
+    ALLOC(w->f_adj, sa); ALLOC(w->f_node, sn); ALLOC(w->c_noise, B); ALLOC(w->sig, B);
+    ALLOC(w->pe, (size_t)B * E); ALLOC(w->emb0, (size_t)B * NOISE_EMB); ALLOC(w->emb, (size_t)B * NOISE_EMB);
+    ALLOC(w->aff, (size_t)B * h->aff_n);
+    ALLOC(w->tok_in, (size_t)B * T0 * h->Kp);
+    ALLOC(w->x, (size_t)B * T0 * E); ALLOC(w->y, (size_t)B * T0 * E);
+    ALLOC(w->qkv, (size_t)B * 3 * T0 * E); ALLOC(w->att, (size_t)B * T0 * E);
+    ALLOC(w->hid, (size_t)B * h->cfg.mlp_ratio * T0 * E);
+    ALLOC(w->stats, (size_t)B * 2 * T0);
+    ALLOC(w->pool, (size_t)B * h->N * E); ALLOC(w->hn, (size_t)B * h->N * E);
+    for (int l = 0; l < h->L; l++) ALLOC(w->skips[l], ((size_t)B * T0 * E) >> (l + 1 < h->L ? l + 1 : l));
+    ALLOC(w->x_adj, sa); ALLOC(w->x_node, sn); ALLOC(w->xh_adj, sa); ALLOC(w->xh_node, sn);
+    for (int k = 0; k < 3; k++) { ALLOC(w->d_adj[k], sa); ALLOC(w->d_node[k], sn); }
+#undef ALLOC
+    void *q;
+    if (int rc = dev_alloc(h, w->allocs, &q, (size_t)B * h->N)) return rc;
+    w->flags = (uint8_t *)q;
+    if (int rc = dev_alloc(h, w->allocs, &q, 16)) return rc;
+    w->has_sc = (int *)q;
+    *out = w.get();
+    h->ws[B] = std::move(w);
+    return 0;
+}
+
+void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStream_t s) {
+    for (auto &t : h->taps)
+        if (t.name == name && (int64_t)numel <= t.cap)
+            (void)hipMemcpyAsync(t.dst, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, s);
+}
+
+// One Swin block (diffusesg.py:232-277) on x [B*T, C] in place.
+void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
+    const int B = w->B, T = b.res * b.res, C = b.C, M = B * T, Hd = h->cfg.mlp_ratio * C;
+    const std::string &p = b.prefix;
+    // x <- silu(shift + x*(1+scale)) (also the shortcut), LayerNorm-1 statistics
+    launch_mod_stats(w->x, w->aff, h->aff_n, b.aff_off, w->stats, B, T, C, s);
+    GemmArgs g;
+    g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M;
+    g.ln_stats = w->stats; g.ln_g = WT(h, p + ".norm1.weight"); g.ln_b = WT(h, p + ".norm1.bias");
+    g.W = WT(h, p + ".attn.qkv.weight"); g.bias = WT(h, p + ".attn.qkv.bias"); g.N = 3 * C;
+    g.C = w->qkv; g.ldc = 3 * C;
+    launch_gemm(g, s);
+    WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
+    launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s);
+    g = GemmArgs();
+    g.A = w->att; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = C;
+    g.W = WT(h, p + ".attn.proj.weight"); g.bias = WT(h, p + ".attn.proj.bias");
+    g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
+    launch_gemm(g, s);
+    launch_ln_stats(w->x, w->stats, M, C, s);
+    g = GemmArgs();
+    g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = Hd;
+    g.ln_stats = w->stats; g.ln_g = WT(h, p + ".norm2.weight"); g.ln_b = WT(h, p + ".norm2.bias");
+    g.W = WT(h, p + ".mlp.fc1.weight"); g.bias = WT(h, p + ".mlp.fc1.bias"); g.act = ACT_GELU;
+    g.C = w->hid; g.ldc = Hd;
+    launch_gemm(g, s);
+    g = GemmArgs();
+    g.A = w->hid; g.lda = Hd; g.K1 = Hd; g.K = Hd; g.M = M; g.N = C;
+    g.W = WT(h, p + ".mlp.fc2.weight"); g.bias = WT(h, p + ".mlp.fc2.bias");
+    g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
+    launch_gemm(g, s);
+}
+
+// DiffuseSG.forward on the workspace's fixed buffers: (in_adj,in_node,sc_*,flags,c_noise) -> (f_adj,f_node)
+void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
+    const dsg_config &c = h->cfg;
+    const int B = w->B, N = h->N, E = h->E, L = h->L, T0 = N * N;
+    char name[64];
+    // noise embedding (diffusesg.py:768-771) and every block's (scale,shift) in one GEMM
+    launch_noise_pe(w->c_noise, w->pe, B, E, s);
+    GemmArgs g;
+    g.A = w->pe; g.lda = E; g.K1 = E; g.K = E; g.M = B; g.N = NOISE_EMB; g.act = ACT_SILU;
+    g.W = WT(h, "map_layer0.weight"); g.bias = WT(h, "map_layer0.bias"); g.C = w->emb0; g.ldc = NOISE_EMB;
+    launch_gemm(g, s);
+    g.A = w->emb0; g.lda = NOISE_EMB; g.K1 = NOISE_EMB; g.K = NOISE_EMB;
+    g.W = WT(h, "map_layer1.weight"); g.bias = WT(h, "map_layer1.bias"); g.C = w->emb;
+    launch_gemm(g, s);
+    g = GemmArgs();
+    g.A = w->emb; g.lda = NOISE_EMB; g.K1 = NOISE_EMB; g.K = NOISE_EMB; g.M = B; g.N = h->aff_n;
+    g.W = h->aff_w; g.bias = h->aff_b; g.C = w->aff; g.ldc = h->aff_n;
+    launch_gemm(g, s);
+    // input assembly + PatchEmbed (diffusesg.py:784-802, 562-577)
+    launch_assemble(w->in_adj, w->in_node, w->sc_adj, w->sc_node, w->has_sc, w->flags, w->tok_in, B, N, h->Ca, h->Cn,
+                    c.self_condition, h->Kp, s);
+    g = GemmArgs();
+    g.A = w->tok_in; g.lda = h->Kp; g.K1 = h->Kp; g.K = h->Kp; g.M = B * T0; g.N = E;
+    g.W = h->pe_w; g.bias = WT(h, "patch_embed.proj.bias"); g.C = w->y; g.ldc = E;
+    launch_gemm(g, s);
+    launch_ln_mod(w->y, WT(h, "patch_embed.norm.weight"), WT(h, "patch_embed.norm.bias"), w->aff, h->aff_n, h->pe_aff_off,
+                  w->x, B, T0, E, s);
+    tap(h, "patch_embed", w->x, (size_t)B * T0 * E, s);
+    // encoder (diffusesg.py:745-748)
+    for (int l = 0; l < L; l++) {
+        const int C = E << l, res = N >> l, T = res * res;
+        for (size_t j = 0; j < h->down[l].size(); j++) {
+            run_block(h, w, h->down[l][j], s);
+            snprintf(name, sizeof(name), "down%d.block%d", l, (int)j);
+            tap(h, name, w->x, (size_t)B * T * C, s);
+        }
+        if (l < L - 1) {
+            const std::string p = "down_layers." + std::to_string(l) + ".downsample";
+            launch_merge_ln(w->x, WT(h, p + ".norm.weight"), WT(h, p + ".norm.bias"), w->y, B, res, C, s);
+            g = GemmArgs();
+            g.A = w->y; g.lda = 4 * C; g.K1 = 4 * C; g.K = 4 * C; g.M = B * T / 4; g.N = 2 * C;
+            g.W = WT(h, p + ".reduction.weight"); g.C = w->x; g.ldc = 2 * C; g.C2 = w->skips[l]; g.ldc2 = 2 * C;
+            launch_gemm(g, s);
+        }
+        snprintf(name, sizeof(name), "down%d", l);
+        tap(h, name, w->x, l < L - 1 ? (size_t)B * (T / 4) * 2 * C : (size_t)B * T * C, s);
+        // the deepest level's skip is popped and discarded by the first up layer (diffusesg.py:754-755)
+    }
+    // decoder (diffusesg.py:751-756)
+    for (int i = 0; i < L; i++) {
+        const int l = L - 1 - i, C = E << l, res = N >> l, T = res * res;
+        if (i > 0) {
+            const std::string p = "up_layers." + std::to_string(i) + ".upsample";
+            const int D = 4 * C, Tc = T / 4;  // coarse tokens, concatenated width
+            g = GemmArgs();                   // pre_linear on cat([x, skip]) without materialising the concat
+            g.A = w->x; g.lda = D / 2; g.K1 = D / 2; g.A2 = w->skips[l]; g.lda2 = D / 2; g.K = D; g.M = B * Tc; g.N = D;
+            g.W = WT(h, p + ".pre_linear.weight"); g.C = w->hid; g.ldc = D;
+            launch_gemm(g, s);
+            launch_breakup_ln(w->hid, WT(h, p + ".norm.weight"), WT(h, p + ".norm.bias"), WT(h, p + ".post_norm.weight"),
+                              WT(h, p + ".post_norm.bias"), w->y, B, res / 2, D, s);
+            g = GemmArgs();
+            g.A = w->y; g.lda = C; g.K1 = C; g.K = C; g.M = B * T; g.N = C;
+            g.W = WT(h, p + ".post_linear.weight"); g.C = w->x; g.ldc = C;
+            launch_gemm(g, s);
+            snprintf(name, sizeof(name), "up%d.upsample", i);
+            tap(h, name, w->x, (size_t)B * T * C, s);
+        }
+        for (size_t j = 0; j < h->up[i].size(); j++) {
+            run_block(h, w, h->up[i][j], s);
+            snprintf(name, sizeof(name), "up%d.block%d", i, (int)j);
+            tap(h, name, w->x, (size_t)B * T * C, s);
+        }
+    }
+    // final norm + read_out (diffusesg.py:758-761)
+    const int M0 = B * T0;
+    launch_ln_stats(w->x, w->stats, M0, E, s);
+    g = GemmArgs();
+    g.A = w->x; g.lda = E; g.K1 = E; g.K = E; g.M = M0; g.N = E;
+    g.ln_stats = w->stats; g.ln_g = WT(h, "norm.weight"); g.ln_b = WT(h, "norm.bias");
+    g.W = h->ro0_w; g.bias = WT(h, "read_out.0.bias"); g.C = w->y; g.ldc = E;
+    launch_gemm(g, s);
+    g = GemmArgs();
+    g.A = w->y; g.lda = E; g.K1 = E; g.K = E; g.M = M0; g.N = E;
+    g.W = WT(h, "read_out.1.weight"); g.bias = WT(h, "read_out.1.bias"); g.C = w->att; g.ldc = E;
+    launch_gemm(g, s);
+    g.A = w->att; g.W = WT(h, "read_out.2.weight"); g.bias = WT(h, "read_out.2.bias"); g.C = w->y;
+    launch_gemm(g, s);  // y = shared_rep, token-major
+    tap(h, "read_out", w->y, (size_t)M0 * E, s);
+    // adjacency head (diffusesg.py:806-809, :825)
+    g.A = w->y; g.W = WT(h, "readout_adj_mlp.fc1.weight"); g.bias = WT(h, "readout_adj_mlp.fc1.bias"); g.act = ACT_GELU;
+    g.C = w->att;
+    launch_gemm(g, s);
+    launch_head_adj(w->att, WT(h, "readout_adj_mlp.fc2.weight"), WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, B, N, E,
+                    h->Ca, s);
+    // node head (diffusesg.py:812-822)
+    launch_pool(w->y, w->flags, w->pool, B, N, E, s);
+    g = GemmArgs();
+    g.A = w->pool; g.lda = E; g.K1 = E; g.K = E; g.M = B * N; g.N = E; g.act = ACT_GELU;
+    g.W = WT(h, "readout_node_mlp.fc1.weight"); g.bias = WT(h, "readout_node_mlp.fc1.bias"); g.C = w->hn; g.ldc = E;
+    launch_gemm(g, s);
+    launch_head_node(w->hn, WT(h, "readout_node_mlp.fc2.weight"), WT(h, "readout_node_mlp.fc2.bias"), w->flags, w->f_node, B, N,
+                     E, h->Cn, s);
+}
+
+// run forward_fixed either eagerly or by replaying a captured graph
+int run_forward(dsg_handle h, Workspace *w, bool use_graph, hipStream_t s) {
+    if (!use_graph || !h->taps.empty()) { forward_fixed(h, w, s); return 0; }
+    if (!w->graph) {
+        if (!w->cap_stream) HIP_TRY(h, hipStreamCreateWithFlags(&w->cap_stream, hipStreamNonBlocking));
+        hipGraph_t graph;
+        HIP_TRY(h, hipStreamBeginCapture(w->cap_stream, hipStreamCaptureModeThreadLocal));
+        forward_fixed(h, w, w->cap_stream);
+        HIP_TRY(h, hipStreamEndCapture(w->cap_stream, &graph));
+        hipError_t e = hipGraphInstantiate(&w->graph, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { w->graph = nullptr; return fail(h, DSG_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+    }
+    HIP_TRY(h, hipGraphLaunch(w->graph, s));
+    h->last_stats.graph_replays++;
+    return 0;
+}
+
+Dims dims_of(dsg_handle h, int B) { return Dims{B, h->N, h->Ca, h->Cn}; }
+
+int check_ready(dsg_handle h, int B) {
+    if (!h) return DSG_ERR_INVALID;
+    if (!h->finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
+    if (B < 1) return fail(h, DSG_ERR_INVALID, "batch must be >= 1");
+    return 0;
+}
+
+// stage caller tensors into the fixed forward inputs
+int stage_inputs(dsg_handle h, Workspace *w, const float *adj, const float *node, const uint8_t *flags, const float *sc_adj,
+                 const float *sc_node, hipStream_t s) {
+    const size_t sa = sizeof(float) * (size_t)w->B * h->Ca * h->N * h->N, sn = sizeof(float) * (size_t)w->B * h->N * h->Cn;
+    if (adj) HIP_TRY(h, hipMemcpyAsync(w->in_adj, adj, sa, hipMemcpyDeviceToDevice, s));
+    if (node) HIP_TRY(h, hipMemcpyAsync(w->in_node, node, sn, hipMemcpyDeviceToDevice, s));
+    if (flags) HIP_TRY(h, hipMemcpyAsync(w->flags, flags, (size_t)w->B * h->N, hipMemcpyDeviceToDevice, s));
+    const int has = (sc_adj && sc_node && h->cfg.self_condition) ? 1 : 0;
+    if (has) {
+        if (sc_adj != w->sc_adj) HIP_TRY(h, hipMemcpyAsync(w->sc_adj, sc_adj, sa, hipMemcpyDeviceToDevice, s));
+        if (sc_node != w->sc_node) HIP_TRY(h, hipMemcpyAsync(w->sc_node, sc_node, sn, hipMemcpyDeviceToDevice, s));
+    }
+    HIP_TRY(h, hipMemsetAsync(w->has_sc, 0, 16, s));
+    if (has) HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)w->has_sc, 1, 1, s));
+    return 0;
+}
+
+// NodeAdjPrecond.forward on workspace state: x (xh_adj/xh_node), sigmas (w->sig) -> D (dst), optionally
+// mirrored into the fixed self-cond input of the next forward.  sc: current self-cond or null.
+int precond_core(dsg_handle h, Workspace *w, CStatePtrs x, const float *sc_adj, const float *sc_node, bool coin, StatePtrs dst,
+                 bool use_graph, hipStream_t s, int64_t *nfe) {
+    const Dims d = dims_of(h, w->B);
+    launch_precond_in(x, w->sig, StatePtrs{w->in_adj, w->in_node}, w->c_noise, d, s);
+    if (int rc = stage_inputs(h, w, nullptr, nullptr, nullptr, sc_adj, sc_node, s)) return rc;
+    if (h->cfg.self_condition && coin) {  // precond.py:90-98
+        if (int rc = run_forward(h, w, use_graph, s)) return rc;
+        (*nfe)++;
+        // the D of the extra pass becomes the self-cond input (written straight into the fixed sc buffers)
+        launch_precond_out(x, CStatePtrs{w->f_adj, w->f_node}, w->sig, w->flags, StatePtrs{w->sc_adj, w->sc_node},
+                           StatePtrs{nullptr, nullptr}, d, s);
+        HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)w->has_sc, 1, 1, s));
+    }
+    if (int rc = run_forward(h, w, use_graph, s)) return rc;
+    (*nfe)++;
+    launch_precond_out(x, CStatePtrs{w->f_adj, w->f_node}, w->sig, w->flags, dst, StatePtrs{nullptr, nullptr}, d, s);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dsg_workspace_bytes(dsg_handle h, int32_t B) {
+    if (!h || !h->finalized || B < 1) return 0;
+    return sizeof(float) * per_sample_floats(h) * (size_t)B + (size_t)B * h->N + 16;
+}
+
+int dsg_debug_tap(dsg_handle h, const char *stage, float *dst, int64_t capacity) {
+    if (!h || !stage || !dst) return DSG_ERR_INVALID;
+    h->taps.push_back({stage, dst, capacity});
+    return DSG_OK;
+}
+void dsg_debug_clear_taps(dsg_handle h) { if (h) h->taps.clear(); }
+
+int dsg_denoise(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, const float *noise_labels,
+                const float *sc_adj, const float *sc_node, float *out_adj, float *out_node, void *stream) {
+    if (int rc = check_ready(h, B)) return rc;
+    if (!adj || !node || !flags || !noise_labels || !out_adj || !out_node) return fail(h, DSG_ERR_INVALID, "null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace *w;
+    if (int rc = get_workspace(h, B, &w)) return rc;
+    if (int rc = stage_inputs(h, w, adj, node, flags, sc_adj, sc_node, s)) return rc;
+    HIP_TRY(h, hipMemcpyAsync(w->c_noise, noise_labels, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    if (int rc = run_forward(h, w, false, s)) return rc;
+    const size_t sa = sizeof(float) * (size_t)B * h->Ca * h->N * h->N, sn = sizeof(float) * (size_t)B * h->N * h->Cn;
+    HIP_TRY(h, hipMemcpyAsync(out_adj, w->f_adj, sa, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(out_node, w->f_node, sn, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipGetLastError());
+    return DSG_OK;
+}
+
+int dsg_precond(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, const float *sigmas,
+                const float *sc_adj, const float *sc_node, int32_t coin, float *out_adj, float *out_node, void *stream) {
+    if (int rc = check_ready(h, B)) return rc;
+    if (!adj || !node || !flags || !sigmas || !out_adj || !out_node) return fail(h, DSG_ERR_INVALID, "null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace *w;
+    if (int rc = get_workspace(h, B, &w)) return rc;
+    HIP_TRY(h, hipMemcpyAsync(w->flags, flags, (size_t)B * h->N, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(w->sig, sigmas, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
+    int64_t nfe = 0;
+    if (int rc = precond_core(h, w, CStatePtrs{adj, node}, sc_adj, sc_node, coin != 0, StatePtrs{out_adj, out_node}, false, s, &nfe))
+        return rc;
+    HIP_TRY(h, hipGetLastError());
+    return DSG_OK;
+}
+
+// Host-side schedule.  Mirrors the reference's fp32 scalar-tensor arithmetic op by op (edm.py:318-323,
+// :355-369); this file is compiled with -ffp-contract=off so no product is fused into a subtraction.
+int dsg_sigma_schedule(const dsg_sampler_cfg *c, double *sigma_steps, float *t_hat, float *noise_coef, float *h_step) {
+    if (!c || c->num_steps < 1) return DSG_ERR_INVALID;
+    const int T = c->num_steps;
+    std::vector<float> t(T + 1);
+    const double a = std::pow(c->sigma_max, 1.0 / c->rho), b = std::pow(c->sigma_min, 1.0 / c->rho);
+    for (int i = 0; i < T; i++) {
+        const double frac = T > 1 ? (double)i / (double)(T - 1) : 0.0;
+        const double sg = std::pow(a + frac * (b - a), c->rho);
+        if (sigma_steps) sigma_steps[i] = sg;
+        t[i] = (float)sg;
+    }
+    t[T] = 0.f;
+    // python: min(S_churn / num_steps, np.sqrt(2) - 1) in double, cast to fp32 when multiplied with t_cur
+    const float gamma_on = (float)std::fmin((double)c->S_churn / (double)T, std::sqrt(2.0) - 1.0);
+    for (int i = 0; i < T; i++) {
+        const float tc = t[i];
+        const float gamma = (c->S_min <= tc && tc <= c->S_max) ? gamma_on : 0.f;
+        volatile float gt = gamma * tc;
+        volatile float th = tc + gt;
+        volatile float th2 = th * th, tc2 = tc * tc;
+        volatile float diff = th2 - tc2;
+        volatile float rt = std::sqrt(diff > 0.f ? diff : 0.f);
+        volatile float nz = rt * c->S_noise;
+        if (t_hat) t_hat[i] = th;
+        if (noise_coef) noise_coef[i] = nz;
+        if (h_step) h_step[i] = t[i + 1] - th;
+    }
+    return DSG_OK;
+}
+
+int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_t *flags, const float *init_adj,
+               const float *init_node, const float *noise_adj, const float *noise_node, const uint8_t *coins, uint64_t seed,
+               const float *gt_adj, const float *gt_node, const int32_t *snap_steps, int32_t n_snap, float *snap_adj,
+               float *snap_node, float *out_adj, float *out_node, dsg_sample_stats *stats, void *stream) {
+    if (int rc = check_ready(h, B)) return rc;
+    if (!cfg || !flags || !out_adj || !out_node) return fail(h, DSG_ERR_INVALID, "null argument");
+    if ((init_adj == nullptr) != (init_node == nullptr)) return fail(h, DSG_ERR_INVALID, "init_adj/init_node must both be given");
+    if ((noise_adj == nullptr) != (noise_node == nullptr)) return fail(h, DSG_ERR_INVALID, "noise_adj/noise_node must both be given");
+    if ((gt_adj == nullptr) != (gt_node == nullptr)) return fail(h, DSG_ERR_INVALID, "gt_adj/gt_node must both be given");
+    const int T = cfg->num_steps;
+    if (T < 1) return fail(h, DSG_ERR_INVALID, "num_steps < 1");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace *w;
+    if (int rc = get_workspace(h, B, &w)) return rc;
+    const Dims d = dims_of(h, B);
+    const size_t sa = (size_t)B * h->Ca * h->N * h->N, sn = (size_t)B * h->N * h->Cn;
+    std::vector<float> t_hat(T), nz(T), hs(T);
+    dsg_sigma_schedule(cfg, nullptr, t_hat.data(), nz.data(), hs.data());
+    std::vector<float> t_steps(T + 1, 0.f);
+    {
+        std::vector<double> sg(T);
+        dsg_sigma_schedule(cfg, sg.data(), nullptr, nullptr, nullptr);
+        for (int i = 0; i < T; i++) t_steps[i] = (float)sg[i];
+    }
+    const int ncalls = cfg->heun ? 2 * T - 1 : T;
+    std::vector<uint8_t> coin_buf(ncalls, 0);
+    if (coins) memcpy(coin_buf.data(), coins, ncalls);
+    else if (h->cfg.self_condition) {
+        std::mt19937_64 gen(seed ^ 0x9E3779B97F4A7C15ull);
+        for (int i = 0; i < ncalls; i++) coin_buf[i] = (gen() >> 63) & 1;
+    }
+    h->last_stats = dsg_sample_stats{};
+    HIP_TRY(h, hipMemcpyAsync(w->flags, flags, (size_t)B * h->N, hipMemcpyDeviceToDevice, s));
+    // x0 = init * sigma(t0) (edm.py:326, :346-347)
+    launch_init(CStatePtrs{init_adj, init_node}, t_steps[0], seed, w->flags, StatePtrs{w->x_adj, w->x_node}, d, s);
+    const bool use_graph = cfg->use_graph != 0;
+    int sc_slot = -1;  // which d_* buffer holds the current self-cond, -1 = None
+    int call = 0, snap_k = 0;
+    int64_t nfe = 0;
+    for (int i = 0; i < T; i++) {
+        // churn (edm.py:355-366)
+        CStatePtrs nptr{noise_adj ? noise_adj + (size_t)i * sa : nullptr, noise_node ? noise_node + (size_t)i * sn : nullptr};
+        launch_churn(CStatePtrs{w->x_adj, w->x_node}, nptr, nz[i], seed, (uint32_t)i, w->flags, StatePtrs{w->xh_adj, w->xh_node}, d, s);
+        launch_fill_f32(w->sig, t_hat[i], B, s);
+        const CStatePtrs xh{w->xh_adj, w->xh_node};
+        const float inv_t = 1.0f / t_hat[i];
+        auto free_slot = [&](int a, int b2) { for (int k = 0; k < 3; k++) if (k != a && k != b2) return k; return 0; };
+        // stage 1
+        const int s1 = free_slot(sc_slot, -1);
+        CStatePtrs D1;
+        if (gt_adj) D1 = CStatePtrs{gt_adj, gt_node};
+        else {
+            if (int rc = precond_core(h, w, xh, sc_slot >= 0 ? w->d_adj[sc_slot] : nullptr, sc_slot >= 0 ? w->d_node[sc_slot] : nullptr,
+                                      coin_buf[call++] != 0, StatePtrs{w->d_adj[s1], w->d_node[s1]}, use_graph, s, &nfe))
+                return rc;
+            D1 = CStatePtrs{w->d_adj[s1], w->d_node[s1]};
+        }
+        if (!cfg->heun || i == T - 1) {  // edm.py:394-396
+            launch_euler(xh, D1, inv_t, hs[i], w->flags, StatePtrs{w->x_adj, w->x_node}, d, s);
+            if (!gt_adj && h->cfg.self_condition) sc_slot = s1;
+        } else {
+            // stage 2 re-evaluates at (x_hat, sigma(t_hat)) with self-cond = D1 (edm.py:400-405)
+            const int s2 = free_slot(s1, -1);
+            CStatePtrs D2;
+            if (gt_adj) D2 = D1;
+            else {
+                const bool sc = h->cfg.self_condition;
+                if (int rc = precond_core(h, w, xh, sc ? w->d_adj[s1] : nullptr, sc ? w->d_node[s1] : nullptr, coin_buf[call++] != 0,
+                                          StatePtrs{w->d_adj[s2], w->d_node[s2]}, use_graph, s, &nfe))
+                    return rc;
+                D2 = CStatePtrs{w->d_adj[s2], w->d_node[s2]};
+            }
+            volatile float t_prime = t_hat[i] + hs[i];  // alpha = 1 (edm.py:391)
+            const float inv_tp = 1.0f / t_prime;
+            launch_heun(xh, D1, D2, inv_t, inv_tp, hs[i], w->flags, StatePtrs{w->x_adj, w->x_node}, d, s);
+            if (!gt_adj && h->cfg.self_condition) sc_slot = s2;
+        }
+        // interim snapshots (edm.py:429-432)
+        while (snap_k < n_snap && snap_steps && snap_steps[snap_k] == i) {
+            if (snap_adj) HIP_TRY(h, hipMemcpyAsync(snap_adj + (size_t)snap_k * sa, w->x_adj, sizeof(float) * sa, hipMemcpyDeviceToDevice, s));
+            if (snap_node) HIP_TRY(h, hipMemcpyAsync(snap_node + (size_t)snap_k * sn, w->x_node, sizeof(float) * sn, hipMemcpyDeviceToDevice, s));
+            snap_k++;
+        }
+    }
+    HIP_TRY(h, hipMemcpyAsync(out_adj, w->x_adj, sizeof(float) * sa, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(out_node, w->x_node, sizeof(float) * sn, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(h, hipGetLastError());
+    h->last_stats.precond_calls = call;
+    h->last_stats.net_forwards = nfe;
+    if (stats) *stats = h->last_stats;
+    return DSG_OK;
+}
+
+int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, int32_t n_adj_type,
+                    int32_t n_node_type, int32_t node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, void *stream) {
+    if (!h || B < 1 || !adj || !node || !flags || !out_adj || !out_node) return fail(h, DSG_ERR_INVALID, "null tensor");
+    if (node_bits < 1 || node_bits > h->Cn || (out_bbox && h->Cn < node_bits + 4)) return fail(h, DSG_ERR_INVALID, "node_bits");
+    launch_decode_bits(adj, node, flags, n_adj_type, n_node_type, node_bits, out_adj, out_node, out_bbox, dims_of(h, B),
+                       (hipStream_t)stream);
+    HIP_TRY(h, hipGetLastError());
+    return DSG_OK;
+}
+
+}  // extern "C"

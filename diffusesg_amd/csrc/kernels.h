@@ -1,0 +1,88 @@
+// kernels.h -- launch wrappers of the gfx950 kernels (kernels.hip), used by dsg_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsg {
+
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
+
+// C[M,N] = act( pro(A)[M,K] * W[N,K]^T + bias ) (+ res), optionally stored twice.
+struct GemmArgs {
+    const float *A = nullptr;  int lda = 0;      // rows of K1 floats (k <  K1)
+    const float *A2 = nullptr; int lda2 = 0;     // optional second source (k >= K1): concat along K
+    int K1 = 0;                                  // == K when A2 is null
+    const float *W = nullptr;                    // [N, K] row-major (torch Linear layout)
+    const float *bias = nullptr;                 // [N] or null
+    const float *ln_stats = nullptr;             // [M,2] (mean, rstd): LayerNorm fused into the A load
+    const float *ln_g = nullptr, *ln_b = nullptr;// [K]
+    const float *res = nullptr; int ldres = 0;   // residual added after the activation, or null
+    float *C = nullptr;  int ldc = 0;
+    float *C2 = nullptr; int ldc2 = 0;           // optional second destination
+    int M = 0, N = 0, K = 0;                     // K % 32 == 0
+    int act = ACT_NONE;
+};
+void launch_gemm(const GemmArgs &g, hipStream_t s);
+
+// geometry of one Swin block's windows
+struct WinGeom {
+    int res;      // tokens per side
+    int ws;       // window side
+    int shift;    // cyclic shift (0 or ws/2)
+    int heads;
+    int C;
+};
+// qkv [B*T, 3C] token order -> out [B*T, C] token order; biasT [nWt][heads][Wp][Wp] (key-major)
+void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s);
+
+// x <- silu(shift + x*(1+scale)), (scale,shift) = aff[b][off .. off+2C); stats of the new rows
+void launch_mod_stats(float *x, const float *aff, int aff_ld, int aff_off, float *stats, int B, int T, int C, hipStream_t s);
+// stats[m] = (mean, rstd) of row m
+void launch_ln_stats(const float *x, float *stats, int M, int C, hipStream_t s);
+// y = silu(shift + LN(x)*(1+scale)) (PatchEmbed tail)
+void launch_ln_mod(const float *x, const float *g, const float *b, const float *aff, int aff_ld, int aff_off,
+                   float *y, int B, int T, int C, hipStream_t s);
+// PatchMerging gather + LN(4C): x [B,res*res,C] -> y [B,(res/2)^2,4C]
+void launch_merge_ln(const float *x, const float *g, const float *b, float *y, int B, int res, int C, hipStream_t s);
+// PatchBreakup middle: LN(D) -> 4 chunks scattered 2x2 -> LN(D/4): y [B,res*res,D] -> z [B,(2res)^2,D/4]
+void launch_breakup_ln(const float *y, const float *g, const float *b, const float *pg, const float *pb, float *z,
+                       int B, int res, int D, hipStream_t s);
+// positional embedding of the noise label: pe [B,E]
+void launch_noise_pe(const float *c_noise, float *pe, int B, int E, hipStream_t s);
+// input assembly: token-major [B*N*N, Kp] (zero padded), channel order of diffusesg.py:792-802
+void launch_assemble(const float *adj, const float *node, const float *sc_adj, const float *sc_node, const int *has_sc,
+                     const uint8_t *flags, float *out, int B, int N, int Ca, int Cn, int self_cond, int Kp, hipStream_t s);
+// adjacency head tail: h [B*N*N, E] -> out [B,Ca,N,N] = mask(h @ W^T + b)
+void launch_head_adj(const float *h, const float *W, const float *bias, const uint8_t *flags, float *out,
+                     int B, int N, int E, int Ca, hipStream_t s);
+// masked mean pooling over j (divided by N): rep [B*N*N, E] -> pool [B*N, E]
+void launch_pool(const float *rep, const uint8_t *flags, float *pool, int B, int N, int E, hipStream_t s);
+// node head tail: h [B*N, E] -> out [B,N,Cn] = mask(h @ W^T + b)
+void launch_head_node(const float *h, const float *W, const float *bias, const uint8_t *flags, float *out,
+                      int B, int N, int E, int Cn, hipStream_t s);
+
+// ---- preconditioning / sampler elementwise kernels (adj and node parts handled in one launch) ----
+struct StatePtrs { float *adj; float *node; };
+struct CStatePtrs { const float *adj; const float *node; };
+struct Dims { int B, N, Ca, Cn; };
+
+// in = c_in(sigma[b]) * x ; c_noise[b] = ln(sigma[b])/4
+void launch_precond_in(CStatePtrs x, const float *sigmas, StatePtrs in, float *c_noise, Dims d, hipStream_t s);
+// D = mask(c_skip*x + c_out*F); optionally stored to a second destination
+void launch_precond_out(CStatePtrs x, CStatePtrs F, const float *sigmas, const uint8_t *flags, StatePtrs D, StatePtrs D2,
+                        Dims d, hipStream_t s);
+// x_hat = mask(x + coef*eps); eps from `noise` (if non-null) or Philox(seed, step)
+void launch_churn(CStatePtrs x, CStatePtrs noise, float coef, uint64_t seed, uint32_t step, const uint8_t *flags,
+                  StatePtrs xhat, Dims d, hipStream_t s);
+// x0 = mask(eps) * scale (gen_init_sample + initial scaling)
+void launch_init(CStatePtrs init, float scale, uint64_t seed, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s);
+// Euler: x = mask(xhat + h*mask(inv*xhat - inv*D))
+void launch_euler(CStatePtrs xhat, CStatePtrs D, float inv_t, float h, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s);
+// Heun: d=mask(inv*xhat-inv*D1); xp=xhat+h*d; dp=invp*xp-invp*D2; x=mask(xhat+h*(0.5d+0.5dp))
+void launch_heun(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, float inv_t, float inv_tp, float h, const uint8_t *flags,
+                 StatePtrs x, Dims d, hipStream_t s);
+void launch_fill_f32(float *p, float v, int64_t n, hipStream_t s);
+void launch_decode_bits(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,
+                        int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d, hipStream_t s);
+
+}  // namespace dsg

@@ -1,0 +1,831 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the DiffuseSG sampling hot path.
+//
+// All arithmetic is fp32.  The dense contractions run on the exact-f32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, 157 TFLOP/s chip peak), everything else is HBM/LDS bound
+// elementwise work fused around them.  Reference semantics are cited per kernel
+// (R/ = DiffuseSG/ of the reference tree).
+#include "kernels.h"
+
+#include <math.h>
+
+namespace dsg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LN_EPS 1e-5f
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// =================================================================================================
+// GEMM: C[M,N] = act(pro(A)[M,K] . W[N,K]^T + bias) (+res)
+//
+// Block = 256 threads = 4 waves, block tile 128 (M) x 96 (N), K step 32.  Every channel count of
+// the network is a multiple of 96 (= 3 MFMA tiles of 32), so a 96-wide N tile wastes nothing where
+// a power-of-two tile would.  Wave w owns rows [32w, 32w+32) x all 96 columns = 3 accumulators of
+// v_mfma_f32_32x32x2_f32.  The MFMA takes ONE f32 per lane for A and for B (lane l: row/col l&31,
+// k = l>>5); the k index inside a step is a free permutation as long as A and B agree, so each lane
+// fetches 4 consecutive k with one ds_read_b128 (k = 8s + 4*(l>>5) + t) and feeds element t to the
+// t-th MFMA: 4 LDS reads feed 12 MFMAs (768 matrix-pipe cycles) -- LDS is never the limiter.
+// A tiles are register-staged (global -> VGPR -> LDS) so that LayerNorm ((a-mean)*rstd*g+b) and the
+// two-source concat are applied on the way in; the next tile's global loads are issued before the
+// MFMAs of the current one.  LDS rows are padded to 36 floats: conflict-free for ds_read_b128.
+// =================================================================================================
+constexpr int GBM = 128, GBN = 96, GBK = 32, GLD = 36;
+
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (GBM + GBN) * GLD];
+    float *As0 = lds, *Ws0 = lds + GBM * GLD;
+    float *As1 = lds + (GBM + GBN) * GLD, *Ws1 = As1 + GBM * GLD;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (L2); give each XCD whole M-tiles and walk
+    // the N-tiles of one M-tile consecutively so the A rows are re-read from that XCD's L2.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, seq = bid >> 3;
+    const int tm = (seq / tiles_n) * 8 + xcd, tn = seq % tiles_n;
+    if (tm >= tiles_m) return;
+    const int m0 = tm * GBM, n0 = tn * GBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c4 = tid & 7;          // which float4 of the 32-wide k chunk this thread stages
+    const int r0 = tid >> 3;         // staging row (0..31), +32 per pass
+
+    // per-thread constants of the A prologue
+    float a_mean[4], a_rstd[4];
+    const float *a_row1[4], *a_row2[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        int m = m0 + r0 + 32 * p;
+        a_ok[p] = m < g.M;
+        if (!a_ok[p]) m = g.M - 1;
+        a_row1[p] = g.A + (size_t)m * g.lda;
+        a_row2[p] = g.A2 ? g.A2 + (size_t)m * g.lda2 : nullptr;
+        if (g.ln_stats) { a_mean[p] = g.ln_stats[2 * m]; a_rstd[p] = g.ln_stats[2 * m + 1]; }
+        else { a_mean[p] = 0.f; a_rstd[p] = 1.f; }
+    }
+    const float *w_row[3];
+    bool w_ok[3];
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        int n = n0 + r0 + 32 * p;
+        w_ok[p] = n < g.N;
+        if (!w_ok[p]) n = g.N - 1;
+        w_row[p] = g.W + (size_t)n * g.K;
+    }
+
+    f32x4 ra[4], rw[3];
+    auto load_tile = [&](int k0) {
+        const int k = k0 + 4 * c4;
+        const bool second = g.A2 && k >= g.K1;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const float *src = second ? a_row2[p] + (k - g.K1) : a_row1[p] + k;
+            ra[p] = *reinterpret_cast<const f32x4 *>(src);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) rw[p] = *reinterpret_cast<const f32x4 *>(w_row[p] + k);
+        if (g.ln_stats) {
+            const f32x4 gg = *reinterpret_cast<const f32x4 *>(g.ln_g + k);
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(g.ln_b + k);
+#pragma unroll
+            for (int p = 0; p < 4; p++) ra[p] = (ra[p] - a_mean[p]) * a_rstd[p] * gg + bb;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) if (!a_ok[p]) ra[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 3; p++) if (!w_ok[p]) rw[p] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_tile = [&](float *As, float *Ws) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) *reinterpret_cast<f32x4 *>(As + (r0 + 32 * p) * GLD + 4 * c4) = ra[p];
+#pragma unroll
+        for (int p = 0; p < 3; p++) *reinterpret_cast<f32x4 *>(Ws + (r0 + 32 * p) * GLD + 4 * c4) = rw[p];
+    };
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+
+    const int nk = g.K / GBK;
+    load_tile(0);
+    store_tile(As0, Ws0);
+    __syncthreads();
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    for (int kc = 0; kc < nk; kc++) {
+        const float *As = (kc & 1) ? As1 : As0, *Ws = (kc & 1) ? Ws1 : Ws0;
+        if (kc + 1 < nk) load_tile((kc + 1) * GBK);
+        const float *ap = As + (wave * 32 + lrow) * GLD + 4 * lhalf;
+        const float *wp = Ws + lrow * GLD + 4 * lhalf;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + 8 * s);
+            f32x4 b[3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) b[j] = *reinterpret_cast<const f32x4 *>(wp + 32 * j * GLD + 8 * s);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b[j][t], acc[j], 0, 0, 0);
+        }
+        if (kc + 1 < nk) store_tile((kc & 1) ? As0 : As1, (kc & 1) ? Ws0 : Ws1);
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int n = n0 + 32 * j + lrow;
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            if (m >= g.M) continue;
+            float v = acc[j][r] + bias;
+            if (g.act == ACT_GELU) v = gelu_f(v);
+            else if (g.act == ACT_SILU) v = silu_exact(v);
+            if (g.res) v += g.res[(size_t)m * g.ldres + n];
+            g.C[(size_t)m * g.ldc + n] = v;
+            if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v;
+        }
+    }
+}
+
+void launch_gemm(const GemmArgs &g, hipStream_t s) {
+    const int tiles_m = (g.M + GBM - 1) / GBM, tiles_n = (g.N + GBN - 1) / GBN;
+    const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(grid), dim3(256), 0, s, g, tiles_m, tiles_n);
+}
+
+// =================================================================================================
+// Window attention core (R/model/diffusesg/diffusesg.py:108-139 with the window partition, cyclic
+// shift and their inverses of :28-57, :246-271 folded into the token index).
+//
+// One wave per (sample, window, head).  q/k/v of a head are 32 floats = one 128-B segment of a
+// token's qkv row, so operands are loaded straight from global memory into MFMA fragments:
+//   S^T[key][query] = K . (scale*Q)^T      (A = K rows, B = Q rows; "swapped" product so that a
+//                                           lane owns one query column and softmax is lane-local)
+//   O[query][d]     = P . V                (A = P taken from the S^T accumulators in place -- a lane
+//                                           already holds P[query][key] for exactly the keys the A
+//                                           operand of k-step r needs; B = V row of that key)
+// Relative-position bias and the shifted-window mask (-100) come pre-combined and transposed
+// (key-major) from a dense table built at weight-load time; padded key slots hold -1e30.
+// =================================================================================================
+template <int KT>  // number of 32-token tiles per window (Wp = 32*KT >= ws*ws)
+__global__ __launch_bounds__(256) void window_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ biasT,
+                                                          float *__restrict__ out, int B, WinGeom g, int n_units) {
+    __shared__ int tok_lds[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int unit = blockIdx.x * 4 + wave;
+    const bool active = unit < n_units;
+    if (!active) unit = n_units - 1;  // keep the wave alive for the block barrier; its stores are skipped
+    const int heads = g.heads, C = g.C, res = g.res, ws = g.ws;
+    const int nwr = res / ws, nW = nwr * nwr, Wt = ws * ws, T = res * res;
+    constexpr int Wp = 32 * KT;
+    const int head = unit % heads;
+    const int bw = unit / heads;
+    const int w = bw % nW, b = bw / nW;
+    const int wi = w / nwr, wj = w % nwr;
+    int *tok = tok_lds[wave];
+    for (int p = lane; p < Wp; p += 64) {
+        int t = 0;
+        if (p < Wt) {
+            const int si = wi * ws + p / ws, sj = wj * ws + p % ws;  // coordinates in the rolled image
+            t = ((si + g.shift) % res) * res + ((sj + g.shift) % res);
+        }
+        tok[p] = t;
+    }
+    __syncthreads();
+    const float scale = 0.17677669529663687f;  // 32^-0.5 (head_dim is 32 at every level)
+    const size_t base = (size_t)b * T * 3 * C;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const float *bias_base = biasT + ((size_t)(g.shift > 0 ? w : 0) * heads + head) * Wp * Wp;
+
+    // K fragments for all key tiles: lane (key = 32*kt + lrow) holds d = 8s + 4*lhalf + {0..3}
+    f32x4 kf[KT][4];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        const float *kp = qkv + base + (size_t)tok[32 * kt + lrow] * 3 * C + C + head * 32 + 4 * lhalf;
+#pragma unroll
+        for (int s = 0; s < 4; s++) kf[kt][s] = *reinterpret_cast<const f32x4 *>(kp + 8 * s);
+    }
+
+    for (int qt = 0; qt < KT; qt++) {
+        if (32 * qt >= Wt) break;
+        const float *qp = qkv + base + (size_t)tok[32 * qt + lrow] * 3 * C + head * 32 + 4 * lhalf;
+        f32x4 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const f32x4 *>(qp + 8 * s) * scale;
+
+        f32x16 sacc[KT];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+            // start from the (bias + mask)^T tile: element [key][query]
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                sacc[kt][r] = bias_base[(size_t)key * Wp + 32 * qt + lrow];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kt][s][t], qf[s][t], sacc[kt], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // the other half-wave holds the remaining keys of this query
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float e = __expf(sacc[kt][r] - mx);
+                sacc[kt][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+
+        f32x16 oacc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                // k-step r of key tile kt: half 0 contributes key (r&3)+8(r>>2), half 1 that key + 4
+                const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                const float v = qkv[base + (size_t)tok[key] * 3 * C + 2 * C + head * 32 + lrow];
+                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r] * inv, v, oacc, 0, 0, 0);
+            }
+        // O tile: col = d = lrow, row = query 32*qt + (r&3) + 8(r>>2) + 4*lhalf
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int q = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            if (q < Wt && active) out[((size_t)b * T + tok[q]) * C + head * 32 + lrow] = oacc[r];
+        }
+    }
+}
+
+void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s) {
+    const int nW = (g.res / g.ws) * (g.res / g.ws);
+    const int n_units = B * nW * g.heads;
+    const int Wt = g.ws * g.ws;
+    const int KT = (Wt + 31) / 32;
+    const dim3 grid((n_units + 3) / 4), block(256);
+    switch (KT) {
+        case 1: hipLaunchKernelGGL(window_attn_kernel<1>, grid, block, 0, s, qkv, biasT, out, B, g, n_units); break;
+        case 2: hipLaunchKernelGGL(window_attn_kernel<2>, grid, block, 0, s, qkv, biasT, out, B, g, n_units); break;
+        case 3: hipLaunchKernelGGL(window_attn_kernel<3>, grid, block, 0, s, qkv, biasT, out, B, g, n_units); break;
+        default: hipLaunchKernelGGL(window_attn_kernel<4>, grid, block, 0, s, qkv, biasT, out, B, g, n_units); break;
+    }
+}
+
+// =================================================================================================
+// Row kernels: one wave per token row, values held in registers between the passes.
+// =================================================================================================
+constexpr int ROW_MAXV = 24;  // rows up to 64*24 = 1536 channels (PatchBreakup at the deepest level)
+
+// x <- silu(shift + x*(1+scale)); stats = LayerNorm statistics of the NEW row (norm1 runs on the
+// modulated tensor, which is also the residual shortcut: diffusesg.py:238-243)
+__global__ __launch_bounds__(256) void mod_stats_kernel(float *x, const float *aff, int aff_ld, int aff_off, float *stats,
+                                                        int T, int C, int M) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int b = m / T;
+    const float *scale = aff + (size_t)b * aff_ld + aff_off, *shift = scale + C;
+    float *xr = x + (size_t)m * C;
+    float v[ROW_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_MAXV; i++) {
+        const int c = lane + 64 * i;
+        v[i] = 0.f;
+        if (c < C) {
+            v[i] = silu_exact(shift[c] + xr[c] * (scale[c] + 1.0f));
+            xr[c] = v[i];
+            sum += v[i];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_MAXV; i++) {
+        const int c = lane + 64 * i;
+        if (c < C) { const float d = v[i] - mean; var += d * d; }
+    }
+    var = wave_sum(var) / (float)C;
+    if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = 1.0f / sqrtf(var + LN_EPS); }
+}
+void launch_mod_stats(float *x, const float *aff, int aff_ld, int aff_off, float *stats, int B, int T, int C, hipStream_t s) {
+    const int M = B * T;
+    hipLaunchKernelGGL(mod_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, aff, aff_ld, aff_off, stats, T, C, M);
+}
+
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float *x, float *stats, int C, int M) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float *xr = x + (size_t)m * C;
+    float v[ROW_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_MAXV; i++) {
+        const int c = lane + 64 * i;
+        v[i] = (c < C) ? xr[c] : 0.f;
+        sum += v[i];
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_MAXV; i++) {
+        const int c = lane + 64 * i;
+        if (c < C) { const float d = v[i] - mean; var += d * d; }
+    }
+    var = wave_sum(var) / (float)C;
+    if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = 1.0f / sqrtf(var + LN_EPS); }
+}
+void launch_ln_stats(const float *x, float *stats, int M, int C, hipStream_t s) {
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, stats, C, M);
+}
+
+// PatchEmbed tail (diffusesg.py:570-576): y = silu(shift + LN(x)*(1+scale))
+__global__ __launch_bounds__(256) void ln_mod_kernel(const float *x, const float *g, const float *bta, const float *aff,
+                                                     int aff_ld, int aff_off, float *y, int T, int C, int M) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int b = m / T;
+    const float *scale = aff + (size_t)b * aff_ld + aff_off, *shift = scale + C;
+    const float *xr = x + (size_t)m * C;
+    float v[ROW_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_MAXV; i++) {
+        const int c = lane + 64 * i;
+        v[i] = (c < C) ? xr[c] : 0.f;
+        sum += v[i];
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < ROW_MAXV; i++) {
+        const int c = lane + 64 * i;
+        if (c < C) { const float d = v[i] - mean; var += d * d; }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)C + LN_EPS);
+#pragma unroll
+    for (int i = 0; i < ROW_MAXV; i++) {
+        const int c = lane + 64 * i;
+        if (c < C) {
+            const float n = (v[i] - mean) * rstd * g[c] + bta[c];
+            y[(size_t)m * C + c] = silu_exact(shift[c] + n * (scale[c] + 1.0f));
+        }
+    }
+}
+void launch_ln_mod(const float *x, const float *g, const float *b, const float *aff, int aff_ld, int aff_off, float *y,
+                   int B, int T, int C, hipStream_t s) {
+    const int M = B * T;
+    hipLaunchKernelGGL(ln_mod_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, aff, aff_ld, aff_off, y, T, C, M);
+}
+
+// PatchMerging (diffusesg.py:323-332): out row (i,j) = LN_4C(cat[x(2i,2j), x(2i+1,2j), x(2i,2j+1), x(2i+1,2j+1)])
+__global__ __launch_bounds__(256) void merge_ln_kernel(const float *x, const float *g, const float *bta, float *y, int res,
+                                                       int C, int M) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int r2 = res / 2, T2 = r2 * r2;
+    const int b = m / T2, t = m % T2, i = t / r2, j = t % r2;
+    const int C4 = 4 * C;
+    const float *xb = x + (size_t)b * res * res * C;
+    float v[ROW_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < ROW_MAXV; q++) {
+        const int c = lane + 64 * q;
+        v[q] = 0.f;
+        if (c < C4) {
+            const int part = c / C, cc = c % C;
+            const int di = part & 1, dj = part >> 1;
+            v[q] = xb[(size_t)((2 * i + di) * res + (2 * j + dj)) * C + cc];
+            sum += v[q];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)C4;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < ROW_MAXV; q++) {
+        const int c = lane + 64 * q;
+        if (c < C4) { const float d = v[q] - mean; var += d * d; }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)C4 + LN_EPS);
+#pragma unroll
+    for (int q = 0; q < ROW_MAXV; q++) {
+        const int c = lane + 64 * q;
+        if (c < C4) y[(size_t)m * C4 + c] = (v[q] - mean) * rstd * g[c] + bta[c];
+    }
+}
+void launch_merge_ln(const float *x, const float *g, const float *b, float *y, int B, int res, int C, hipStream_t s) {
+    const int M = B * (res / 2) * (res / 2);
+    hipLaunchKernelGGL(merge_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y, res, C, M);
+}
+
+// PatchBreakup middle (diffusesg.py:386-400): LN_D(row) -> chunk q -> token (2i+(q&1), 2j+(q>>1)) -> LN_{D/4}
+__global__ __launch_bounds__(256) void breakup_ln_kernel(const float *y, const float *g, const float *bta, const float *pg,
+                                                         const float *pb, float *z, int res, int D, int M) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int T = res * res, b = m / T, t = m % T, i = t / res, j = t % res;
+    const int Co = D / 4, R = 2 * res;
+    const float *yr = y + (size_t)m * D;
+    float v[ROW_MAXV];
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < ROW_MAXV; q++) {
+        const int c = lane + 64 * q;
+        v[q] = (c < D) ? yr[c] : 0.f;
+        sum += v[q];
+    }
+    const float mean = wave_sum(sum) / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int q = 0; q < ROW_MAXV; q++) {
+        const int c = lane + 64 * q;
+        if (c < D) { const float d = v[q] - mean; var += d * d; }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)D + LN_EPS);
+    // per-chunk statistics of the normalised row
+    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < ROW_MAXV; q++) {
+        const int c = lane + 64 * q;
+        if (c < D) {
+            v[q] = (v[q] - mean) * rstd * g[c] + bta[c];
+            const int part = c / Co;
+#pragma unroll
+            for (int p = 0; p < 4; p++) csum[p] += (part == p) ? v[q] : 0.f;
+        }
+    }
+    float cmean[4], cvar[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 4; p++) cmean[p] = wave_sum(csum[p]) / (float)Co;
+#pragma unroll
+    for (int q = 0; q < ROW_MAXV; q++) {
+        const int c = lane + 64 * q;
+        if (c < D) {
+            const int part = c / Co;
+#pragma unroll
+            for (int p = 0; p < 4; p++) { const float d = v[q] - cmean[p]; cvar[p] += (part == p) ? d * d : 0.f; }
+        }
+    }
+    float crstd[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) crstd[p] = 1.0f / sqrtf(wave_sum(cvar[p]) / (float)Co + LN_EPS);
+#pragma unroll
+    for (int q = 0; q < ROW_MAXV; q++) {
+        const int c = lane + 64 * q;
+        if (c < D) {
+            const int part = c / Co, cc = c % Co;
+            const int di = part & 1, dj = part >> 1;
+            float mu = cmean[0], rs = crstd[0];
+#pragma unroll
+            for (int p = 1; p < 4; p++) if (part == p) { mu = cmean[p]; rs = crstd[p]; }
+            const size_t orow = (size_t)b * 4 * T + (size_t)(2 * i + di) * R + (2 * j + dj);
+            z[orow * Co + cc] = (v[q] - mu) * rs * pg[cc] + pb[cc];
+        }
+    }
+}
+void launch_breakup_ln(const float *y, const float *g, const float *b, const float *pg, const float *pb, float *z, int B,
+                       int res, int D, hipStream_t s) {
+    const int M = B * res * res;
+    hipLaunchKernelGGL(breakup_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, s, y, g, b, pg, pb, z, res, D, M);
+}
+
+// PositionalEmbedding (diffusesg.py:507-513): freqs = (1/10000)^(k/(E/2)); [cos(x f), sin(x f)]
+__global__ void noise_pe_kernel(const float *c_noise, float *pe, int B, int E) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = E / 2;
+    if (idx >= B * half) return;
+    const int b = idx / half, k = idx % half;
+    const float f = powf(1.0f / 10000.0f, (float)k / (float)half);
+    const float v = c_noise[b] * f;
+    pe[(size_t)b * E + k] = cosf(v);
+    pe[(size_t)b * E + half + k] = sinf(v);
+}
+void launch_noise_pe(const float *c_noise, float *pe, int B, int E, hipStream_t s) {
+    const int n = B * (E / 2);
+    hipLaunchKernelGGL(noise_pe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, c_noise, pe, B, E);
+}
+
+// Input assembly (diffusesg.py:784-802), token-major with the K dim zero-padded to Kp.
+// channel order: [sc_adj, adj, sc_node(i), node(i), sc_node(j), node(j)]; node part masked by flags[i]&flags[j]
+__global__ void assemble_kernel(const float *adj, const float *node, const float *sc_adj, const float *sc_node,
+                                const int *has_sc, const uint8_t *flags, float *out, int B, int N, int Ca, int Cn,
+                                int self_cond, int Kp) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * N * N * Kp;
+    if (idx >= total) return;
+    const int c = idx % Kp;
+    const size_t tokg = idx / Kp;
+    const int j = tokg % N, i = (tokg / N) % N, b = tokg / ((size_t)N * N);
+    const bool sc_on = self_cond && (has_sc == nullptr || *has_sc != 0) && sc_adj != nullptr;
+    const int nsc = self_cond ? 2 : 1;
+    float v = 0.f;
+    if (c < nsc * Ca) {
+        const int which = self_cond ? c / Ca : 1, a = c % Ca;  // 0 = self-cond copy, 1 = current
+        const float *src = (which == 0) ? (sc_on ? sc_adj : nullptr) : adj;
+        if (src) v = src[(((size_t)b * Ca + a) * N + i) * N + j];
+    } else if (c < nsc * (Ca + 2 * Cn)) {
+        const int cc = c - nsc * Ca;
+        const int colpart = cc / (nsc * Cn);  // 0: node_mat (row index i), 1: node_mat_t (column index j)
+        const int c2 = cc % (nsc * Cn);
+        const int which = self_cond ? c2 / Cn : 1, a = c2 % Cn;
+        const int nodei = colpart ? j : i;
+        const float *src = (which == 0) ? (sc_on ? sc_node : nullptr) : node;
+        const bool m = flags[(size_t)b * N + i] && flags[(size_t)b * N + j];
+        if (src && m) v = src[((size_t)b * N + nodei) * Cn + a];
+    }
+    out[idx] = v;
+}
+void launch_assemble(const float *adj, const float *node, const float *sc_adj, const float *sc_node, const int *has_sc,
+                     const uint8_t *flags, float *out, int B, int N, int Ca, int Cn, int self_cond, int Kp, hipStream_t s) {
+    const size_t total = (size_t)B * N * N * Kp;
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, adj, node, sc_adj, sc_node,
+                       has_sc, flags, out, B, N, Ca, Cn, self_cond, Kp);
+}
+
+// Adjacency head tail (diffusesg.py:806-809, :825): out[b][c][i][j] = mask * (h[tok] . W[c] + bias[c])
+// one wave per token: lanes split the E-long dot product
+__global__ __launch_bounds__(256) void head_adj_kernel(const float *h, const float *W, const float *bias,
+                                                       const uint8_t *flags, float *out, int N, int E, int Ca, int M) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int T = N * N, b = m / T, t = m % T, i = t / N, j = t % N;
+    const bool ok = flags[(size_t)b * N + i] && flags[(size_t)b * N + j];
+    const float *hr = h + (size_t)m * E;
+    for (int c = 0; c < Ca; c++) {
+        float acc = 0.f;
+        if (ok)
+            for (int e = lane; e < E; e += 64) acc += hr[e] * W[(size_t)c * E + e];
+        acc = wave_sum(acc);
+        if (lane == 0) out[(((size_t)b * Ca + c) * N + i) * N + j] = ok ? acc + bias[c] : 0.f;
+    }
+}
+void launch_head_adj(const float *h, const float *W, const float *bias, const uint8_t *flags, float *out, int B, int N,
+                     int E, int Ca, hipStream_t s) {
+    const int M = B * N * N;
+    hipLaunchKernelGGL(head_adj_kernel, dim3((M + 3) / 4), dim3(256), 0, s, h, W, bias, flags, out, N, E, Ca, M);
+}
+
+// Padding-aware pooling (diffusesg.py:812-813): mean over j of the row/col-masked rep, divided by N_pad
+__global__ void pool_kernel(const float *rep, const uint8_t *flags, float *pool, int B, int N, int E) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * N * E) return;
+    const int e = idx % E, i = (idx / E) % N, b = idx / (E * N);
+    float acc = 0.f;
+    if (flags[(size_t)b * N + i])
+        for (int j = 0; j < N; j++)
+            if (flags[(size_t)b * N + j]) acc += rep[(((size_t)b * N + i) * N + j) * E + e];
+    pool[idx] = acc / (float)N;
+}
+void launch_pool(const float *rep, const uint8_t *flags, float *pool, int B, int N, int E, hipStream_t s) {
+    const int n = B * N * E;
+    hipLaunchKernelGGL(pool_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rep, flags, pool, B, N, E);
+}
+
+__global__ __launch_bounds__(256) void head_node_kernel(const float *h, const float *W, const float *bias,
+                                                        const uint8_t *flags, float *out, int N, int E, int Cn, int M) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const bool ok = flags[m];
+    const float *hr = h + (size_t)m * E;
+    for (int c = 0; c < Cn; c++) {
+        float acc = 0.f;
+        if (ok)
+            for (int e = lane; e < E; e += 64) acc += hr[e] * W[(size_t)c * E + e];
+        acc = wave_sum(acc);
+        if (lane == 0) out[(size_t)m * Cn + c] = ok ? acc + bias[c] : 0.f;
+    }
+}
+void launch_head_node(const float *h, const float *W, const float *bias, const uint8_t *flags, float *out, int B, int N,
+                      int E, int Cn, hipStream_t s) {
+    const int M = B * N;
+    hipLaunchKernelGGL(head_node_kernel, dim3((M + 3) / 4), dim3(256), 0, s, h, W, bias, flags, out, N, E, Cn, M);
+}
+
+// =================================================================================================
+// Preconditioning and sampler elementwise kernels.  One launch covers the adjacency part
+// [B,Ca,N,N] and the node part [B,N,Cn]; a flat index below n_adj addresses the former.
+// The arithmetic mirrors torch's op-by-op rounding of the reference (no fused multiply-add where the
+// reference has two rounded ops), see R/model/precond/precond.py:100-105, R/runner/mcmc_sampler/edm.py:355-427.
+// =================================================================================================
+struct ElemIdx { bool is_adj; size_t off; int b; bool valid; };
+
+__device__ __forceinline__ ElemIdx elem_index(size_t idx, const Dims &d, const uint8_t *flags) {
+    ElemIdx e;
+    const size_t n_adj = (size_t)d.B * d.Ca * d.N * d.N;
+    if (idx < n_adj) {
+        e.is_adj = true; e.off = idx;
+        const int j = idx % d.N, i = (idx / d.N) % d.N;
+        e.b = idx / ((size_t)d.Ca * d.N * d.N);
+        e.valid = flags ? (flags[(size_t)e.b * d.N + i] && flags[(size_t)e.b * d.N + j]) : true;
+    } else {
+        e.is_adj = false; e.off = idx - n_adj;
+        const int i = (e.off / d.Cn) % d.N;
+        e.b = e.off / ((size_t)d.N * d.Cn);
+        e.valid = flags ? (bool)flags[(size_t)e.b * d.N + i] : true;
+    }
+    return e;
+}
+__host__ __device__ inline size_t total_elems(const Dims &d) { return (size_t)d.B * ((size_t)d.Ca * d.N * d.N + (size_t)d.N * d.Cn); }
+
+#define FMUL(a, b) __fmul_rn((a), (b))
+#define FADD(a, b) __fadd_rn((a), (b))
+#define FSUB(a, b) __fsub_rn((a), (b))
+
+__global__ void precond_in_kernel(CStatePtrs x, const float *sigmas, StatePtrs in, float *c_noise, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (size_t)d.B) c_noise[idx] = __fdiv_rn(logf(sigmas[idx]), 4.0f);  // objectives/edm.py:126
+    if (idx >= total_elems(d)) return;
+    const ElemIdx e = elem_index(idx, d, nullptr);
+    const float s = sigmas[e.b];
+    const float c_in = __fdiv_rn(1.0f, __fsqrt_rn(FADD(0.25f, FMUL(s, s))));       // objectives/edm.py:125
+    if (e.is_adj) in.adj[e.off] = FMUL(c_in, x.adj[e.off]);
+    else in.node[e.off] = FMUL(c_in, x.node[e.off]);
+}
+void launch_precond_in(CStatePtrs x, const float *sigmas, StatePtrs in, float *c_noise, Dims d, hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(precond_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, sigmas, in, c_noise, d);
+}
+
+__global__ void precond_out_kernel(CStatePtrs x, CStatePtrs F, const float *sigmas, const uint8_t *flags, StatePtrs D,
+                                   StatePtrs D2, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_elems(d)) return;
+    const ElemIdx e = elem_index(idx, d, flags);
+    const float s = sigmas[e.b];
+    const float s2 = FADD(FMUL(s, s), 0.25f);
+    const float c_skip = __fdiv_rn(0.25f, s2);                                       // objectives/edm.py:123
+    const float c_out = __fdiv_rn(FMUL(s, 0.5f), __fsqrt_rn(s2));                    // objectives/edm.py:124
+    const float xv = e.is_adj ? x.adj[e.off] : x.node[e.off];
+    const float fv = e.is_adj ? F.adj[e.off] : F.node[e.off];
+    const float v = e.valid ? FADD(FMUL(c_skip, xv), FMUL(c_out, fv)) : 0.f;         // precond.py:102-105
+    if (e.is_adj) { D.adj[e.off] = v; if (D2.adj) D2.adj[e.off] = v; }
+    else { D.node[e.off] = v; if (D2.node) D2.node[e.off] = v; }
+}
+void launch_precond_out(CStatePtrs x, CStatePtrs F, const float *sigmas, const uint8_t *flags, StatePtrs D, StatePtrs D2,
+                        Dims d, hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(precond_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, F, sigmas, flags, D, D2, d);
+}
+
+// Philox4x32-10 counter-based generator -> one N(0,1) per (seed, stream, element)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    const uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    const uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n2 = hi0 ^ c[3] ^ k[1];
+    c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+}
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t stream, uint64_t idx) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), stream, 0x5eedu};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+    for (int r = 0; r < 10; r++) philox_round(c, k);
+    const float u1 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+__global__ void churn_kernel(CStatePtrs x, CStatePtrs noise, float coef, uint64_t seed, uint32_t step, const uint8_t *flags,
+                             StatePtrs xhat, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_elems(d)) return;
+    const ElemIdx e = elem_index(idx, d, flags);
+    const float xv = e.is_adj ? x.adj[e.off] : x.node[e.off];
+    float eps;
+    if (noise.adj) eps = e.is_adj ? noise.adj[e.off] : noise.node[e.off];
+    else eps = (coef != 0.f && e.valid) ? philox_normal(seed, step + 1u, idx) : 0.f;
+    const float v = e.valid ? FADD(xv, FMUL(coef, eps)) : 0.f;  // edm.py:361-366
+    if (e.is_adj) xhat.adj[e.off] = v; else xhat.node[e.off] = v;
+}
+void launch_churn(CStatePtrs x, CStatePtrs noise, float coef, uint64_t seed, uint32_t step, const uint8_t *flags,
+                  StatePtrs xhat, Dims d, hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(churn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, noise, coef, seed, step, flags, xhat, d);
+}
+
+__global__ void init_kernel(CStatePtrs init, float scale, uint64_t seed, const uint8_t *flags, StatePtrs x, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_elems(d)) return;
+    const ElemIdx e = elem_index(idx, d, flags);
+    float v;
+    if (init.adj) v = e.is_adj ? init.adj[e.off] : init.node[e.off];
+    else v = philox_normal(seed, 0u, idx);                       // gen_init_sample, edm.py:279,285
+    v = e.valid ? FMUL(v, scale) : 0.f;                          // edm.py:346-347
+    if (e.is_adj) x.adj[e.off] = v; else x.node[e.off] = v;
+}
+void launch_init(CStatePtrs init, float scale, uint64_t seed, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, init, scale, seed, flags, x, d);
+}
+
+__global__ void euler_kernel(CStatePtrs xhat, CStatePtrs D, float inv_t, float h, const uint8_t *flags, StatePtrs x, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_elems(d)) return;
+    const ElemIdx e = elem_index(idx, d, flags);
+    const float xh = e.is_adj ? xhat.adj[e.off] : xhat.node[e.off];
+    const float dn = e.is_adj ? D.adj[e.off] : D.node[e.off];
+    const float dc = FSUB(FMUL(inv_t, xh), FMUL(inv_t, dn));     // edm.py:384-385
+    const float v = e.valid ? FADD(xh, FMUL(h, dc)) : 0.f;       // edm.py:395-396, :421-422
+    if (e.is_adj) x.adj[e.off] = v; else x.node[e.off] = v;
+}
+void launch_euler(CStatePtrs xhat, CStatePtrs D, float inv_t, float h, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(euler_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xhat, D, inv_t, h, flags, x, d);
+}
+
+__global__ void heun_kernel(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, float inv_t, float inv_tp, float h,
+                            const uint8_t *flags, StatePtrs x, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_elems(d)) return;
+    const ElemIdx e = elem_index(idx, d, flags);
+    const float xh = e.is_adj ? xhat.adj[e.off] : xhat.node[e.off];
+    const float d1 = e.is_adj ? D1.adj[e.off] : D1.node[e.off];
+    const float d2 = e.is_adj ? D2.adj[e.off] : D2.node[e.off];
+    const float dc = FSUB(FMUL(inv_t, xh), FMUL(inv_t, d1));            // edm.py:384-385
+    const float xp = FADD(xh, FMUL(h, dc));                             // edm.py:389-390 (alpha = 1)
+    const float dp = FSUB(FMUL(inv_tp, xp), FMUL(inv_tp, d2));          // edm.py:414-417
+    const float avg = FADD(FMUL(0.5f, dc), FMUL(0.5f, dp));
+    const float v = e.valid ? FADD(xh, FMUL(h, avg)) : 0.f;             // edm.py:418-422
+    if (e.is_adj) x.adj[e.off] = v; else x.node[e.off] = v;
+}
+void launch_heun(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, float inv_t, float inv_tp, float h, const uint8_t *flags,
+                 StatePtrs x, Dims d, hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(heun_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xhat, D1, D2, inv_t, inv_tp, h, flags, x, d);
+}
+
+__global__ void fill_kernel(float *p, float v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void launch_fill_f32(float *p, float v, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+}
+
+// Post-decode of 'bits' samples (sampler_node_adj.py:222-285, attribute_code.py:319-328):
+// value > 0 -> bit 1, channel 0 is the MSB; clamp to [0, n_type-1]; masked; adjacency diagonal zeroed;
+// bbox = node[..., -4:]*0.5+0.5 masked (sampler_node_adj.py:201-209)
+__global__ void decode_bits_kernel(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,
+                                   int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n_a = (size_t)d.B * d.N * d.N, n_n = (size_t)d.B * d.N;
+    if (idx < n_a) {
+        const int j = idx % d.N, i = (idx / d.N) % d.N, b = idx / ((size_t)d.N * d.N);
+        int v = 0;
+        if (flags[(size_t)b * d.N + i] && flags[(size_t)b * d.N + j] && i != j) {
+            for (int c = 0; c < d.Ca; c++) v = (v << 1) | (adj[(((size_t)b * d.Ca + c) * d.N + i) * d.N + j] > 0.f ? 1 : 0);
+            v = min(max(v, 0), n_adj_type - 1);
+        }
+        out_adj[idx] = v;
+    } else if (idx < n_a + n_n) {
+        const size_t m = idx - n_a;
+        const bool ok = flags[m];
+        int v = 0;
+        if (ok) {
+            for (int c = 0; c < node_bits; c++) v = (v << 1) | (node[m * d.Cn + c] > 0.f ? 1 : 0);
+            v = min(max(v, 0), n_node_type - 1);
+        }
+        out_node[m] = v;
+        if (out_bbox)
+            for (int c = 0; c < 4; c++) out_bbox[m * 4 + c] = ok ? node[m * d.Cn + (d.Cn - 4) + c] * 0.5f + 0.5f : 0.f;
+    }
+}
+void launch_decode_bits(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,
+                        int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d, hipStream_t s) {
+    const size_t n = (size_t)d.B * d.N * d.N + (size_t)d.B * d.N;
+    hipLaunchKernelGGL(decode_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, adj, node, flags, n_adj_type,
+                       n_node_type, node_bits, out_adj, out_node, out_bbox, d);
+}
+
+}  // namespace dsg

@@ -1,0 +1,155 @@
+"""Drop-in counterpart of `runner.mcmc_sampler.edm.NodeAdjEDMSampler` (R/runner/mcmc_sampler/edm.py:231-445).
+
+Same constructor kwargs as `get_mc_sampler` passes (R/utils/sampling_utils.py:15-23), same `sample(...)`
+signature and return convention (CPU tensors; 4-tuple with `[None]` in slot 3 when interim snapshots of a
+multi-channel adjacency are requested, edm.py:439-443).  The T-step loop itself runs inside libdsg.so
+(`dsg_sample`): per-step scalars are computed on the host up front, no device->host sync happens inside the
+loop (the reference's per-step `.item()` logging, edm.py:433-434, is dropped), and the network forward is
+replayed from a captured hipGraph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .model import NodeAdjPrecondHip
+
+
+class NodeAdjEDMSamplerHip(object):
+    def __init__(self, *, sigma_min=None, sigma_max=None, solver="heun", discretization="edm", schedule="linear",
+                 scaling="none", C_1=0.001, C_2=0.008, M=1000, alpha=1,
+                 num_steps=256, S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
+                 clip_samples=False, clip_samples_min=None, clip_samples_max=None, clip_samples_scope="x_0",
+                 self_condition=True, dev="cuda", objective="edm", symmetric_noise=False, use_graph=True):
+        assert clip_samples_scope == "x_0"
+        assert solver in ["euler", "heun"]
+        assert objective in ["diffusion", "score", "edm"]
+        if discretization != "edm" or schedule != "linear" or scaling != "none" or alpha != 1:
+            raise NotImplementedError("only discretization='edm', schedule='linear', scaling='none', alpha=1 "
+                                      "(what get_mc_sampler builds, sampling_utils.py:15-23)")
+        if symmetric_noise:
+            raise NotImplementedError("symmetric_noise=True is not used for scene graphs (sampling_utils.py:23)")
+        self.solver, self.num_steps = solver, int(num_steps)
+        self.S_churn, self.S_min, self.S_max, self.S_noise = S_churn, S_min, S_max, S_noise
+        self.sigma_min = 0.002 if sigma_min is None else sigma_min   # edm_params.sigma_min_sampling
+        self.sigma_max = 80.0 if sigma_max is None else sigma_max
+        self.self_condition = self_condition
+        self.dev = dev
+        # stored but never applied by the reference loop either (mcmc_sampler/__init__.py:24-26)
+        self.clip_samples, self.clip_samples_min, self.clip_samples_max = clip_samples, clip_samples_min, clip_samples_max
+        self.symmetric_noise = False
+        self.use_graph = use_graph
+        self.seed = 1234
+        self.last_stats = None
+        self.sigma_steps = torch.from_numpy(_lib.sigma_schedule(self._cfg())[0])
+
+    def _cfg(self) -> _lib.DsgSamplerCfg:
+        return _lib.make_sampler_cfg(self.num_steps, self.solver, float(self.S_churn), float(self.S_min), float(self.S_max),
+                                     float(self.S_noise), float(self.sigma_min), float(self.sigma_max), 7.0, self.use_graph)
+
+    @staticmethod
+    def adj_to_int(adjs_cont, node_flags, threshold):
+        f = node_flags.to(adjs_cont.dtype)
+        m = f.unsqueeze(-1) * f.unsqueeze(-2)
+        if adjs_cont.dim() == 4:
+            m = m.unsqueeze(1)
+        return (adjs_cont >= threshold).to(adjs_cont.dtype) * m
+
+    @staticmethod
+    def get_num_edges(adjs_cont, node_flags, threshold):
+        return (NodeAdjEDMSamplerHip.adj_to_int(adjs_cont, node_flags, threshold) > 0.0).sum([-1, -2]).float() / 2.0
+
+    def draw_coins(self, n_calls: int) -> np.ndarray:
+        """One `np.random.rand() < 0.5` per preconditioned call, in call order -- the same draws, from the same
+        global NumPy generator, the reference makes inside NodeAdjPrecond.forward (precond.py:90)."""
+        if not self.self_condition:
+            return np.zeros(n_calls, dtype=np.uint8)
+        return np.array([np.random.rand() < 0.5 for _ in range(n_calls)], dtype=np.uint8)
+
+    @torch.no_grad()
+    def sample(self, model, node_flags, init_adjs=None, init_nodes=None,
+               sanity_check_gt_adjs=None, sanity_check_gt_nodes=None,
+               flag_interim_adjs=False, max_num_interim_adjs=None, flag_use_double=False,
+               flag_node_multi_channel=False, flag_adj_multi_channel=False,
+               num_node_chan=150, num_edge_chan=51, churn_noise=None, coins=None, seed=None, return_device=False):
+        """See NodeAdjEDMSampler.sample (edm.py:291).  Extra keyword-only knobs (not in the reference):
+        `churn_noise=(adj [T,B,..], node [T,B,..])` and `coins` replay recorded randomness (parity tests);
+        `seed` seeds the on-device Philox streams; `return_device=True` skips the final `.cpu()`."""
+        if flag_use_double:
+            raise NotImplementedError("flag_use_double: the HIP path computes in fp32 (the reference default)")
+        if isinstance(model, (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel)):
+            model = model.module
+        if not isinstance(model, NodeAdjPrecondHip):
+            raise TypeError("NodeAdjEDMSamplerHip needs the NodeAdjPrecondHip network returned by build_network()")
+        net = model.model
+        h = net._ensure_handle()
+        cfg = net.config
+        assert num_node_chan == cfg.c_node and num_edge_chan == cfg.c_adj, "channel counts do not match the network"
+        B, n, T = node_flags.shape[0], cfg.max_node_num, self.num_steps
+        dev = net._dev
+        fl = node_flags.to(device=dev).to(torch.uint8).contiguous()
+
+        def prep(x, shape):
+            return None if x is None else x.to(device=dev, dtype=torch.float32).reshape(shape).contiguous()
+        sa, sn = (B, cfg.c_adj, n, n), (B, n, cfg.c_node)
+        if init_adjs is None or init_nodes is None:
+            init_adjs = init_nodes = None  # both are redrawn together (edm.py:325-329)
+        ia, inn = prep(init_adjs, sa), prep(init_nodes, sn)
+        ga, gn = prep(sanity_check_gt_adjs, sa), prep(sanity_check_gt_nodes, sn)
+        na = nn_ = None
+        if churn_noise is not None:
+            na, nn_ = prep(churn_noise[0], (T,) + sa), prep(churn_noise[1], (T,) + sn)
+        n_calls = T if self.solver == "euler" else 2 * T - 1
+        if coins is None:
+            coins = self.draw_coins(n_calls) if ga is None else np.zeros(n_calls, np.uint8)
+        coins = np.ascontiguousarray(coins, dtype=np.uint8)
+        assert coins.size >= n_calls
+        # snapshot schedule (edm.py:333-337, :429-432)
+        snap_steps = None
+        snap_a = snap_n = None
+        if flag_interim_adjs:
+            if max_num_interim_adjs is None:
+                ts = np.arange(T)
+            else:
+                ts = np.linspace(0, T, max_num_interim_adjs).astype(int).clip(max=T - 1)
+            snap_steps = np.ascontiguousarray(np.unique(ts), dtype=np.int32)
+            snap_n = torch.empty((len(snap_steps),) + sn, dtype=torch.float32, device=dev)
+            if not flag_adj_multi_channel:
+                snap_a = torch.empty((len(snap_steps),) + sa, dtype=torch.float32, device=dev)
+        oa = torch.empty(sa, dtype=torch.float32, device=dev)
+        on = torch.empty(sn, dtype=torch.float32, device=dev)
+        stats = _lib.DsgSampleStats()
+        scfg = self._cfg()
+        st = torch.cuda.current_stream(dev).cuda_stream
+        p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+        init_keep = None
+        if flag_interim_adjs and ia is None:
+            raise NotImplementedError("interim snapshots with library-drawn initial noise: pass init_adjs/init_nodes")
+        h.check(h.L.dsg_sample(h.raw, C.byref(scfg), B, p(fl), p(ia), p(inn), p(na), p(nn_),
+                               C.c_void_p(coins.ctypes.data), C.c_uint64(self.seed if seed is None else int(seed)),
+                               p(ga), p(gn),
+                               C.c_void_p(0 if snap_steps is None else snap_steps.ctypes.data),
+                               0 if snap_steps is None else len(snap_steps), p(snap_a), p(snap_n),
+                               p(oa), p(on), C.byref(stats), C.c_void_p(st)), "dsg_sample")
+        self.last_stats = {"precond_calls": stats.precond_calls, "net_forwards": stats.net_forwards,
+                           "graph_replays": stats.graph_replays}
+        logging.info("Done with EDM-NodeAdj MCMC (HIP).")
+        if cfg.c_adj == 1:
+            oa = oa[:, 0]
+        if cfg.c_node == 1:
+            on = on[..., 0]
+        if return_device:
+            return oa, on
+        adjs, nodes = oa.cpu(), on.cpu()
+        if flag_interim_adjs:
+            nodes_ls = torch.cat([inn.cpu().reshape((1,) + sn), snap_n.cpu()])
+            if flag_adj_multi_channel:
+                return adjs, nodes, [None], nodes_ls
+            adjs_ls = torch.cat([ia.cpu().reshape((1,) + sa), snap_a.cpu()])
+            return adjs, nodes, adjs_ls, nodes_ls
+        return adjs, nodes

@@ -1,0 +1,146 @@
+/*
+ * dsg.h -- C ABI of libdsg.so: the MI355X (gfx950) scene-graph diffusion sampler.
+ *
+ * The reference (ubc-vision/DiffuseSG) has no FFI layer; its seam for this path is three
+ * Python callables.  Each entry point below names the reference interface it
+ * replaces (R/ = DiffuseSG/ in the reference tree):
+ *
+ *   dsg_denoise  <->  DiffuseSG.forward                R/model/diffusesg/diffusesg.py:765
+ *   dsg_precond  <->  NodeAdjPrecond.forward           R/model/precond/precond.py:65
+ *   dsg_sample   <->  NodeAdjEDMSampler.sample         R/runner/mcmc_sampler/edm.py:291
+ *   dsg_set_weight / dsg_finalize_weights <-> load_model(strict=True)  R/utils/sampling_utils.py:34
+ *   dsg_create   <->  get_network's DiffuseSG(...) ctor kwargs         R/utils/learning_utils.py:47-64
+ *
+ * Conventions
+ *   - return 0 on success, a negative dsg_status otherwise; dsg_last_error(h) has the message.
+ *   - plain pointers and sizes only.  All tensor arguments are DEVICE pointers to contiguous
+ *     fp32 (flags: uint8) in the reference's layouts:
+ *        adj   [B, C_adj, N, N]     node  [B, N, C_node]     flags [B, N] (1 = valid node)
+ *     (the reference squeezes singleton channel dims; the memory layout is unchanged).
+ *   - the caller owns every I/O buffer; the library owns packed weights and its workspace and
+ *     never mutates an input.  One handle per device, not re-entrant.  All work is enqueued on
+ *     the caller's stream (`stream` is a hipStream_t passed as void*; NULL = default stream).
+ *   - there is no CPU fallback: every entry point fails with DSG_ERR_HIP if the device is missing.
+ */
+#ifndef DSG_H
+#define DSG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSG_MAX_LAYERS 8
+
+typedef enum {
+    DSG_OK = 0,
+    DSG_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    DSG_ERR_WEIGHTS = -2,   /* unknown key, shape mismatch, or missing tensor at finalize */
+    DSG_ERR_HIP = -3,       /* HIP runtime error (no device, out of memory, launch failure) */
+    DSG_ERR_STATE = -4      /* call order violated (e.g. denoise before finalize_weights) */
+} dsg_status;
+
+typedef struct dsg_handle_s *dsg_handle;
+
+/* Mirrors the kwargs of DiffuseSG(...) as passed by get_network (learning_utils.py:47-64). */
+typedef struct dsg_config {
+    int32_t max_node_num;              /* img_size (N); patch_size is 1 */
+    int32_t c_adj;                     /* out_chans_adj */
+    int32_t c_node;                    /* out_chans_node */
+    int32_t embed_dim;                 /* feature_dims[-1], 96 */
+    int32_t num_layers;                /* len(depths) */
+    int32_t depths[DSG_MAX_LAYERS];
+    int32_t num_heads[DSG_MAX_LAYERS]; /* [3,6,12,24]; head_dim must be 32 */
+    int32_t window_size;
+    int32_t mlp_ratio;                 /* 4 */
+    int32_t self_condition;            /* train.self_cond */
+} dsg_config;
+
+/* Mirrors NodeAdjEDMSampler.__init__ (edm.py:236-255) for discretization='edm', schedule='linear',
+ * scaling='none' (the only combination get_mc_sampler builds, sampling_utils.py:15-23). */
+typedef struct dsg_sampler_cfg {
+    int32_t num_steps;
+    int32_t heun;                      /* 1: solver='heun', 0: 'euler' */
+    float S_churn, S_min, S_max, S_noise;
+    double sigma_min, sigma_max, rho;  /* 0.002, 80, 7 */
+    int32_t use_graph;                 /* 1: replay the network forward from a captured hipGraph */
+    int32_t reserved;
+} dsg_sampler_cfg;
+
+/* Counters of the last dsg_sample call. */
+typedef struct dsg_sample_stats {
+    int64_t precond_calls;             /* 2T-1 (heun) or T (euler) */
+    int64_t net_forwards;              /* precond_calls + number of coins that fired */
+    int64_t graph_replays;
+} dsg_sample_stats;
+
+int dsg_create(const dsg_config *cfg, dsg_handle *out);
+void dsg_destroy(dsg_handle h);
+const char *dsg_last_error(dsg_handle h);
+const char *dsg_version(void);
+
+/* `key` is the reference state-dict name, with or without the 'model.' prefix of the precond
+ * wrapper (precond.py:15) and/or the 'module.' prefix of DDP (sampling_utils.py:47-53).
+ * `data` is fp32 (int64 for relative_position_index, which is validated and dropped);
+ * is_device != 0 means `data` is a device pointer. */
+int dsg_set_weight(dsg_handle h, const char *key, const void *data, const int64_t *shape, int32_t ndim,
+                   int32_t is_device);
+/* Packs derived tables; fails with DSG_ERR_WEIGHTS naming the first missing tensor (strict=True). */
+int dsg_finalize_weights(dsg_handle h);
+/* Number of state-dict keys expected / names, to let a binding iterate them. */
+int dsg_num_weight_keys(dsg_handle h);
+const char *dsg_weight_key(dsg_handle h, int32_t i);
+
+/* Device bytes the library holds for batch size B (activations + sampler state). */
+size_t dsg_workspace_bytes(dsg_handle h, int32_t B);
+
+/* DiffuseSG.forward: noise_labels[B] = c_noise; sc_adj / sc_node may be NULL (zeros). */
+int dsg_denoise(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags,
+                const float *noise_labels, const float *sc_adj, const float *sc_node,
+                float *out_adj, float *out_node, void *stream);
+
+/* NodeAdjPrecond.forward with precond='edm'.  `coin` is the outcome of the reference's
+ * `np.random.rand() < 0.5` (precond.py:90), drawn by the caller. */
+int dsg_precond(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags,
+                const float *sigmas, const float *sc_adj, const float *sc_node, int32_t coin,
+                float *out_adj, float *out_node, void *stream);
+
+/* NodeAdjEDMSampler.sample.
+ *   init_adj/init_node  NULL: drawn on device (Philox, `seed`), masked (gen_init_sample, edm.py:257-289)
+ *   noise_adj [T,B,C_adj,N,N], noise_node [T,B,N,C_node]  NULL: churn noise drawn on device
+ *   coins [precond calls] host pointer, one byte per preconditioned call in call order;
+ *         NULL: Bernoulli(0.5) from a host generator seeded with `seed`
+ *   gt_adj/gt_node non-NULL: sanity-check mode (edm.py:372-377), the denoiser is bypassed
+ *   snap_steps/snap_adj/snap_node: optional interim snapshots (edm.py:429-432): after step
+ *         snap_steps[k] the state is copied to slot k of snap_adj / snap_node (device) */
+int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_t *flags,
+               const float *init_adj, const float *init_node,
+               const float *noise_adj, const float *noise_node,
+               const uint8_t *coins, uint64_t seed,
+               const float *gt_adj, const float *gt_node,
+               const int32_t *snap_steps, int32_t n_snap, float *snap_adj, float *snap_node,
+               float *out_adj, float *out_node, dsg_sample_stats *stats, void *stream);
+
+/* sigma_steps (fp64, edm.py:84-88) and the fp32 per-step scalars the loop uses; out arrays of
+ * length num_steps.  Host-only helper, exposed so bindings/tests can inspect the schedule. */
+int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t_hat, float *noise_coef,
+                       float *h_step);
+
+/* Debug: copy the named stage's activation (e.g. "down0.block0") of the next dsg_denoise call to
+ * `dst` (device, capacity in floats).  Token-major [B, T, C]. */
+int dsg_debug_tap(dsg_handle h, const char *stage, float *dst, int64_t capacity);
+void dsg_debug_clear_taps(dsg_handle h);
+
+/* On-device post-decode of 'bits'-encoded samples (sampler_node_adj.py:222-285):
+ * clamp(-1,1) -> >0 -> MSB-first integer -> clamp to [0, n_type-1]; adjacency diagonal zeroed. */
+int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags,
+                    int32_t n_adj_type, int32_t n_node_type, int32_t node_bits,
+                    int32_t *out_adj /*[B,N,N]*/, int32_t *out_node /*[B,N]*/, float *out_bbox /*[B,N,4] or NULL*/,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSG_H */

@@ -596,7 +596,8 @@ NO_FMA int dsgref_sample(dsgref *h, const dsgref_sampler_cfg *c, int B, const ui
     int have_sc = 0, call = 0;
     for (size_t i = 0; i < sa; i++) xa[i] = init_adj[i] * t_steps[0]; /* :346-347 */
     for (size_t i = 0; i < sn; i++) xn[i] = init_node[i] * t_steps[0];
-    const float gamma_on = fminf(c->S_churn / (float)T, sqrtf(2.0f) - 1.0f);
+    /* python: min(S_churn / num_steps, np.sqrt(2) - 1) in double; becomes fp32 when multiplied with t_cur */
+    const float gamma_on = (float)fmin((double)c->S_churn / (double)T, sqrt(2.0) - 1.0);
     const int nsteps = (c->max_steps > 0 && c->max_steps < T) ? c->max_steps : T;
     for (int i = 0; i < nsteps; i++) {
         const float t_cur = t_steps[i], t_next = t_steps[i + 1];
