@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py -- scene-graphs/sec of the MI355X sampling path on BASELINE.json's headline configuration.
+
+One "step" = one full pass of the hot path over one batch: NodeAdjEDMSamplerHip.sample() of B graphs with the
+reference sampler settings (Visual-Genome shape: 64 padded / 30 valid nodes, 6 adjacency + 12 node channels,
+stochastic Heun, S_churn=40, num_steps T=1000, fp32), from on-device initial noise to the raw generated
+(adj, node) resident in HBM, followed (N>1) by the single all-gather of the packed results.  Nothing is skipped:
+every preconditioned call, every coin-triggered extra self-conditioning forward, churn noise and masking run.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task prompt) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from diffusesg_amd import dist as dsg_dist  # noqa: E402
+from diffusesg_amd import spec, synth, weights  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def cpu_baseline(cfg, sd, T, valid, budget_s=20.0):
+    """The ORACLE (oracle/dsg_ref.c, kind 'port') timed on this box's host cores on a bounded sample of the same
+    workload: B=2 graphs, the first `max_steps` sampler steps with the same coin stream; extrapolated by network
+    forwards (per-forward cost is constant)."""
+    from oracle.oracle import Oracle
+    orc = Oracle(cfg, sd)
+    cores = os.cpu_count() if not hasattr(os, "sched_getaffinity") else len(os.sched_getaffinity(0))
+    B = max(2, min(64, cores))   # one sample per thread (the oracle parallelises over the batch)
+    flags, ia, inn, _, _, cv = synth.sampler_case(cfg, 4, B, valid, 77, "bench/cpu")
+    coins_all = (weights.coins(77, "bench/cpu/all", 2 * T - 1) < 0.5).astype(np.uint8)
+    nfe_total = (2 * T - 1) + int(coins_all.sum())
+    steps, elapsed, nfe = 1, 0.0, 0
+    while True:
+        n0 = orc.nfe
+        t0 = time.perf_counter()
+        orc.sample(flags, ia, inn, None, None, coins_all, num_steps=T, max_steps=steps)
+        elapsed = time.perf_counter() - t0
+        nfe = orc.nfe - n0
+        if elapsed >= budget_s / 2 or steps >= 64:
+            break
+        steps = min(64, max(steps + 1, int(steps * (budget_s * 0.75) / max(elapsed, 1e-3))))
+    per_fwd = elapsed / nfe
+    graphs_per_s = B / (per_fwd * nfe_total)
+    return {"value": graphs_per_s, "unit": "scene-graphs/s", "cores": int(min(cores, B)), "kind": "port",
+            "sample": f"oracle/dsg_ref.c (OpenMP, one graph per thread), VG config B={B}, first {steps} of T={T} Heun steps = {nfe} network "
+                      f"forwards in {elapsed:.1f} s, scaled to {nfe_total} forwards/graph-batch"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="graphs per GPU per step (configs[1]: 64)")
+    ap.add_argument("--num-steps", type=int, default=1000, help="sampler steps T (BASELINE metric: 1000)")
+    ap.add_argument("--config", default="vg", choices=["vg", "coco", "tiny"])
+    ap.add_argument("--valid", type=int, default=None, help="valid nodes per graph (VG: 30)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=1234)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from diffusesg_amd.model import build_network
+    from diffusesg_amd.sampler import NodeAdjEDMSamplerHip
+
+    cfg = synth.CONFIGS[args.config]()
+    n = cfg.max_node_num
+    valid = args.valid if args.valid is not None else {"vg": 30, "coco": 20, "tiny": 8}[args.config]
+    sd = weights.synth_state_dict(cfg, 0)
+    net = build_network(cfg, sd, device=dev)
+    T, B = args.num_steps, args.batch
+    smp = NodeAdjEDMSamplerHip(num_steps=T, solver="heun", S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
+                               clip_samples=True, clip_samples_min=-1.0, clip_samples_max=1.0, clip_samples_scope="x_0",
+                               self_condition=cfg.self_condition, dev=dev, use_graph=not args.no_graph)
+    flags = torch.from_numpy(weights.synth_flags(B, n, valid)).to(dev)
+    seed = dsg_dist.rank_seed(args.seed, rank)
+    np.random.seed(seed)   # the coin stream (np.random.rand, precond.py:90) is part of the workload
+
+    def one_step(k):
+        oa, on = smp.sample(net, flags, num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj, seed=seed + 1000 * k,
+                            return_device=True)
+        packed = dsg_dist.pack_results(oa.reshape(B, cfg.c_adj, n, n), on.reshape(B, n, cfg.c_node))
+        return dsg_dist.gather_results(packed), dict(smp.last_stats)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for k in range(args.warmup):
+        one_step(-1 - k)
+    fence()
+    t0 = time.perf_counter()
+    nfe = 0
+    out = None
+    for k in range(args.steps):
+        out, st = one_step(k)
+        nfe += st["net_forwards"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert out.shape[0] == world * B and bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        graphs = world * B * args.steps
+        value = graphs / elapsed
+        f_fwd = spec.flops_per_forward(cfg)
+        # roofline of the dominant kernel (gemm_f32_kernel): HIP events around every launch of eager forwards on the
+        # state the timed run left in the workspace (random-data clocks, not zeros)
+        h = net.model._ensure_handle()
+        ms, cnt, fl = (C.c_double * 4)(), (C.c_int64 * 4)(), (C.c_double * 4)()
+        iters = 3
+        st_ptr = torch.cuda.current_stream(dev).cuda_stream
+        h.check(h.L.dsg_profile_forward(h.raw, B, iters, ms, cnt, fl, C.c_void_p(st_ptr)), "dsg_profile_forward")
+        gemm_avg_ms = ms[0] / cnt[0]
+        achieved = (fl[0] / cnt[0]) / (gemm_avg_ms * 1e-3) / 1e12
+        kinds = ["gemm_f32", "window_attn", "row", "elementwise"]
+        breakdown = {kinds[i]: {"ms_per_forward": ms[i] / iters, "launches_per_forward": cnt[i] // iters,
+                                "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] > 0 else None} for i in range(4)}
+        roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "avg_launch_ms": gemm_avg_ms, "flops_per_launch": fl[0] / cnt[0], "launches_per_forward": cnt[0] // iters,
+                    "forward_breakdown": breakdown}
+        # whole-path achieved rate: graphs/s/GPU x forwards per graph x FLOPs per forward
+        roofline["whole_path_tflops"] = nfe * B * f_fwd / elapsed / 1e12
+        roofline["whole_path_frac"] = roofline["whole_path_tflops"] / PEAK_F32_MFMA_TFLOPS
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(cfg, sd, T, valid)
+        line = {
+            "metric": "scene-graphs/sec", "value": value, "unit": "scene-graphs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}-bits N={n} valid={valid} C_adj={cfg.c_adj} C_node={cfg.c_node} "
+                                   f"T={T} heun S_churn=40 self_cond={int(cfg.self_condition)}",
+                       "batch_per_gpu": B, "global_batch": world * B, "num_steps": T,
+                       "net_forwards_per_step": nfe / args.steps, "gflop_per_forward_per_graph": f_fwd / 1e9,
+                       "hip_graph": not args.no_graph, "parallelism": f"batch-sharded x{world}, one all-gather"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

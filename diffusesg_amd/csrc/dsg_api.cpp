@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -85,6 +86,13 @@ struct dsg_handle_s {
     std::map<int, std::unique_ptr<Workspace>> ws;
     std::vector<Tap> taps;
     dsg_sample_stats last_stats{};
+    // per-kernel-class timing (dsg_profile_forward): HIP events bracketing every launch on the launch stream
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_events;
+    size_t prof_used = 0;
+    std::vector<int> prof_kind;
+    std::vector<double> prof_flops;
+    std::vector<std::string> prof_tag;
 };
 
 namespace {
@@ -104,6 +112,29 @@ int fail(dsg_handle h, int code, const char *fmt, ...) {
         hipError_t e_ = (expr);                                                                   \
         if (e_ != hipSuccess) return fail(h, DSG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+enum ProfKind { PK_GEMM = 0, PK_ATTN = 1, PK_ROW = 2, PK_ELEM = 3, PK_COUNT = 4 };
+
+struct ProfScope {
+    dsg_handle h; hipStream_t s;
+    ProfScope(dsg_handle h_, hipStream_t s_, int kind, double flops, const char *tag = nullptr) : h(h_), s(s_) {
+        if (!h->prof_on) return;
+        while (h->prof_events.size() < h->prof_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) { h->prof_on = false; return; }
+            h->prof_events.push_back(e);
+        }
+        h->prof_kind.push_back(kind);
+        h->prof_flops.push_back(flops);
+        h->prof_tag.push_back(tag ? tag : "");
+        (void)hipEventRecord(h->prof_events[h->prof_used], s);
+    }
+    ~ProfScope() {
+        if (!h->prof_on) return;
+        (void)hipEventRecord(h->prof_events[h->prof_used + 1], s);
+        h->prof_used += 2;
+    }
+};
 
 int level_window(const dsg_config &c, int lvl) {
     const int r = c.max_node_num >> lvl;
@@ -295,6 +326,7 @@ void dsg_destroy(dsg_handle h) {
     if (!h) return;
     for (auto &kv : h->w) (void)hipFree(kv.second.p);
     for (void *p : h->derived_allocs) (void)hipFree(p);
+    for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     for (auto &kv : h->ws) {
         if (kv.second->graph) (void)hipGraphExecDestroy(kv.second->graph);
         if (kv.second->cap_stream) (void)hipStreamDestroy(kv.second->cap_stream);
@@ -477,37 +509,41 @@ void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStre
             (void)hipMemcpyAsync(t.dst, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, s);
 }
 
+#define P_GEMM(g) do { char tg_[96]; if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm M=%d N=%d K=%d ln=%d act=%d res=%d", (g).M, (g).N, (g).K, (g).ln_stats != nullptr, (g).act, (g).res != nullptr); \
+    ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)(g).M * (double)(g).N * (double)(g).K, tg_); launch_gemm((g), s); } while (0)
+#define P_KERN(kind, flops, call) do { ProfScope ps_(h, s, (kind), (flops), #call); call; } while (0)
+
 // One Swin block (diffusesg.py:232-277) on x [B*T, C] in place.
 void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
     const int B = w->B, T = b.res * b.res, C = b.C, M = B * T, Hd = h->cfg.mlp_ratio * C;
     const std::string &p = b.prefix;
     // x <- silu(shift + x*(1+scale)) (also the shortcut), LayerNorm-1 statistics
-    launch_mod_stats(w->x, w->aff, h->aff_n, b.aff_off, w->stats, B, T, C, s);
+    P_KERN(PK_ROW, 0.0, launch_mod_stats(w->x, w->aff, h->aff_n, b.aff_off, w->stats, B, T, C, s));
     GemmArgs g;
     g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M;
     g.ln_stats = w->stats; g.ln_g = WT(h, p + ".norm1.weight"); g.ln_b = WT(h, p + ".norm1.bias");
     g.W = WT(h, p + ".attn.qkv.weight"); g.bias = WT(h, p + ".attn.qkv.bias"); g.N = 3 * C;
     g.C = w->qkv; g.ldc = 3 * C;
-    launch_gemm(g, s);
+    P_GEMM(g);
     WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
-    launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s);
+    P_KERN(PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s));
     g = GemmArgs();
     g.A = w->att; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = C;
     g.W = WT(h, p + ".attn.proj.weight"); g.bias = WT(h, p + ".attn.proj.bias");
     g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
-    launch_gemm(g, s);
-    launch_ln_stats(w->x, w->stats, M, C, s);
+    P_GEMM(g);
+    P_KERN(PK_ROW, 0.0, launch_ln_stats(w->x, w->stats, M, C, s));
     g = GemmArgs();
     g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = Hd;
     g.ln_stats = w->stats; g.ln_g = WT(h, p + ".norm2.weight"); g.ln_b = WT(h, p + ".norm2.bias");
     g.W = WT(h, p + ".mlp.fc1.weight"); g.bias = WT(h, p + ".mlp.fc1.bias"); g.act = ACT_GELU;
     g.C = w->hid; g.ldc = Hd;
-    launch_gemm(g, s);
+    P_GEMM(g);
     g = GemmArgs();
     g.A = w->hid; g.lda = Hd; g.K1 = Hd; g.K = Hd; g.M = M; g.N = C;
     g.W = WT(h, p + ".mlp.fc2.weight"); g.bias = WT(h, p + ".mlp.fc2.bias");
     g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
-    launch_gemm(g, s);
+    P_GEMM(g);
 }
 
 // DiffuseSG.forward on the workspace's fixed buffers: (in_adj,in_node,sc_*,flags,c_noise) -> (f_adj,f_node)
@@ -516,27 +552,27 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     const int B = w->B, N = h->N, E = h->E, L = h->L, T0 = N * N;
     char name[64];
     // noise embedding (diffusesg.py:768-771) and every block's (scale,shift) in one GEMM
-    launch_noise_pe(w->c_noise, w->pe, B, E, s);
+    P_KERN(PK_ELEM, 0.0, launch_noise_pe(w->c_noise, w->pe, B, E, s));
     GemmArgs g;
     g.A = w->pe; g.lda = E; g.K1 = E; g.K = E; g.M = B; g.N = NOISE_EMB; g.act = ACT_SILU;
     g.W = WT(h, "map_layer0.weight"); g.bias = WT(h, "map_layer0.bias"); g.C = w->emb0; g.ldc = NOISE_EMB;
-    launch_gemm(g, s);
+    P_GEMM(g);
     g.A = w->emb0; g.lda = NOISE_EMB; g.K1 = NOISE_EMB; g.K = NOISE_EMB;
     g.W = WT(h, "map_layer1.weight"); g.bias = WT(h, "map_layer1.bias"); g.C = w->emb;
-    launch_gemm(g, s);
+    P_GEMM(g);
     g = GemmArgs();
     g.A = w->emb; g.lda = NOISE_EMB; g.K1 = NOISE_EMB; g.K = NOISE_EMB; g.M = B; g.N = h->aff_n;
     g.W = h->aff_w; g.bias = h->aff_b; g.C = w->aff; g.ldc = h->aff_n;
-    launch_gemm(g, s);
+    P_GEMM(g);
     // input assembly + PatchEmbed (diffusesg.py:784-802, 562-577)
-    launch_assemble(w->in_adj, w->in_node, w->sc_adj, w->sc_node, w->has_sc, w->flags, w->tok_in, B, N, h->Ca, h->Cn,
-                    c.self_condition, h->Kp, s);
+    P_KERN(PK_ELEM, 0.0, launch_assemble(w->in_adj, w->in_node, w->sc_adj, w->sc_node, w->has_sc, w->flags, w->tok_in, B, N, h->Ca, h->Cn,
+                    c.self_condition, h->Kp, s));
     g = GemmArgs();
     g.A = w->tok_in; g.lda = h->Kp; g.K1 = h->Kp; g.K = h->Kp; g.M = B * T0; g.N = E;
     g.W = h->pe_w; g.bias = WT(h, "patch_embed.proj.bias"); g.C = w->y; g.ldc = E;
-    launch_gemm(g, s);
-    launch_ln_mod(w->y, WT(h, "patch_embed.norm.weight"), WT(h, "patch_embed.norm.bias"), w->aff, h->aff_n, h->pe_aff_off,
-                  w->x, B, T0, E, s);
+    P_KERN(PK_GEMM, 2.0 * (double)g.M * (double)g.N * (double)h->Cin, launch_gemm(g, s));  // padded K is not algorithmic work
+    P_KERN(PK_ROW, 0.0, launch_ln_mod(w->y, WT(h, "patch_embed.norm.weight"), WT(h, "patch_embed.norm.bias"), w->aff, h->aff_n, h->pe_aff_off,
+                  w->x, B, T0, E, s));
     tap(h, "patch_embed", w->x, (size_t)B * T0 * E, s);
     // encoder (diffusesg.py:745-748)
     for (int l = 0; l < L; l++) {
@@ -548,11 +584,11 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
         }
         if (l < L - 1) {
             const std::string p = "down_layers." + std::to_string(l) + ".downsample";
-            launch_merge_ln(w->x, WT(h, p + ".norm.weight"), WT(h, p + ".norm.bias"), w->y, B, res, C, s);
+            P_KERN(PK_ROW, 0.0, launch_merge_ln(w->x, WT(h, p + ".norm.weight"), WT(h, p + ".norm.bias"), w->y, B, res, C, s));
             g = GemmArgs();
             g.A = w->y; g.lda = 4 * C; g.K1 = 4 * C; g.K = 4 * C; g.M = B * T / 4; g.N = 2 * C;
             g.W = WT(h, p + ".reduction.weight"); g.C = w->x; g.ldc = 2 * C; g.C2 = w->skips[l]; g.ldc2 = 2 * C;
-            launch_gemm(g, s);
+            P_GEMM(g);
         }
         snprintf(name, sizeof(name), "down%d", l);
         tap(h, name, w->x, l < L - 1 ? (size_t)B * (T / 4) * 2 * C : (size_t)B * T * C, s);
@@ -567,13 +603,13 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
             g = GemmArgs();                   // pre_linear on cat([x, skip]) without materialising the concat
             g.A = w->x; g.lda = D / 2; g.K1 = D / 2; g.A2 = w->skips[l]; g.lda2 = D / 2; g.K = D; g.M = B * Tc; g.N = D;
             g.W = WT(h, p + ".pre_linear.weight"); g.C = w->hid; g.ldc = D;
-            launch_gemm(g, s);
-            launch_breakup_ln(w->hid, WT(h, p + ".norm.weight"), WT(h, p + ".norm.bias"), WT(h, p + ".post_norm.weight"),
-                              WT(h, p + ".post_norm.bias"), w->y, B, res / 2, D, s);
+            P_GEMM(g);
+            P_KERN(PK_ROW, 0.0, launch_breakup_ln(w->hid, WT(h, p + ".norm.weight"), WT(h, p + ".norm.bias"), WT(h, p + ".post_norm.weight"),
+                              WT(h, p + ".post_norm.bias"), w->y, B, res / 2, D, s));
             g = GemmArgs();
             g.A = w->y; g.lda = C; g.K1 = C; g.K = C; g.M = B * T; g.N = C;
             g.W = WT(h, p + ".post_linear.weight"); g.C = w->x; g.ldc = C;
-            launch_gemm(g, s);
+            P_GEMM(g);
             snprintf(name, sizeof(name), "up%d.upsample", i);
             tap(h, name, w->x, (size_t)B * T * C, s);
         }
@@ -585,33 +621,33 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     }
     // final norm + read_out (diffusesg.py:758-761)
     const int M0 = B * T0;
-    launch_ln_stats(w->x, w->stats, M0, E, s);
+    P_KERN(PK_ROW, 0.0, launch_ln_stats(w->x, w->stats, M0, E, s));
     g = GemmArgs();
     g.A = w->x; g.lda = E; g.K1 = E; g.K = E; g.M = M0; g.N = E;
     g.ln_stats = w->stats; g.ln_g = WT(h, "norm.weight"); g.ln_b = WT(h, "norm.bias");
     g.W = h->ro0_w; g.bias = WT(h, "read_out.0.bias"); g.C = w->y; g.ldc = E;
-    launch_gemm(g, s);
+    P_GEMM(g);
     g = GemmArgs();
     g.A = w->y; g.lda = E; g.K1 = E; g.K = E; g.M = M0; g.N = E;
     g.W = WT(h, "read_out.1.weight"); g.bias = WT(h, "read_out.1.bias"); g.C = w->att; g.ldc = E;
-    launch_gemm(g, s);
+    P_GEMM(g);
     g.A = w->att; g.W = WT(h, "read_out.2.weight"); g.bias = WT(h, "read_out.2.bias"); g.C = w->y;
-    launch_gemm(g, s);  // y = shared_rep, token-major
+    P_GEMM(g);  // y = shared_rep, token-major
     tap(h, "read_out", w->y, (size_t)M0 * E, s);
     // adjacency head (diffusesg.py:806-809, :825)
     g.A = w->y; g.W = WT(h, "readout_adj_mlp.fc1.weight"); g.bias = WT(h, "readout_adj_mlp.fc1.bias"); g.act = ACT_GELU;
     g.C = w->att;
-    launch_gemm(g, s);
-    launch_head_adj(w->att, WT(h, "readout_adj_mlp.fc2.weight"), WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, B, N, E,
-                    h->Ca, s);
+    P_GEMM(g);
+    P_KERN(PK_ROW, 0.0, launch_head_adj(w->att, WT(h, "readout_adj_mlp.fc2.weight"), WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, B, N, E,
+                    h->Ca, s));
     // node head (diffusesg.py:812-822)
-    launch_pool(w->y, w->flags, w->pool, B, N, E, s);
+    P_KERN(PK_ELEM, 0.0, launch_pool(w->y, w->flags, w->pool, B, N, E, s));
     g = GemmArgs();
     g.A = w->pool; g.lda = E; g.K1 = E; g.K = E; g.M = B * N; g.N = E; g.act = ACT_GELU;
     g.W = WT(h, "readout_node_mlp.fc1.weight"); g.bias = WT(h, "readout_node_mlp.fc1.bias"); g.C = w->hn; g.ldc = E;
-    launch_gemm(g, s);
-    launch_head_node(w->hn, WT(h, "readout_node_mlp.fc2.weight"), WT(h, "readout_node_mlp.fc2.bias"), w->flags, w->f_node, B, N,
-                     E, h->Cn, s);
+    P_GEMM(g);
+    P_KERN(PK_ROW, 0.0, launch_head_node(w->hn, WT(h, "readout_node_mlp.fc2.weight"), WT(h, "readout_node_mlp.fc2.bias"), w->flags, w->f_node, B, N,
+                     E, h->Cn, s));
 }
 
 // run forward_fixed either eagerly or by replaying a captured graph
@@ -850,6 +886,35 @@ int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_
     h->last_stats.precond_calls = call;
     h->last_stats.net_forwards = nfe;
     if (stats) *stats = h->last_stats;
+    return DSG_OK;
+}
+
+int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_kind, int64_t *launches_by_kind,
+                        double *flops_by_kind, void *stream) {
+    if (int rc = check_ready(h, B)) return rc;
+    if (!ms_by_kind || !launches_by_kind || !flops_by_kind || n_iters < 1) return fail(h, DSG_ERR_INVALID, "null argument");
+    auto it = h->ws.find(B);
+    if (it == h->ws.end()) return fail(h, DSG_ERR_STATE, "no workspace for batch %d: run dsg_denoise/dsg_sample first", B);
+    hipStream_t s = (hipStream_t)stream;
+    Workspace *w = it->second.get();
+    for (int k = 0; k < PK_COUNT; k++) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; flops_by_kind[k] = 0.0; }
+    for (int iter = 0; iter < n_iters; iter++) {
+        h->prof_on = true; h->prof_used = 0; h->prof_kind.clear(); h->prof_flops.clear(); h->prof_tag.clear();
+        forward_fixed(h, w, s);
+        const bool ok = h->prof_on;
+        h->prof_on = false;
+        HIP_TRY(h, hipStreamSynchronize(s));
+        if (!ok) return fail(h, DSG_ERR_HIP, "hipEventCreate failed");
+        for (size_t i = 0; i < h->prof_kind.size(); i++) {
+            float ms = 0.f;
+            HIP_TRY(h, hipEventElapsedTime(&ms, h->prof_events[2 * i], h->prof_events[2 * i + 1]));
+            if (iter == n_iters - 1 && getenv("DSG_PROFILE_VERBOSE"))
+                fprintf(stderr, "[dsg-prof] %8.1f us %7.2f TF  %.60s\n", ms * 1e3, h->prof_flops[i] / (ms * 1e-3) / 1e12, h->prof_tag[i].c_str());
+            ms_by_kind[h->prof_kind[i]] += ms;
+            launches_by_kind[h->prof_kind[i]] += 1;
+            flops_by_kind[h->prof_kind[i]] += h->prof_flops[i];
+        }
+    }
     return DSG_OK;
 }
 

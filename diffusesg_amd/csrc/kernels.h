@@ -23,6 +23,7 @@ struct GemmArgs {
     int act = ACT_NONE;
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
+extern int g_gemm_variant;  // dev switch for tools/gemm_bench
 
 // geometry of one Swin block's windows
 struct WinGeom {

@@ -1,0 +1,48 @@
+"""Multi-GPU side of the sampling path: independent samples shard batch-wise, one collective at the end.
+
+Reference: each rank samples its DistributedSampler shard with per-GPU batch `batch_size // world_size`
+(R/runner/sampler/sampler_utils.py:32-36), seeds are offset by rank (R/utils/arg_parser.py:293-294) and the
+results are collected with 13 `all_gather_into_tensor` calls staged through the host
+(R/runner/sampler/sampler_node_adj.py:331-345, R/utils/dist_training.py:170-195).  Here: one process per GPU,
+no data-path collective during sampling, and ONE all-gather (RCCL over xGMI with backend "nccl"; gloo in the
+CPU tests) of a packed per-rank buffer.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def rank_seed(base_seed: int, rank: int) -> int:
+    return int(base_seed) + int(rank)
+
+
+def shard_batch(total_batch: int, world_size: int) -> int:
+    """Per-rank batch, like the reference: batch_size // world_size (remainder samples are not generated)."""
+    if world_size < 1 or total_batch < world_size:
+        raise ValueError("batch smaller than world size")
+    return total_batch // world_size
+
+
+def pack_results(adj: torch.Tensor, node: torch.Tensor) -> torch.Tensor:
+    """[B,C,N,N] + [B,N,Cn] -> one contiguous [B, C*N*N + N*Cn] buffer (the unit of the single all-gather)."""
+    B = adj.shape[0]
+    return torch.cat([adj.reshape(B, -1), node.reshape(B, -1)], dim=1).contiguous()
+
+
+def unpack_results(packed: torch.Tensor, c_adj: int, n: int, c_node: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    B = packed.shape[0]
+    sa = c_adj * n * n
+    return packed[:, :sa].reshape(B, c_adj, n, n), packed[:, sa:].reshape(B, n, c_node)
+
+
+def gather_results(packed: torch.Tensor) -> torch.Tensor:
+    """All ranks get [world*B, D] in rank order.  One collective; identity when not distributed."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return packed
+    world = dist.get_world_size()
+    out = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed)
+    return out

@@ -128,6 +128,13 @@ int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_
 int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t_hat, float *noise_coef,
                        float *h_step);
 
+/* Measurement: runs n_iters eager network forwards on the batch-B workspace (whatever inputs the last call left
+ * there) with HIP events bracketing every kernel launch on `stream`, and accumulates per kernel class
+ * (0 = MFMA GEMM, 1 = window attention, 2 = row kernels (LayerNorm/modulate/heads), 3 = elementwise):
+ * total milliseconds, number of launches, algorithmic FLOPs (2*M*N*K; 4*T*W*C for attention).  Arrays of length 4. */
+int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_kind, int64_t *launches_by_kind,
+                        double *flops_by_kind, void *stream);
+
 /* Debug: copy the named stage's activation (e.g. "down0.block0") of the next dsg_denoise call to
  * `dst` (device, capacity in floats).  Token-major [B, T, C]. */
 int dsg_debug_tap(dsg_handle h, const char *stage, float *dst, int64_t capacity);

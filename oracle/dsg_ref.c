@@ -137,9 +137,13 @@ static inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710
 /* y[M,N] = x[M,K] @ W[N,K]^T + b   (torch.nn.functional.linear; diffusesg.py:14-16 etc.) */
 static void linear(wentry *w, const float *bias, const float *x, float *y, int M, int K, int N) {
     if (!w->tr) {
-        w->tr = (float *)malloc(sizeof(float) * (size_t)K * N);
-        for (int n = 0; n < N; n++)
-            for (int k = 0; k < K; k++) w->tr[(size_t)k * N + n] = w->data[(size_t)n * K + k];
+#pragma omp critical(dsgref_tr)
+        if (!w->tr) { /* samples of a batch may run in parallel: build the transposed copy once */
+            float *t = (float *)malloc(sizeof(float) * (size_t)K * N);
+            for (int n = 0; n < N; n++)
+                for (int k = 0; k < K; k++) t[(size_t)k * N + n] = w->data[(size_t)n * K + k];
+            w->tr = t;
+        }
     }
     const float *wt = w->tr;
 #pragma omp parallel for schedule(static)
@@ -478,8 +482,11 @@ int dsgref_forward(dsgref *h, int B, const float *adj, const float *node, const 
                    const float *sc_adj, const float *sc_node, float *out_adj, float *out_node) {
     const size_t sa = (size_t)h->c_adj * h->N * h->N, sn = (size_t)h->N * h->c_node;
     h->cur_B = B;
+    /* samples are independent: with a batch of >= 4 (and no debug taps) run one sample per thread; the
+     * parallel loops inside the ops then run serially (nested parallelism is off by default) */
+#pragma omp parallel for schedule(dynamic, 1) if (B >= 4 && h->ntaps == 0)
     for (int b = 0; b < B; b++) {
-        h->cur_sample = b;
+        if (h->ntaps) h->cur_sample = b;
         forward_one(h, adj + b * sa, node + b * sn, flags + (size_t)b * h->N, c_noise[b],
                     sc_adj ? sc_adj + b * sa : NULL, sc_node ? sc_node + b * sn : NULL,
                     out_adj + b * sa, out_node + b * sn);
