@@ -1,0 +1,94 @@
+"""CPU: host-side logic -- YAML schema, batch sharding, the packed gather over world-size-2 gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from diffusesg_amd import config as dcfg
+from diffusesg_amd import dist as ddist
+from diffusesg_amd import spec
+
+VG_YAML = """
+seed: 1234
+dataset: {name: visual_genome, max_node_num: 64, subset: null}
+mcmc:
+  name: edm
+  precond: edm
+  sigma_dist: edm
+  num_steps: 256
+  sample_clip: {min: -1.0, max: 1.0, scope: x_0}
+model: {name: diffuse_sg, feature_dims: [96], depths: [1, 1, 3, 1], window_size: 8, patch_size: 1}
+test: {batch_size: 0, eval_size: 0}
+train: {batch_size: 1000, node_encoding: ddpm, edge_encoding: ddpm, self_cond: true, node_only: false, binary_edge: false}
+"""
+
+
+def test_yaml_schema_to_model_config():
+    y = dcfg.load_yaml(VG_YAML)
+    c = dcfg.model_config_from_yaml(y, node_encoding="bits", edge_encoding="bits")   # README: --node_encoding bits
+    assert c == spec.vg_config()
+    d = dcfg.model_config_from_yaml(y)            # yaml default 'ddpm'
+    assert (d.c_adj, d.c_node, d.in_chans) == (1, 5, 22)
+    y["model"]["name"] = "something_else"
+    with pytest.raises(ValueError):
+        dcfg.model_config_from_yaml(y)
+
+
+def test_sampler_from_yaml_host_only():
+    y = dcfg.load_yaml(VG_YAML)
+    s = dcfg.sampler_from_yaml(y, device="cpu", num_steps=100)
+    assert s.num_steps == 100 and s.solver == "heun" and s.clip_samples
+    assert abs(float(s.sigma_steps[0]) - 80.0) < 1e-12 and abs(float(s.sigma_steps[-1]) - 0.002) < 1e-12
+
+
+def test_shard_and_seed():
+    assert ddist.shard_batch(2048, 8) == 256 and ddist.shard_batch(67, 8) == 8
+    assert ddist.rank_seed(1234, 3) == 1237
+    with pytest.raises(ValueError):
+        ddist.shard_batch(4, 8)
+
+
+def test_pack_roundtrip():
+    a, n = torch.randn(5, 6, 8, 8), torch.randn(5, 8, 12)
+    p = ddist.pack_results(a, n)
+    assert p.shape == (5, 6 * 64 + 96) and p.is_contiguous()
+    a2, n2 = ddist.unpack_results(p, 6, 8, 12)
+    assert torch.equal(a, a2) and torch.equal(n, n2)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B = ddist.shard_batch(6, world)
+        g = torch.Generator().manual_seed(ddist.rank_seed(1234, rank))
+        adj, node = torch.randn(B, 3, 4, 4, generator=g), torch.randn(B, 4, 5, generator=g)
+        out = ddist.gather_results(ddist.pack_results(adj, node))
+        q.put((rank, out.numpy(), adj.numpy(), node.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_world2_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    full0, full1 = res[0][1], res[1][1]
+    assert np.array_equal(full0, full1) and full0.shape == (6, 3 * 16 + 20)       # every rank holds all graphs
+    for r in range(2):                                                           # rank order, contents intact
+        a, n = ddist.unpack_results(torch.from_numpy(full0[3 * r:3 * r + 3]), 3, 4, 5)
+        assert np.array_equal(a.numpy(), res[r][2]) and np.array_equal(n.numpy(), res[r][3])
+    assert not np.array_equal(res[0][2], res[1][2])                              # seeds differ by rank
