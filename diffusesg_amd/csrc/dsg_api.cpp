@@ -46,6 +46,8 @@ struct BlockPlan {
     int lvl, C, res, ws, shift, heads;
     int aff_off;        // offset of this block's (scale,shift) in the concatenated affine output
     float *biasT = nullptr;  // [nWt][heads][Wp][Wp]
+    float *w1p = nullptr, *w2p = nullptr;  // fragment-major packed MLP weights (fused_mlp_kernel), narrow levels only
+    float *wqp = nullptr, *wpp = nullptr;  // fragment-major packed qkv / proj weights (fused_attn96_kernel), C == 96 only
 };
 
 struct Workspace {
@@ -289,6 +291,75 @@ int build_bias_table(dsg_handle h, BlockPlan &bp) {
     return 0;
 }
 
+// Fragment-major packing for fused_mlp_kernel: every MFMA operand fetch becomes one coalesced 1-KiB wave load.
+//   W1p[nt][s][lane][t]    = fc1.weight[32nt + (lane&31)][8s + 4(lane>>5) + t]
+//   W2p[nt][ct][g][lane][t] = fc2.weight[32ct + (lane&31)][32nt + 8g + 4(lane>>5) + t]
+int pack_mlp_weights(dsg_handle h, BlockPlan &bp) {
+    const int C = bp.C, Hd = h->cfg.mlp_ratio * C;
+    if (!(C == 96 || C == 192) || h->cfg.mlp_ratio != 4) return 0;
+    const int S = C / 8, CT = C / 32, NT = Hd / 32;
+    std::vector<float> w1((size_t)Hd * C), w2((size_t)C * Hd), p1((size_t)Hd * C), p2((size_t)C * Hd);
+    HIP_TRY(h, hipMemcpy(w1.data(), WT(h, bp.prefix + ".mlp.fc1.weight"), sizeof(float) * w1.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(w2.data(), WT(h, bp.prefix + ".mlp.fc2.weight"), sizeof(float) * w2.size(), hipMemcpyDeviceToHost));
+    for (int nt = 0; nt < NT; nt++)
+        for (int s = 0; s < S; s++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int t = 0; t < 4; t++)
+                    p1[(((size_t)nt * S + s) * 64 + lane) * 4 + t] = w1[(size_t)(32 * nt + (lane & 31)) * C + 8 * s + 4 * (lane >> 5) + t];
+    for (int nt = 0; nt < NT; nt++)
+        for (int ct = 0; ct < CT; ct++)
+            for (int g = 0; g < 4; g++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int t = 0; t < 4; t++)
+                        p2[((((size_t)nt * CT + ct) * 4 + g) * 64 + lane) * 4 + t] =
+                            w2[(size_t)(32 * ct + (lane & 31)) * Hd + 32 * nt + 8 * g + 4 * (lane >> 5) + t];
+    void *p;
+    if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * p1.size())) return rc;
+    bp.w1p = (float *)p;
+    HIP_TRY(h, hipMemcpy(bp.w1p, p1.data(), sizeof(float) * p1.size(), hipMemcpyHostToDevice));
+    if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * p2.size())) return rc;
+    bp.w2p = (float *)p;
+    HIP_TRY(h, hipMemcpy(bp.w2p, p2.data(), sizeof(float) * p2.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// Fragment-major packing for fused_attn96_kernel (same two patterns as the MLP):
+//   Wqp[nt][s][lane][t]     = qkv.weight[32nt + (lane&31)][8s + 4(lane>>5) + t]      nt = {q,k,v} x head
+//   Wpp[hd][ct][g][lane][t] = proj.weight[32ct + (lane&31)][32hd + 8g + 4(lane>>5) + t]
+int pack_attn_weights(dsg_handle h, BlockPlan &bp) {
+    const int C = bp.C;
+    if (C != 96 || bp.ws * bp.ws > 64) return 0;
+    const int S = C / 8, CT = C / 32, NT = 3 * C / 32, HD = C / 32;
+    std::vector<float> wq((size_t)3 * C * C), wp((size_t)C * C), p1(wq.size()), p2(wp.size());
+    HIP_TRY(h, hipMemcpy(wq.data(), WT(h, bp.prefix + ".attn.qkv.weight"), sizeof(float) * wq.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(wp.data(), WT(h, bp.prefix + ".attn.proj.weight"), sizeof(float) * wp.size(), hipMemcpyDeviceToHost));
+    for (int nt = 0; nt < NT; nt++)
+        for (int s = 0; s < S; s++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int t = 0; t < 4; t++)
+                    p1[(((size_t)nt * S + s) * 64 + lane) * 4 + t] = wq[(size_t)(32 * nt + (lane & 31)) * C + 8 * s + 4 * (lane >> 5) + t];
+    for (int hd = 0; hd < HD; hd++)
+        for (int ct = 0; ct < CT; ct++)
+            for (int g = 0; g < 4; g++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int t = 0; t < 4; t++)
+                        p2[((((size_t)hd * CT + ct) * 4 + g) * 64 + lane) * 4 + t] =
+                            wp[(size_t)(32 * ct + (lane & 31)) * C + 32 * hd + 8 * g + 4 * (lane >> 5) + t];
+    void *p;
+    if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * p1.size())) return rc;
+    bp.wqp = (float *)p;
+    HIP_TRY(h, hipMemcpy(bp.wqp, p1.data(), sizeof(float) * p1.size(), hipMemcpyHostToDevice));
+    if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * p2.size())) return rc;
+    bp.wpp = (float *)p;
+    HIP_TRY(h, hipMemcpy(bp.wpp, p2.data(), sizeof(float) * p2.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+bool env_on(const char *name, bool dflt) {
+    const char *v = getenv(name);
+    return v ? (v[0] != '0') : dflt;
+}
+
 }  // namespace
 
 extern "C" {
@@ -410,8 +481,12 @@ int dsg_finalize_weights(dsg_handle h) {
         }
     }
     for (int l = 0; l < L; l++) {
-        for (auto &b : h->down[l]) if (int rc = build_bias_table(h, b)) return rc;
-        for (auto &b : h->up[l]) if (int rc = build_bias_table(h, b)) return rc;
+        for (auto *vec : {&h->down[l], &h->up[l]})
+            for (auto &b : *vec) {
+                if (int rc = build_bias_table(h, b)) return rc;
+                if (int rc = pack_mlp_weights(h, b)) return rc;
+                if (int rc = pack_attn_weights(h, b)) return rc;
+            }
     }
     // patch_embed.proj [E,Cin,1,1] -> [E,Kp] zero padded
     {
@@ -517,21 +592,39 @@ void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStre
 void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
     const int B = w->B, T = b.res * b.res, C = b.C, M = B * T, Hd = h->cfg.mlp_ratio * C;
     const std::string &p = b.prefix;
-    // x <- silu(shift + x*(1+scale)) (also the shortcut), LayerNorm-1 statistics
-    P_KERN(PK_ROW, 0.0, launch_mod_stats(w->x, w->aff, h->aff_n, b.aff_off, w->stats, B, T, C, s));
+    static const bool fused_attn = env_on("DSG_FUSED_ATTN", true);
     GemmArgs g;
-    g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M;
-    g.ln_stats = w->stats; g.ln_g = WT(h, p + ".norm1.weight"); g.ln_b = WT(h, p + ".norm1.bias");
-    g.W = WT(h, p + ".attn.qkv.weight"); g.bias = WT(h, p + ".attn.qkv.bias"); g.N = 3 * C;
-    g.C = w->qkv; g.ldc = 3 * C;
-    P_GEMM(g);
-    WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
-    P_KERN(PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s));
-    g = GemmArgs();
-    g.A = w->att; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = C;
-    g.W = WT(h, p + ".attn.proj.weight"); g.bias = WT(h, p + ".attn.proj.bias");
-    g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
-    P_GEMM(g);
+    if (fused_attn && b.wqp) {
+        // modulate+SiLU, LN1, QKV, window attention, proj and the residual in one register-resident kernel
+        WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
+        P_KERN(PK_ATTN, 2.0 * (double)M * C * 4.0 * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C,
+               launch_fused_attn96(w->x, w->aff, h->aff_n, b.aff_off, WT(h, p + ".norm1.weight"), WT(h, p + ".norm1.bias"), b.wqp,
+                                   WT(h, p + ".attn.qkv.bias"), b.biasT, b.wpp, WT(h, p + ".attn.proj.bias"), B, wg, s));
+    } else {
+        // x <- silu(shift + x*(1+scale)) (also the shortcut), LayerNorm-1 statistics
+        P_KERN(PK_ROW, 0.0, launch_mod_stats(w->x, w->aff, h->aff_n, b.aff_off, w->stats, B, T, C, s));
+        g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M;
+        g.ln_stats = w->stats; g.ln_g = WT(h, p + ".norm1.weight"); g.ln_b = WT(h, p + ".norm1.bias");
+        g.W = WT(h, p + ".attn.qkv.weight"); g.bias = WT(h, p + ".attn.qkv.bias"); g.N = 3 * C;
+        g.C = w->qkv; g.ldc = 3 * C;
+        P_GEMM(g);
+        WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
+        P_KERN(PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s));
+        g = GemmArgs();
+        g.A = w->att; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = C;
+        g.W = WT(h, p + ".attn.proj.weight"); g.bias = WT(h, p + ".attn.proj.bias");
+        g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
+        P_GEMM(g);
+    }
+    static const bool fused_mlp = env_on("DSG_FUSED_MLP", true);
+    static const int fused_mlp_maxc = getenv("DSG_FUSED_MLP_MAXC") ? atoi(getenv("DSG_FUSED_MLP_MAXC")) : 192;
+    if (fused_mlp && b.w1p && C <= fused_mlp_maxc) {
+        // LN2 + fc1 + GELU + fc2 + residual in one kernel, hidden activations never leave the register file
+        P_KERN(PK_GEMM, 4.0 * (double)M * (double)C * (double)Hd,
+               launch_fused_mlp(w->x, WT(h, p + ".norm2.weight"), WT(h, p + ".norm2.bias"), b.w1p, WT(h, p + ".mlp.fc1.bias"), b.w2p,
+                                WT(h, p + ".mlp.fc2.bias"), M, C, s));
+        return;
+    }
     P_KERN(PK_ROW, 0.0, launch_ln_stats(w->x, w->stats, M, C, s));
     g = GemmArgs();
     g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = Hd;

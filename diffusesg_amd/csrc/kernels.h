@@ -25,6 +25,10 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs &g, hipStream_t s);
 extern int g_gemm_variant;  // dev switch for tools/gemm_bench
 
+// x <- x + fc2(GELU(fc1(LN(x)))) with fragment-major packed weights (pack_mlp_weights in dsg_api.cpp); C in {96,192}
+void launch_fused_mlp(float *x, const float *gam, const float *bet, const float *W1p, const float *b1, const float *W2p,
+                      const float *b2, int M, int C, hipStream_t s);
+
 // geometry of one Swin block's windows
 struct WinGeom {
     int res;      // tokens per side
@@ -33,6 +37,11 @@ struct WinGeom {
     int heads;
     int C;
 };
+// whole attention half of a C=96 Swin block in one kernel (modulate+SiLU, LN1, QKV, window attention, proj, residual);
+// windows of at most 64 tokens; packed weights from pack_attn_weights in dsg_api.cpp
+void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, const float *gam, const float *bet, const float *Wqp,
+                         const float *bqkv, const float *biasT, const float *Wpp, const float *bproj, int B, const WinGeom &g,
+                         hipStream_t s);
 // qkv [B*T, 3C] token order -> out [B*T, C] token order; biasT [nWt][heads][Wp][Wp] (key-major)
 void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s);
 

@@ -17,7 +17,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|eps| <= 1.5e-7), evaluated so that the
+// negative tail has no cancellation: 1+erf(z) = poly*exp(-z^2) for z<0, 2 - poly*exp(-z^2) otherwise.  Measured max
+// abs error vs an fp64 GELU over [-12,12]: 4.2e-7 -- the same as the fp32 erff formula (4.5e-7); ~3x fewer VALU ops.
+__device__ __forceinline__ float gelu_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float pe = p * t * __expf(-z * z);
+    return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -600,6 +612,338 @@ void launch_gemm(const GemmArgs &g, hipStream_t s) {
     else if (!ln && g.act == ACT_GELU && res) GEMM_CASE(false, ACT_GELU, true);
     else GEMM_CASE(false, ACT_SILU, true);
 #undef GEMM_CASE
+}
+
+// =================================================================================================
+// Fused MLP half of a Swin block (diffusesg.py:275, :19-25):  x <- x + fc2(GELU(fc1(LayerNorm2(x))))
+// for the narrow levels (C = 96, 192), where the unfused version is bound by the 4C-wide hidden tensor's
+// round trip through HBM.  Everything stays in registers, there is no LDS and no barrier:
+//   * one wave owns 32 tokens.  Products are formed TRANSPOSED, H^T = W1 . Xn^T, so a lane (m, half) always owns
+//     token m: the fc1 accumulator (lane = token, register r = hidden unit (r&3)+8(r>>2)+4*half) is, register by
+//     register, exactly the B operand of k-step r of the second product O^T = W2 . H^T -- the hidden activations
+//     never leave the accumulator file (the f32 MFMA takes one VGPR per operand, so no repacking is needed);
+//   * LayerNorm statistics come from the same fragments (a row is split over the two half-waves);
+//   * weights are pre-packed fragment-major at load time ([tile][k-step][lane][4]) so every operand fetch is one
+//     fully coalesced 1-KiB wave load served by L2; the next tile's fragments are in flight during the current MFMAs.
+// =================================================================================================
+template <int C>
+__global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float *__restrict__ x, const float *__restrict__ gam,
+                                                           const float *__restrict__ bet, const float *__restrict__ W1p,
+                                                           const float *__restrict__ b1, const float *__restrict__ W2p,
+                                                           const float *__restrict__ b2, int M) {
+    constexpr int S = C / 8, CT = C / 32, NT = 4 * C / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int m = (blockIdx.x * 4 + wave) * 32 + lrow;
+    const bool ok = m < M;
+    float *xr = x + (size_t)(ok ? m : M - 1) * C + 4 * lhalf;
+
+    f32x4 xn[S];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        xn[s] = *reinterpret_cast<const f32x4 *>(xr + 8 * s);
+        sum += (xn[s][0] + xn[s][1]) + (xn[s][2] + xn[s][3]);
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / C);
+    float var = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; s++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) { const float d = xn[s][t] - mean; var = fmaf(d, d, var); }
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / C) + LN_EPS);
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        const f32x4 gg = *reinterpret_cast<const f32x4 *>(gam + 8 * s + 4 * lhalf);
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(bet + 8 * s + 4 * lhalf);
+        xn[s] = (xn[s] - mean) * rstd * gg + bb;
+    }
+
+    f32x16 oacc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
+
+    const f32x4 *w1 = reinterpret_cast<const f32x4 *>(W1p) + lane;  // [NT][S][64] float4
+    const f32x4 *w2 = reinterpret_cast<const f32x4 *>(W2p) + lane;  // [NT][CT][4][64] float4
+    f32x4 w1f[S], w2f[CT * 4];
+#pragma unroll
+    for (int s = 0; s < S; s++) w1f[s] = w1[(size_t)s * 64];
+    for (int nt = 0; nt < NT; nt++) {
+        f32x16 hacc;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(b1 + 32 * nt + 8 * g + 4 * lhalf);
+#pragma unroll
+            for (int t = 0; t < 4; t++) hacc[4 * g + t] = bv[t];
+        }
+#pragma unroll
+        for (int q = 0; q < CT * 4; q++) w2f[q] = w2[((size_t)nt * CT * 4 + q) * 64];
+#pragma unroll
+        for (int s = 0; s < S; s++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1f[s][t], xn[s][t], hacc, 0, 0, 0);
+        if (nt + 1 < NT) {
+#pragma unroll
+            for (int s = 0; s < S; s++) w1f[s] = w1[((size_t)(nt + 1) * S + s) * 64];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) hacc[r] = gelu_f(hacc[r]);
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[ct * 4 + g][t], hacc[4 * g + t], oacc[ct], 0, 0, 0);
+    }
+    // epilogue: channel of oacc[ct][4g+t] is 32ct + 8g + 4*half + t -- the same pattern as the input fragments
+    if (ok) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int c = 32 * ct + 8 * g;
+                const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + c);
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(b2 + c + 4 * lhalf);
+                f32x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; t++) o[t] = oacc[ct][4 * g + t] + bv[t] + xv[t];
+                *reinterpret_cast<f32x4 *>(xr + c) = o;
+            }
+    }
+}
+
+void launch_fused_mlp(float *x, const float *gam, const float *bet, const float *W1p, const float *b1, const float *W2p,
+                      const float *b2, int M, int C, hipStream_t s) {
+    const dim3 grid((M + 127) / 128), block(256);
+    if (C == 96) hipLaunchKernelGGL(fused_mlp_kernel<96>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, M);
+    else if (C == 192) hipLaunchKernelGGL(fused_mlp_kernel<192>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, M);
+}
+
+// =================================================================================================
+// Fused attention half of a Swin block for C = 96 (3 heads of 32), diffusesg.py:238-272:
+//   x <- silu(shift + x*(1+scale));  x <- x + proj(window_attention(LayerNorm1(x)))
+// One wave owns one window (MB blocks of 32 tokens) and chains every product through the accumulator file:
+//   Q^T, K^T = W . Xn^T      (lane = token, register = head dim d)        -- "swapped" products
+//   V        = Xn . Wv^T     (lane = head dim d, register = key)           -- unswapped product, same Xn fragments
+//   S^T     += K^T[r] x Q^T[r]   over the 16 registers r (both operands already have lane = key / query, slot = d)
+//   softmax over keys: lane-local over registers + one half-wave exchange
+//   O^T      = V[r] x P[r]   (lane = query, register = d)  ->  Y^T += Wproj[:, head] x O^T[r]
+// No LDS, no barrier, no intermediate tensor in HBM; weights are read as pre-packed fragment-major 1-KiB wave loads.
+// =================================================================================================
+template <int MB>
+__global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict__ x, const float *__restrict__ aff, int aff_ld,
+                                                             int aff_off, const float *__restrict__ gam,
+                                                             const float *__restrict__ bet, const float *__restrict__ Wqp,
+                                                             const float *__restrict__ bqkv, const float *__restrict__ biasT,
+                                                             const float *__restrict__ Wpp, const float *__restrict__ bproj,
+                                                             WinGeom g, int n_windows) {
+    constexpr int C = 96, S = 12, CT = 3, HEADS = 3, Wp = 32 * MB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int win = blockIdx.x * 4 + wave;
+    if (win >= n_windows) return;  // no block-level synchronisation below
+    const int res = g.res, ws = g.ws, nwr = res / ws, nW = nwr * nwr, Wt = ws * ws, T = res * res;
+    const int w = win % nW, b = win / nW;
+    const int wi = w / nwr, wj = w % nwr;
+    const float *bias_w = biasT + (size_t)(g.shift > 0 ? w : 0) * HEADS * Wp * Wp;
+    const float *scale = aff + (size_t)b * aff_ld + aff_off + 4 * lhalf, *shift = scale + C;
+
+    // this lane's token in each 32-token block of the window (cyclic shift folded in)
+    float *xrow[MB];
+    bool valid[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+        const int p = 32 * mb + lrow;
+        valid[mb] = p < Wt;
+        int t = 0;
+        if (valid[mb]) {
+            const int si = wi * ws + p / ws, sj = wj * ws + p % ws;
+            t = ((si + g.shift) % res) * res + ((sj + g.shift) % res);
+        }
+        xrow[mb] = x + ((size_t)b * T + t) * C + 4 * lhalf;
+    }
+
+    // modulate + SiLU, LayerNorm-1 (statistics of the modulated row; a row is split over the two half-waves)
+    f32x4 xn[MB][S];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+        float sum = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow[mb] + 8 * s);
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + 8 * s);
+            const f32x4 sh = *reinterpret_cast<const f32x4 *>(shift + 8 * s);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                xn[mb][s][t] = silu_exact(sh[t] + v[t] * (sc[t] + 1.0f));
+                sum += xn[mb][s][t];
+            }
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / C);
+        float var = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; s++)
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const float d = xn[mb][s][t] - mean; var = fmaf(d, d, var); }
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = 1.0f / sqrtf(var * (1.0f / C) + LN_EPS);
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const f32x4 gg = *reinterpret_cast<const f32x4 *>(gam + 8 * s + 4 * lhalf);
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(bet + 8 * s + 4 * lhalf);
+            xn[mb][s] = (xn[mb][s] - mean) * rstd * gg + bb;
+        }
+    }
+
+    f32x16 yacc[MB][CT];
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++)
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) yacc[mb][ct][r] = 0.f;
+
+    const f32x4 *wq = reinterpret_cast<const f32x4 *>(Wqp) + lane;  // [9 tiles][S][64] float4
+    const f32x4 *wp = reinterpret_cast<const f32x4 *>(Wpp) + lane;  // [3 heads][CT][4][64] float4
+    const float qscale = 0.17677669529663687f;                      // 32^-0.5
+
+    for (int hd = 0; hd < HEADS; hd++) {
+        f32x16 qa[MB], ka[MB], va[MB];
+        // Q^T and K^T tiles: bias per register (= per head dim)
+#pragma unroll
+        for (int which = 0; which < 2; which++) {
+            const int nt = which * 3 + hd;
+            f32x4 wf[S];
+#pragma unroll
+            for (int s = 0; s < S; s++) wf[s] = wq[((size_t)nt * S + s) * 64];
+            f32x16 init;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(bqkv + 32 * nt + 8 * gq + 4 * lhalf);
+#pragma unroll
+                for (int t = 0; t < 4; t++) init[4 * gq + t] = bv[t];
+            }
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++) {
+                f32x16 a = init;
+#pragma unroll
+                for (int s = 0; s < S; s++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) a = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s][t], xn[mb][s][t], a, 0, 0, 0);
+                if (which == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) a[r] *= qscale;
+                    qa[mb] = a;
+                } else ka[mb] = a;
+            }
+        }
+        // V tile, unswapped: lane = head dim, register = key; bias per lane
+        {
+            const int nt = 6 + hd;
+            f32x4 wf[S];
+#pragma unroll
+            for (int s = 0; s < S; s++) wf[s] = wq[((size_t)nt * S + s) * 64];
+            const float bv = bqkv[32 * nt + lrow];
+#pragma unroll
+            for (int mb = 0; mb < MB; mb++) {
+                f32x16 a;
+#pragma unroll
+                for (int r = 0; r < 16; r++) a[r] = bv;
+#pragma unroll
+                for (int s = 0; s < S; s++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) a = __builtin_amdgcn_mfma_f32_32x32x2f32(xn[mb][s][t], wf[s][t], a, 0, 0, 0);
+                va[mb] = a;
+            }
+        }
+        f32x4 pf[CT * 4];
+#pragma unroll
+        for (int q = 0; q < CT * 4; q++) pf[q] = wp[((size_t)hd * CT * 4 + q) * 64];
+        const float *bias_h = bias_w + (size_t)hd * Wp * Wp;
+#pragma unroll
+        for (int qb = 0; qb < MB; qb++) {
+            if (32 * qb >= Wt) break;
+            f32x16 sa[MB];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int kb = 0; kb < MB; kb++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                    sa[kb][r] = bias_h[(size_t)key * Wp + 32 * qb + lrow];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) sa[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kb][r], qa[qb][r], sa[kb], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; r++) mx = fmaxf(mx, sa[kb][r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < MB; kb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float e = __expf(sa[kb][r] - mx);
+                    sa[kb][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = 1.0f / sum;
+            f32x16 ot;
+#pragma unroll
+            for (int r = 0; r < 16; r++) ot[r] = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < MB; kb++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) ot = __builtin_amdgcn_mfma_f32_32x32x2f32(va[kb][r], sa[kb][r] * inv, ot, 0, 0, 0);
+            // proj partial of this head: Y^T[c][m] += Wp[c][32hd + d] * O[m][d]
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+                        yacc[qb][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(pf[ct * 4 + gq][t], ot[4 * gq + t], yacc[qb][ct], 0, 0, 0);
+        }
+    }
+
+    // epilogue: x_new = silu(shift + x*(1+scale)) (recomputed: the shortcut) + Y + proj bias
+#pragma unroll
+    for (int mb = 0; mb < MB; mb++) {
+        if (!valid[mb]) continue;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                const int c = 32 * ct + 8 * gq;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(xrow[mb] + c);
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + c);
+                const f32x4 sh = *reinterpret_cast<const f32x4 *>(shift + c);
+                const f32x4 bp = *reinterpret_cast<const f32x4 *>(bproj + c + 4 * lhalf);
+                f32x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; t++) o[t] = silu_exact(sh[t] + v[t] * (sc[t] + 1.0f)) + yacc[mb][ct][4 * gq + t] + bp[t];
+                *reinterpret_cast<f32x4 *>(xrow[mb] + c) = o;
+            }
+    }
+}
+
+void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, const float *gam, const float *bet, const float *Wqp,
+                         const float *bqkv, const float *biasT, const float *Wpp, const float *bproj, int B, const WinGeom &g,
+                         hipStream_t s) {
+    const int nW = (g.res / g.ws) * (g.res / g.ws), n_windows = B * nW;
+    const int MB = (g.ws * g.ws + 31) / 32;
+    const dim3 grid((n_windows + 3) / 4), block(256);
+    if (MB == 1)
+        hipLaunchKernelGGL(fused_attn96_kernel<1>, grid, block, 0, s, x, aff, aff_ld, aff_off, gam, bet, Wqp, bqkv, biasT, Wpp, bproj, g, n_windows);
+    else
+        hipLaunchKernelGGL(fused_attn96_kernel<2>, grid, block, 0, s, x, aff, aff_ld, aff_off, gam, bet, Wqp, bqkv, biasT, Wpp, bproj, g, n_windows);
 }
 
 // =================================================================================================
