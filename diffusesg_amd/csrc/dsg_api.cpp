@@ -58,12 +58,16 @@ struct Workspace {
     float *in_adj, *in_node, *sc_adj, *sc_node, *c_noise, *f_adj, *f_node;
     uint8_t *flags;
     int *has_sc;
-    float *pe, *emb0, *emb, *aff, *tok_in, *x, *y, *qkv, *att, *hid, *stats, *pool, *hn;
+    float *pe, *emb0, *emb, *aff, *tok_in, *x, *y, *qkv, *att, *hid, *stats, *pool, *hn, *pool_ext;
     float *skips[DSG_MAX_LAYERS];
     // sampler state
     float *x_adj, *x_node, *xh_adj, *xh_node, *sig;
     float *d_adj[3], *d_node[3];
-    hipGraphExec_t graph = nullptr;
+    // batch-uniform noise level (the sampler): every sample shares one (scale,shift) row, taken from a table that
+    // dsg_sample computes once for all steps; aff_ld == 0 broadcasts row 0 of `aff`
+    bool uniform = false;
+    int aff_ld = 0;
+    hipGraphExec_t graph = nullptr, graph_uniform = nullptr;
     hipStream_t cap_stream = nullptr;
 };
 
@@ -83,9 +87,15 @@ struct dsg_handle_s {
     float *aff_w = nullptr, *aff_b = nullptr;  // concatenated affine linears [aff_n, 512]
     int aff_n = 0, pe_aff_off = 0;
     float *pe_w = nullptr;      // patch_embed.proj padded to [E, Kp]
+    float *pe_wp = nullptr;     // the same, fragment-major packed [E/32][Kp/8][64][4] (fused_patch_embed96_kernel)
     float *ro0_w = nullptr;     // read_out.0 transposed to [out,in]
+    // folded read-out (E = 96): Fa = F1.W2.W1.W0^T packed fragment-major, fa; F2 padded+packed; node: Gext [E,128]
+    float *ro_fap = nullptr, *ro_fa = nullptr, *ro_f2p = nullptr, *ro_gext = nullptr;
     std::vector<void *> derived_allocs;
     std::map<int, std::unique_ptr<Workspace>> ws;
+    // per-step (scale,shift) table of the sampler (batch-uniform sigma): [cap][aff_n] and its staging buffers
+    int tab_cap = 0;
+    float *tab_sig = nullptr, *tab_cn = nullptr, *tab_pe = nullptr, *tab_e0 = nullptr, *tab_e1 = nullptr, *tab_aff = nullptr;
     std::vector<Tap> taps;
     dsg_sample_stats last_stats{};
     // per-kernel-class timing (dsg_profile_forward): HIP events bracketing every launch on the launch stream
@@ -398,8 +408,10 @@ void dsg_destroy(dsg_handle h) {
     for (auto &kv : h->w) (void)hipFree(kv.second.p);
     for (void *p : h->derived_allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    for (float *q : {h->tab_sig, h->tab_cn, h->tab_pe, h->tab_e0, h->tab_e1, h->tab_aff}) if (q) (void)hipFree(q);
     for (auto &kv : h->ws) {
         if (kv.second->graph) (void)hipGraphExecDestroy(kv.second->graph);
+        if (kv.second->graph_uniform) (void)hipGraphExecDestroy(kv.second->graph_uniform);
         if (kv.second->cap_stream) (void)hipStreamDestroy(kv.second->cap_stream);
         for (void *p : kv.second->allocs) (void)hipFree(p);
     }
@@ -497,6 +509,19 @@ int dsg_finalize_weights(dsg_handle h) {
         if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * dst.size())) return rc;
         h->pe_w = (float *)p;
         HIP_TRY(h, hipMemcpy(h->pe_w, dst.data(), sizeof(float) * dst.size(), hipMemcpyHostToDevice));
+        h->pe_wp = nullptr;
+        if (E == 96 && h->Kp <= 64) {
+            const int S = h->Kp / 8;
+            std::vector<float> pk(dst.size());
+            for (int nt = 0; nt < E / 32; nt++)
+                for (int sx = 0; sx < S; sx++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int t = 0; t < 4; t++)
+                            pk[(((size_t)nt * S + sx) * 64 + lane) * 4 + t] = dst[(size_t)(32 * nt + (lane & 31)) * h->Kp + 8 * sx + 4 * (lane >> 5) + t];
+            if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * pk.size())) return rc;
+            h->pe_wp = (float *)p;
+            HIP_TRY(h, hipMemcpy(h->pe_wp, pk.data(), sizeof(float) * pk.size(), hipMemcpyHostToDevice));
+        }
     }
     // read_out.0 is a ConvTranspose2d: weight [in,out,1,1] (diffusesg.py:706) -> [out,in]
     {
@@ -508,9 +533,66 @@ int dsg_finalize_weights(dsg_handle h) {
         h->ro0_w = (float *)p;
         HIP_TRY(h, hipMemcpy(h->ro0_w, dst.data(), sizeof(float) * dst.size(), hipMemcpyHostToDevice));
     }
+    // Folded read-out (E = 96, C_adj <= 32): final-LN output -> read_out.0/1/2 -> readout_adj_mlp.fc1 is affine up to the
+    // GELU, and the node head's pooled shared_rep is an affine image of the pooled LN output.  Fold in double precision.
+    h->ro_fap = h->ro_fa = h->ro_f2p = h->ro_gext = nullptr;
+    if (E == 96 && h->Ca <= 32) {
+        auto dl = [&](const char *k, size_t n) { std::vector<float> v(n); (void)hipMemcpy(v.data(), WT(h, k), sizeof(float) * n, hipMemcpyDeviceToHost); return v; };
+        const std::vector<float> r0 = dl("read_out.0.weight", (size_t)E * E), r1 = dl("read_out.1.weight", (size_t)E * E),
+                                 r2 = dl("read_out.2.weight", (size_t)E * E), b0 = dl("read_out.0.bias", E), b1 = dl("read_out.1.bias", E),
+                                 b2 = dl("read_out.2.bias", E), F1 = dl("readout_adj_mlp.fc1.weight", (size_t)E * E),
+                                 f1 = dl("readout_adj_mlp.fc1.bias", E), F2 = dl("readout_adj_mlp.fc2.weight", (size_t)h->Ca * E),
+                                 G1 = dl("readout_node_mlp.fc1.weight", (size_t)E * E);
+        typedef std::vector<double> dv;
+        auto matmul = [&](const dv &X, const dv &Y) { dv Z((size_t)E * E, 0.0); for (int i = 0; i < E; i++) for (int k = 0; k < E; k++) { const double a = X[(size_t)i * E + k]; for (int j = 0; j < E; j++) Z[(size_t)i * E + j] += a * Y[(size_t)k * E + j]; } return Z; };
+        auto matvec = [&](const dv &X, const dv &v) { dv z(E, 0.0); for (int i = 0; i < E; i++) for (int k = 0; k < E; k++) z[i] += X[(size_t)i * E + k] * v[k]; return z; };
+        dv W0t((size_t)E * E), W1(r1.begin(), r1.end()), W2(r2.begin(), r2.end()), dF1(F1.begin(), F1.end()), dG1(G1.begin(), G1.end());
+        for (int i = 0; i < E; i++) for (int o = 0; o < E; o++) W0t[(size_t)o * E + i] = r0[(size_t)i * E + o];  // ConvTranspose2d [in,out]
+        const dv A = matmul(W2, matmul(W1, W0t));
+        dv t1 = matvec(W1, dv(b0.begin(), b0.end()));
+        for (int i = 0; i < E; i++) t1[i] += b1[i];
+        dv a = matvec(W2, t1);
+        for (int i = 0; i < E; i++) a[i] += b2[i];
+        const dv Fa = matmul(dF1, A);
+        dv fa = matvec(dF1, a);
+        for (int i = 0; i < E; i++) fa[i] += f1[i];
+        const dv Gn = matmul(dG1, A), ga = matvec(dG1, a);
+        const int S = E / 8;
+        std::vector<float> fap((size_t)E * E), f2p((size_t)3 * 4 * 64 * 4, 0.f), gext((size_t)E * 128, 0.f), faf(E);
+        for (int nt = 0; nt < 3; nt++)
+            for (int sx = 0; sx < S; sx++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int t = 0; t < 4; t++)
+                        fap[(((size_t)nt * S + sx) * 64 + lane) * 4 + t] = (float)Fa[(size_t)(32 * nt + (lane & 31)) * E + 8 * sx + 4 * (lane >> 5) + t];
+        for (int nt = 0; nt < 3; nt++)
+            for (int g = 0; g < 4; g++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int t = 0; t < 4; t++) {
+                        const int c = lane & 31;
+                        f2p[(((size_t)nt * 4 + g) * 64 + lane) * 4 + t] = c < h->Ca ? F2[(size_t)c * E + 32 * nt + 8 * g + 4 * (lane >> 5) + t] : 0.f;
+                    }
+        for (int i = 0; i < E; i++) {
+            faf[i] = (float)fa[i];
+            for (int k = 0; k < E; k++) gext[(size_t)i * 128 + k] = (float)Gn[(size_t)i * E + k];
+            gext[(size_t)i * 128 + 96] = (float)ga[i];
+        }
+        auto up = [&](const std::vector<float> &v, float **dst) -> int {
+            void *q;
+            if (int rc = dev_alloc(h, h->derived_allocs, &q, sizeof(float) * v.size())) return rc;
+            *dst = (float *)q;
+            HIP_TRY(h, hipMemcpy(q, v.data(), sizeof(float) * v.size(), hipMemcpyHostToDevice));
+            return 0;
+        };
+        if (int rc = up(fap, &h->ro_fap)) return rc;
+        if (int rc = up(faf, &h->ro_fa)) return rc;
+        if (int rc = up(f2p, &h->ro_f2p)) return rc;
+        if (int rc = up(gext, &h->ro_gext)) return rc;
+    }
     // captured graphs bake weight pointers: drop them
-    for (auto &kv : h->ws)
+    for (auto &kv : h->ws) {
         if (kv.second->graph) { (void)hipGraphExecDestroy(kv.second->graph); kv.second->graph = nullptr; }
+        if (kv.second->graph_uniform) { (void)hipGraphExecDestroy(kv.second->graph_uniform); kv.second->graph_uniform = nullptr; }
+    }
     h->finalized = true;
     return DSG_OK;
 }
@@ -563,7 +645,7 @@ int get_workspace(dsg_handle h, int B, Workspace **out) {
     ALLOC(w->qkv, (size_t)B * 3 * T0 * E); ALLOC(w->att, (size_t)B * T0 * E);
     ALLOC(w->hid, (size_t)B * h->cfg.mlp_ratio * T0 * E);
     ALLOC(w->stats, (size_t)B * 2 * T0);
-    ALLOC(w->pool, (size_t)B * h->N * E); ALLOC(w->hn, (size_t)B * h->N * E);
+    ALLOC(w->pool, (size_t)B * h->N * E); ALLOC(w->hn, (size_t)B * h->N * E); ALLOC(w->pool_ext, (size_t)B * h->N * 128);
     for (int l = 0; l < h->L; l++) ALLOC(w->skips[l], ((size_t)B * T0 * E) >> (l + 1 < h->L ? l + 1 : l));
     ALLOC(w->x_adj, sa); ALLOC(w->x_node, sn); ALLOC(w->xh_adj, sa); ALLOC(w->xh_node, sn);
     for (int k = 0; k < 3; k++) { ALLOC(w->d_adj[k], sa); ALLOC(w->d_node[k], sn); }
@@ -598,11 +680,11 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
         // modulate+SiLU, LN1, QKV, window attention, proj and the residual in one register-resident kernel
         WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
         P_KERN(PK_ATTN, 2.0 * (double)M * C * 4.0 * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C,
-               launch_fused_attn96(w->x, w->aff, h->aff_n, b.aff_off, WT(h, p + ".norm1.weight"), WT(h, p + ".norm1.bias"), b.wqp,
+               launch_fused_attn96(w->x, w->aff, w->aff_ld, b.aff_off, WT(h, p + ".norm1.weight"), WT(h, p + ".norm1.bias"), b.wqp,
                                    WT(h, p + ".attn.qkv.bias"), b.biasT, b.wpp, WT(h, p + ".attn.proj.bias"), B, wg, s));
     } else {
         // x <- silu(shift + x*(1+scale)) (also the shortcut), LayerNorm-1 statistics
-        P_KERN(PK_ROW, 0.0, launch_mod_stats(w->x, w->aff, h->aff_n, b.aff_off, w->stats, B, T, C, s));
+        P_KERN(PK_ROW, 0.0, launch_mod_stats(w->x, w->aff, w->aff_ld, b.aff_off, w->stats, B, T, C, s));
         g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M;
         g.ln_stats = w->stats; g.ln_g = WT(h, p + ".norm1.weight"); g.ln_b = WT(h, p + ".norm1.bias");
         g.W = WT(h, p + ".attn.qkv.weight"); g.bias = WT(h, p + ".attn.qkv.bias"); g.N = 3 * C;
@@ -639,33 +721,54 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
     P_GEMM(g);
 }
 
+// PositionalEmbedding + map_layer0/1 + all affine linears for `rows` noise labels (diffusesg.py:768-771, :238, :574)
+void embed_rows(dsg_handle h, const float *c_noise, int rows, float *pe, float *emb0, float *emb, float *aff, hipStream_t s) {
+    const int E = h->E;
+    P_KERN(PK_ELEM, 0.0, launch_noise_pe(c_noise, pe, rows, E, s));
+    GemmArgs g;
+    g.A = pe; g.lda = E; g.K1 = E; g.K = E; g.M = rows; g.N = NOISE_EMB; g.act = ACT_SILU;
+    g.W = WT(h, "map_layer0.weight"); g.bias = WT(h, "map_layer0.bias"); g.C = emb0; g.ldc = NOISE_EMB;
+    P_GEMM(g);
+    g.A = emb0; g.lda = NOISE_EMB; g.K1 = NOISE_EMB; g.K = NOISE_EMB;
+    g.W = WT(h, "map_layer1.weight"); g.bias = WT(h, "map_layer1.bias"); g.C = emb;
+    P_GEMM(g);
+    g = GemmArgs();
+    g.A = emb; g.lda = NOISE_EMB; g.K1 = NOISE_EMB; g.K = NOISE_EMB; g.M = rows; g.N = h->aff_n;
+    g.W = h->aff_w; g.bias = h->aff_b; g.C = aff; g.ldc = h->aff_n;
+    P_GEMM(g);
+}
+
 // DiffuseSG.forward on the workspace's fixed buffers: (in_adj,in_node,sc_*,flags,c_noise) -> (f_adj,f_node)
 void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     const dsg_config &c = h->cfg;
     const int B = w->B, N = h->N, E = h->E, L = h->L, T0 = N * N;
     char name[64];
-    // noise embedding (diffusesg.py:768-771) and every block's (scale,shift) in one GEMM
-    P_KERN(PK_ELEM, 0.0, launch_noise_pe(w->c_noise, w->pe, B, E, s));
     GemmArgs g;
-    g.A = w->pe; g.lda = E; g.K1 = E; g.K = E; g.M = B; g.N = NOISE_EMB; g.act = ACT_SILU;
-    g.W = WT(h, "map_layer0.weight"); g.bias = WT(h, "map_layer0.bias"); g.C = w->emb0; g.ldc = NOISE_EMB;
-    P_GEMM(g);
-    g.A = w->emb0; g.lda = NOISE_EMB; g.K1 = NOISE_EMB; g.K = NOISE_EMB;
-    g.W = WT(h, "map_layer1.weight"); g.bias = WT(h, "map_layer1.bias"); g.C = w->emb;
-    P_GEMM(g);
-    g = GemmArgs();
-    g.A = w->emb; g.lda = NOISE_EMB; g.K1 = NOISE_EMB; g.K = NOISE_EMB; g.M = B; g.N = h->aff_n;
-    g.W = h->aff_w; g.bias = h->aff_b; g.C = w->aff; g.ldc = h->aff_n;
-    P_GEMM(g);
+    w->aff_ld = w->uniform ? 0 : h->aff_n;
+    if (!w->uniform) {
+        // noise embedding (diffusesg.py:768-771) and every block's (scale,shift) in one GEMM
+        embed_rows(h, w->c_noise, B, w->pe, w->emb0, w->emb, w->aff, s);
+    }
     // input assembly + PatchEmbed (diffusesg.py:784-802, 562-577)
-    P_KERN(PK_ELEM, 0.0, launch_assemble(w->in_adj, w->in_node, w->sc_adj, w->sc_node, w->has_sc, w->flags, w->tok_in, B, N, h->Ca, h->Cn,
-                    c.self_condition, h->Kp, s));
-    g = GemmArgs();
-    g.A = w->tok_in; g.lda = h->Kp; g.K1 = h->Kp; g.K = h->Kp; g.M = B * T0; g.N = E;
-    g.W = h->pe_w; g.bias = WT(h, "patch_embed.proj.bias"); g.C = w->y; g.ldc = E;
-    P_KERN(PK_GEMM, 2.0 * (double)g.M * (double)g.N * (double)h->Cin, launch_gemm(g, s));  // padded K is not algorithmic work
-    P_KERN(PK_ROW, 0.0, launch_ln_mod(w->y, WT(h, "patch_embed.norm.weight"), WT(h, "patch_embed.norm.bias"), w->aff, h->aff_n, h->pe_aff_off,
-                  w->x, B, T0, E, s));
+    static const bool fused_pe = env_on("DSG_FUSED_PE", true);
+    bool pe_done = false;
+    if (fused_pe && h->pe_wp) {
+        ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)B * T0 * E * h->Cin, "launch_fused_patch_embed96");
+        pe_done = launch_fused_patch_embed96(w->in_adj, w->in_node, w->sc_adj, w->sc_node, w->has_sc, w->flags, h->pe_wp,
+                                             WT(h, "patch_embed.proj.bias"), WT(h, "patch_embed.norm.weight"),
+                                             WT(h, "patch_embed.norm.bias"), w->aff, w->aff_ld, h->pe_aff_off, w->x, B, N, h->Ca, h->Cn,
+                                             c.self_condition, h->Kp, s);
+    }
+    if (!pe_done) {
+        P_KERN(PK_ELEM, 0.0, launch_assemble(w->in_adj, w->in_node, w->sc_adj, w->sc_node, w->has_sc, w->flags, w->tok_in, B, N, h->Ca, h->Cn,
+                        c.self_condition, h->Kp, s));
+        g = GemmArgs();
+        g.A = w->tok_in; g.lda = h->Kp; g.K1 = h->Kp; g.K = h->Kp; g.M = B * T0; g.N = E;
+        g.W = h->pe_w; g.bias = WT(h, "patch_embed.proj.bias"); g.C = w->y; g.ldc = E;
+        P_KERN(PK_GEMM, 2.0 * (double)g.M * (double)g.N * (double)h->Cin, launch_gemm(g, s));  // padded K is not algorithmic work
+        P_KERN(PK_ROW, 0.0, launch_ln_mod(w->y, WT(h, "patch_embed.norm.weight"), WT(h, "patch_embed.norm.bias"), w->aff, w->aff_ld, h->pe_aff_off,
+                      w->x, B, T0, E, s));
+    }
     tap(h, "patch_embed", w->x, (size_t)B * T0 * E, s);
     // encoder (diffusesg.py:745-748)
     for (int l = 0; l < L; l++) {
@@ -712,8 +815,23 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
             tap(h, name, w->x, (size_t)B * T * C, s);
         }
     }
-    // final norm + read_out (diffusesg.py:758-761)
+    // final norm + read_out + heads
     const int M0 = B * T0;
+    static const bool fused_ro = env_on("DSG_FUSED_READOUT", true);
+    if (fused_ro && h->ro_fap && h->taps.empty()) {
+        // one pass over x: LN, folded read_out+fc1, GELU, fc2, masked adjacency store; pooled LN(x) for the node head
+        P_KERN(PK_GEMM, 2.0 * (double)M0 * E * (E + 32.0),
+               launch_fused_readout96(w->x, WT(h, "norm.weight"), WT(h, "norm.bias"), h->ro_fap, h->ro_fa, h->ro_f2p,
+                                      WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, w->pool_ext, B, N, h->Ca, s));
+        g = GemmArgs();
+        g.A = w->pool_ext; g.lda = 128; g.K1 = 128; g.K = 128; g.M = B * N; g.N = E; g.act = ACT_GELU;
+        g.W = h->ro_gext; g.bias = WT(h, "readout_node_mlp.fc1.bias"); g.C = w->hn; g.ldc = E;
+        P_GEMM(g);
+        P_KERN(PK_ROW, 0.0, launch_head_node(w->hn, WT(h, "readout_node_mlp.fc2.weight"), WT(h, "readout_node_mlp.fc2.bias"), w->flags,
+                                             w->f_node, B, N, E, h->Cn, s));
+        return;
+    }
+    // faithful chain (diffusesg.py:758-761): final norm, three 1x1 convs
     P_KERN(PK_ROW, 0.0, launch_ln_stats(w->x, w->stats, M0, E, s));
     g = GemmArgs();
     g.A = w->x; g.lda = E; g.K1 = E; g.K = E; g.M = M0; g.N = E;
@@ -746,17 +864,18 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
 // run forward_fixed either eagerly or by replaying a captured graph
 int run_forward(dsg_handle h, Workspace *w, bool use_graph, hipStream_t s) {
     if (!use_graph || !h->taps.empty()) { forward_fixed(h, w, s); return 0; }
-    if (!w->graph) {
+    hipGraphExec_t &exec = w->uniform ? w->graph_uniform : w->graph;
+    if (!exec) {
         if (!w->cap_stream) HIP_TRY(h, hipStreamCreateWithFlags(&w->cap_stream, hipStreamNonBlocking));
         hipGraph_t graph;
         HIP_TRY(h, hipStreamBeginCapture(w->cap_stream, hipStreamCaptureModeThreadLocal));
         forward_fixed(h, w, w->cap_stream);
         HIP_TRY(h, hipStreamEndCapture(w->cap_stream, &graph));
-        hipError_t e = hipGraphInstantiate(&w->graph, graph, nullptr, nullptr, 0);
+        hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
-        if (e != hipSuccess) { w->graph = nullptr; return fail(h, DSG_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { exec = nullptr; return fail(h, DSG_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
     }
-    HIP_TRY(h, hipGraphLaunch(w->graph, s));
+    HIP_TRY(h, hipGraphLaunch(exec, s));
     h->last_stats.graph_replays++;
     return 0;
 }
@@ -790,8 +909,10 @@ int stage_inputs(dsg_handle h, Workspace *w, const float *adj, const float *node
 // NodeAdjPrecond.forward on workspace state: x (xh_adj/xh_node), sigmas (w->sig) -> D (dst), optionally
 // mirrored into the fixed self-cond input of the next forward.  sc: current self-cond or null.
 int precond_core(dsg_handle h, Workspace *w, CStatePtrs x, const float *sc_adj, const float *sc_node, bool coin, StatePtrs dst,
-                 bool use_graph, hipStream_t s, int64_t *nfe) {
+                 bool use_graph, hipStream_t s, int64_t *nfe, const float *aff_row = nullptr) {
     const Dims d = dims_of(h, w->B);
+    w->uniform = aff_row != nullptr;
+    if (aff_row) HIP_TRY(h, hipMemcpyAsync(w->aff, aff_row, sizeof(float) * h->aff_n, hipMemcpyDeviceToDevice, s));
     launch_precond_in(x, w->sig, StatePtrs{w->in_adj, w->in_node}, w->c_noise, d, s);
     if (int rc = stage_inputs(h, w, nullptr, nullptr, nullptr, sc_adj, sc_node, s)) return rc;
     if (h->cfg.self_condition && coin) {  // precond.py:90-98
@@ -832,6 +953,7 @@ int dsg_denoise(dsg_handle h, int32_t B, const float *adj, const float *node, co
     Workspace *w;
     if (int rc = get_workspace(h, B, &w)) return rc;
     if (int rc = stage_inputs(h, w, adj, node, flags, sc_adj, sc_node, s)) return rc;
+    w->uniform = false;
     HIP_TRY(h, hipMemcpyAsync(w->c_noise, noise_labels, sizeof(float) * B, hipMemcpyDeviceToDevice, s));
     if (int rc = run_forward(h, w, false, s)) return rc;
     const size_t sa = sizeof(float) * (size_t)B * h->Ca * h->N * h->N, sn = sizeof(float) * (size_t)B * h->N * h->Cn;
@@ -925,6 +1047,24 @@ int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_
     // x0 = init * sigma(t0) (edm.py:326, :346-347)
     launch_init(CStatePtrs{init_adj, init_node}, t_steps[0], seed, w->flags, StatePtrs{w->x_adj, w->x_node}, d, s);
     const bool use_graph = cfg->use_graph != 0;
+    // sigma is batch-uniform (edm.py:371): one noise embedding + (scale,shift) row per step, computed once for all steps
+    if (!gt_adj) {
+        if (h->tab_cap < T) {
+            for (float **q : {&h->tab_sig, &h->tab_cn, &h->tab_pe, &h->tab_e0, &h->tab_e1, &h->tab_aff}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+            h->tab_cap = 0;
+            HIP_TRY(h, hipMalloc((void **)&h->tab_sig, sizeof(float) * T));
+            HIP_TRY(h, hipMalloc((void **)&h->tab_cn, sizeof(float) * T));
+            HIP_TRY(h, hipMalloc((void **)&h->tab_pe, sizeof(float) * (size_t)T * h->E));
+            HIP_TRY(h, hipMalloc((void **)&h->tab_e0, sizeof(float) * (size_t)T * NOISE_EMB));
+            HIP_TRY(h, hipMalloc((void **)&h->tab_e1, sizeof(float) * (size_t)T * NOISE_EMB));
+            HIP_TRY(h, hipMalloc((void **)&h->tab_aff, sizeof(float) * (size_t)T * h->aff_n));
+            h->tab_cap = T;
+        }
+        HIP_TRY(h, hipMemcpyAsync(h->tab_sig, t_hat.data(), sizeof(float) * T, hipMemcpyHostToDevice, s));
+        launch_cnoise(h->tab_sig, h->tab_cn, T, s);
+        embed_rows(h, h->tab_cn, T, h->tab_pe, h->tab_e0, h->tab_e1, h->tab_aff, s);
+        HIP_TRY(h, hipStreamSynchronize(s));  // t_hat (host vector) must outlive the async copy; once per sample() call
+    }
     int sc_slot = -1;  // which d_* buffer holds the current self-cond, -1 = None
     int call = 0, snap_k = 0;
     int64_t nfe = 0;
@@ -942,7 +1082,8 @@ int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_
         if (gt_adj) D1 = CStatePtrs{gt_adj, gt_node};
         else {
             if (int rc = precond_core(h, w, xh, sc_slot >= 0 ? w->d_adj[sc_slot] : nullptr, sc_slot >= 0 ? w->d_node[sc_slot] : nullptr,
-                                      coin_buf[call++] != 0, StatePtrs{w->d_adj[s1], w->d_node[s1]}, use_graph, s, &nfe))
+                                      coin_buf[call++] != 0, StatePtrs{w->d_adj[s1], w->d_node[s1]}, use_graph, s, &nfe,
+                                      h->tab_aff + (size_t)i * h->aff_n))
                 return rc;
             D1 = CStatePtrs{w->d_adj[s1], w->d_node[s1]};
         }
@@ -957,7 +1098,7 @@ int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_
             else {
                 const bool sc = h->cfg.self_condition;
                 if (int rc = precond_core(h, w, xh, sc ? w->d_adj[s1] : nullptr, sc ? w->d_node[s1] : nullptr, coin_buf[call++] != 0,
-                                          StatePtrs{w->d_adj[s2], w->d_node[s2]}, use_graph, s, &nfe))
+                                          StatePtrs{w->d_adj[s2], w->d_node[s2]}, use_graph, s, &nfe, h->tab_aff + (size_t)i * h->aff_n))
                     return rc;
                 D2 = CStatePtrs{w->d_adj[s2], w->d_node[s2]};
             }

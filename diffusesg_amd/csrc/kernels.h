@@ -37,6 +37,15 @@ struct WinGeom {
     int heads;
     int C;
 };
+// input assembly + 1x1 conv + LayerNorm + modulate+SiLU in one kernel (E = 96, in_chans <= 64); false if unsupported
+bool launch_fused_patch_embed96(const float *adj, const float *node, const float *sc_adj, const float *sc_node, const int *has_sc,
+                                const uint8_t *flags, const float *Wp, const float *bias, const float *gam, const float *bet,
+                                const float *aff, int aff_ld, int aff_off, float *x, int B, int N, int Ca, int Cn, int self_cond, int Kp,
+                                hipStream_t s);
+// final LN + folded read_out/adj-head chain + masked adjacency output, and the LN(x) pooling for the node head (E = 96)
+void launch_fused_readout96(const float *x, const float *gam, const float *bet, const float *Wfp, const float *fa, const float *W2p,
+                            const float *f2, const uint8_t *flags, float *out_adj, float *pool_ext, int B, int N, int Ca,
+                            hipStream_t s);
 // whole attention half of a C=96 Swin block in one kernel (modulate+SiLU, LN1, QKV, window attention, proj, residual);
 // windows of at most 64 tokens; packed weights from pack_attn_weights in dsg_api.cpp
 void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, const float *gam, const float *bet, const float *Wqp,
@@ -76,6 +85,8 @@ struct StatePtrs { float *adj; float *node; };
 struct CStatePtrs { const float *adj; const float *node; };
 struct Dims { int B, N, Ca, Cn; };
 
+// c_noise[i] = ln(sigma[i])/4
+void launch_cnoise(const float *sigmas, float *c_noise, int n, hipStream_t s);
 // in = c_in(sigma[b]) * x ; c_noise[b] = ln(sigma[b])/4
 void launch_precond_in(CStatePtrs x, const float *sigmas, StatePtrs in, float *c_noise, Dims d, hipStream_t s);
 // D = mask(c_skip*x + c_out*F); optionally stored to a second destination

@@ -947,6 +947,250 @@ void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, co
 }
 
 // =================================================================================================
+// Fused read-out for E = 96 (diffusesg.py:758-761, 806-813, 825): final LayerNorm, the three 1x1 read_out convs and
+// readout_adj_mlp.fc1 are one affine map before the GELU (folded on the host at weight load: Fa = F1.W2.W1.W0^T),
+// so per 32 tokens:  H^T = Fa . LN(x)^T -> GELU -> out^T = F2 . H^T  -> masked store in [B,C_adj,N,N] layout.
+// The same pass accumulates the node head's padding-aware pooling of LN(x) (the pooled shared_rep is recovered
+// from it by linearity in the node chain): pool[b,i,:] += (f_i f_j / N) * LN(x)[b,i,j,:].
+// =================================================================================================
+__global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__restrict__ x, const float *__restrict__ gam,
+                                                                 const float *__restrict__ bet, const float *__restrict__ Wfp,
+                                                                 const float *__restrict__ fa, const float *__restrict__ W2p,
+                                                                 const float *__restrict__ f2, const uint8_t *__restrict__ flags,
+                                                                 float *__restrict__ out_adj, float *__restrict__ pool_ext,
+                                                                 int B, int N, int Ca) {
+    constexpr int C = 96, S = 12;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int T = N * N, M = B * T;
+    const int m = (blockIdx.x * 4 + wave) * 32 + lrow;
+    const bool ok = m < M;
+    const int mc = ok ? m : M - 1;
+    const int b = mc / T, i = (mc / N) % N, j = mc % N;
+    const float *xr = x + (size_t)mc * C + 4 * lhalf;
+    f32x4 xn[S];
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        xn[s] = *reinterpret_cast<const f32x4 *>(xr + 8 * s);
+        sum += (xn[s][0] + xn[s][1]) + (xn[s][2] + xn[s][3]);
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / C);
+    float var = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; s++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) { const float d = xn[s][t] - mean; var = fmaf(d, d, var); }
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / C) + LN_EPS);
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+        const f32x4 gg = *reinterpret_cast<const f32x4 *>(gam + 8 * s + 4 * lhalf);
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(bet + 8 * s + 4 * lhalf);
+        xn[s] = (xn[s] - mean) * rstd * gg + bb;
+    }
+    const bool fi = flags[(size_t)b * N + i] != 0, fj = flags[(size_t)b * N + j] != 0;
+    const bool valid = ok && fi && fj;
+
+    // pooled LN(x): segmented sum over the tokens of this wave that share a row (b,i)
+    {
+        const int rowid = ok ? b * N + i : -1;
+        const int r_first = __shfl(rowid, 0, 64);
+        int r_last = __shfl(rowid, 31, 64);
+        if (r_last < 0) r_last = (M - 1) / N;  // partially filled last tile
+        const float wgt = valid ? 1.0f / (float)N : 0.f;
+        for (int r = r_first; r <= r_last; r++) {
+            const float sel = (rowid == r) ? wgt : 0.f;
+            if (__ballot(sel != 0.f) == 0ull) continue;
+#pragma unroll
+            for (int s = 0; s < S; s++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    float v = sel * xn[s][t];
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    if (lrow == 0) atomicAdd(pool_ext + (size_t)r * 128 + 8 * s + 4 * lhalf + t, v);
+                }
+        }
+    }
+
+    const f32x4 *w1 = reinterpret_cast<const f32x4 *>(Wfp) + lane;
+    const f32x4 *w2 = reinterpret_cast<const f32x4 *>(W2p) + lane;
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[r] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++) {
+        f32x16 hacc;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(fa + 32 * nt + 8 * g + 4 * lhalf);
+#pragma unroll
+            for (int t = 0; t < 4; t++) hacc[4 * g + t] = bv[t];
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const f32x4 a = w1[((size_t)nt * S + s) * 64];
+#pragma unroll
+            for (int t = 0; t < 4; t++) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], xn[s][t], hacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) hacc[r] = gelu_f(hacc[r]);
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f32x4 a = w2[((size_t)nt * 4 + g) * 64];
+#pragma unroll
+            for (int t = 0; t < 4; t++) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], hacc[4 * g + t], oacc, 0, 0, 0);
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            if (c < Ca) out_adj[(((size_t)b * Ca + c) * N + i) * N + j] = valid ? oacc[r] + f2[c] : 0.f;
+        }
+    }
+}
+
+// pool_ext [B*N,128]: zero, and column 96 = f_i * (#valid nodes) / N (the factor of the folded constant term)
+__global__ void pool_init_kernel(const uint8_t *flags, float *pool_ext, int B, int N) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * N * 128) return;
+    const int col = idx & 127, row = idx >> 7, b = row / N;
+    float v = 0.f;
+    if (col == 96 && flags[row]) {
+        int cnt = 0;
+        for (int jj = 0; jj < N; jj++) cnt += flags[(size_t)b * N + jj] ? 1 : 0;
+        v = (float)cnt / (float)N;
+    }
+    pool_ext[idx] = v;
+}
+
+void launch_fused_readout96(const float *x, const float *gam, const float *bet, const float *Wfp, const float *fa, const float *W2p,
+                            const float *f2, const uint8_t *flags, float *out_adj, float *pool_ext, int B, int N, int Ca,
+                            hipStream_t s) {
+    const int n = B * N * 128;
+    hipLaunchKernelGGL(pool_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flags, pool_ext, B, N);
+    const int M = B * N * N;
+    hipLaunchKernelGGL(fused_readout96_kernel, dim3((M + 127) / 128), dim3(256), 0, s, x, gam, bet, Wfp, fa, W2p, f2, flags, out_adj,
+                       pool_ext, B, N, Ca);
+}
+
+// =================================================================================================
+// Fused PatchEmbed for E = 96 (diffusesg.py:784-802 input assembly, :562-577 1x1 conv + LayerNorm + modulate+SiLU).
+// Per 32 tokens: the (i,j) input vector [sc_adj, adj, sc_node(i), node(i), sc_node(j), node(j)] is gathered straight
+// into MFMA B-fragments (lane = token; consecutive lanes = consecutive j, so the channel-major adjacency reads are
+// coalesced), Y^T = Wpe . in^T on the matrix cores, LayerNorm over the 96 outputs (split over registers and the two
+// half-waves), modulate, SiLU, 16-B stores.  KP = in_chans rounded up to 32.
+// =================================================================================================
+template <int KP>
+__global__ __launch_bounds__(256, 2) void fused_patch_embed96_kernel(const float *__restrict__ adj, const float *__restrict__ node,
+                                                                    const float *__restrict__ sc_adj, const float *__restrict__ sc_node,
+                                                                    const int *__restrict__ has_sc, const uint8_t *__restrict__ flags,
+                                                                    const float *__restrict__ Wp, const float *__restrict__ bias,
+                                                                    const float *__restrict__ gam, const float *__restrict__ bet,
+                                                                    const float *__restrict__ aff, int aff_ld, int aff_off,
+                                                                    float *__restrict__ x, int B, int N, int Ca, int Cn, int self_cond) {
+    constexpr int C = 96, S = KP / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int T = N * N, M = B * T;
+    const int m = (blockIdx.x * 4 + wave) * 32 + lrow;
+    const bool ok = m < M;
+    const int mc = ok ? m : M - 1;
+    const int b = mc / T, i = (mc / N) % N, j = mc % N;
+    const bool sc_on = self_cond && sc_adj != nullptr && (has_sc == nullptr || *has_sc != 0);
+    const int nsc = self_cond ? 2 : 1;
+    const bool mask = flags[(size_t)b * N + i] && flags[(size_t)b * N + j];
+    f32x4 in[S];
+#pragma unroll
+    for (int s = 0; s < S; s++)
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int c = 8 * s + 4 * lhalf + t;
+            float v = 0.f;
+            if (c < nsc * Ca) {
+                const int which = self_cond ? c / Ca : 1, a = c % Ca;
+                const float *src = (which == 0) ? (sc_on ? sc_adj : nullptr) : adj;
+                if (src) v = src[(((size_t)b * Ca + a) * N + i) * N + j];
+            } else if (c < nsc * (Ca + 2 * Cn)) {
+                const int cc = c - nsc * Ca;
+                const int colpart = cc / (nsc * Cn), c2 = cc % (nsc * Cn);
+                const int which = self_cond ? c2 / Cn : 1, a = c2 % Cn;
+                const float *src = (which == 0) ? (sc_on ? sc_node : nullptr) : node;
+                if (src && mask) v = src[((size_t)b * N + (colpart ? j : i)) * Cn + a];
+            }
+            in[s][t] = v;
+        }
+    const f32x4 *w = reinterpret_cast<const f32x4 *>(Wp) + lane;  // [3][S][64] float4
+    f32x16 acc[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + 32 * nt + 8 * g + 4 * lhalf);
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[nt][4 * g + t] = bv[t];
+        }
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const f32x4 a = w[((size_t)nt * S + s) * 64];
+#pragma unroll
+            for (int t = 0; t < 4; t++) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], in[s][t], acc[nt], 0, 0, 0);
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) sum += acc[nt][r];
+    sum += __shfl_xor(sum, 32, 64);
+    const float mean = sum * (1.0f / C);
+    float var = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const float d = acc[nt][r] - mean; var = fmaf(d, d, var); }
+    var += __shfl_xor(var, 32, 64);
+    const float rstd = 1.0f / sqrtf(var * (1.0f / C) + LN_EPS);
+    if (!ok) return;
+    const float *scale = aff + (size_t)b * aff_ld + aff_off + 4 * lhalf, *shift = scale + C;
+    float *xr = x + (size_t)m * C + 4 * lhalf;
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int e = 32 * nt + 8 * g;
+            const f32x4 gg = *reinterpret_cast<const f32x4 *>(gam + e + 4 * lhalf);
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(bet + e + 4 * lhalf);
+            const f32x4 sc = *reinterpret_cast<const f32x4 *>(scale + e);
+            const f32x4 sh = *reinterpret_cast<const f32x4 *>(shift + e);
+            f32x4 o;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const float n = (acc[nt][4 * g + t] - mean) * rstd * gg[t] + bb[t];
+                o[t] = silu_exact(sh[t] + n * (sc[t] + 1.0f));
+            }
+            *reinterpret_cast<f32x4 *>(xr + e) = o;
+        }
+}
+
+bool launch_fused_patch_embed96(const float *adj, const float *node, const float *sc_adj, const float *sc_node, const int *has_sc,
+                                const uint8_t *flags, const float *Wp, const float *bias, const float *gam, const float *bet,
+                                const float *aff, int aff_ld, int aff_off, float *x, int B, int N, int Ca, int Cn, int self_cond, int Kp,
+                                hipStream_t s) {
+    const int M = B * N * N;
+    const dim3 grid((M + 127) / 128), block(256);
+#define PE_ARGS adj, node, sc_adj, sc_node, has_sc, flags, Wp, bias, gam, bet, aff, aff_ld, aff_off, x, B, N, Ca, Cn, self_cond
+    if (Kp == 32) hipLaunchKernelGGL(fused_patch_embed96_kernel<32>, grid, block, 0, s, PE_ARGS);
+    else if (Kp == 64) hipLaunchKernelGGL(fused_patch_embed96_kernel<64>, grid, block, 0, s, PE_ARGS);
+    else return false;
+#undef PE_ARGS
+    return true;
+}
+
+// =================================================================================================
 // Window attention core (R/model/diffusesg/diffusesg.py:108-139 with the window partition, cyclic
 // shift and their inverses of :28-57, :246-271 folded into the token index).
 //
@@ -1076,36 +1320,38 @@ void launch_window_attn(const float *qkv, const float *biasT, float *out, int B,
 // Row kernels: one wave per token row, values held in registers between the passes.
 // =================================================================================================
 constexpr int ROW_MAXV = 24;  // rows up to 64*24 = 1536 channels (PatchBreakup at the deepest level)
+constexpr int ROW_MAXV4 = 6;  // the same in float4 units per lane
 
 // x <- silu(shift + x*(1+scale)); stats = LayerNorm statistics of the NEW row (norm1 runs on the
-// modulated tensor, which is also the residual shortcut: diffusesg.py:238-243)
+// modulated tensor, which is also the residual shortcut: diffusesg.py:238-243).  16 B per lane per access.
 __global__ __launch_bounds__(256) void mod_stats_kernel(float *x, const float *aff, int aff_ld, int aff_off, float *stats,
                                                         int T, int C, int M) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
-    const int b = m / T;
-    const float *scale = aff + (size_t)b * aff_ld + aff_off, *shift = scale + C;
-    float *xr = x + (size_t)m * C;
-    float v[ROW_MAXV];
+    const int b = m / T, C4 = C >> 2;
+    const f32x4 *scale = reinterpret_cast<const f32x4 *>(aff + (size_t)b * aff_ld + aff_off), *shift = scale + C4;
+    f32x4 *xr = reinterpret_cast<f32x4 *>(x + (size_t)m * C);
+    f32x4 v[ROW_MAXV4];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < ROW_MAXV; i++) {
+    for (int i = 0; i < ROW_MAXV4; i++) {
         const int c = lane + 64 * i;
-        v[i] = 0.f;
-        if (c < C) {
-            v[i] = silu_exact(shift[c] + xr[c] * (scale[c] + 1.0f));
+        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c < C4) {
+            const f32x4 xv = xr[c], sc = scale[c], sh = shift[c];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { v[i][t] = silu_exact(sh[t] + xv[t] * (sc[t] + 1.0f)); sum += v[i][t]; }
             xr[c] = v[i];
-            sum += v[i];
         }
     }
     const float mean = wave_sum(sum) / (float)C;
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < ROW_MAXV; i++) {
-        const int c = lane + 64 * i;
-        if (c < C) { const float d = v[i] - mean; var += d * d; }
-    }
+    for (int i = 0; i < ROW_MAXV4; i++)
+        if (lane + 64 * i < C4)
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const float d = v[i][t] - mean; var += d * d; }
     var = wave_sum(var) / (float)C;
     if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = 1.0f / sqrtf(var + LN_EPS); }
 }
@@ -1118,22 +1364,23 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float *x, float *st
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
-    const float *xr = x + (size_t)m * C;
-    float v[ROW_MAXV];
+    const int C4 = C >> 2;
+    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + (size_t)m * C);
+    f32x4 v[ROW_MAXV4];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < ROW_MAXV; i++) {
+    for (int i = 0; i < ROW_MAXV4; i++) {
         const int c = lane + 64 * i;
-        v[i] = (c < C) ? xr[c] : 0.f;
-        sum += v[i];
+        v[i] = (c < C4) ? xr[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = wave_sum(sum) / (float)C;
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < ROW_MAXV; i++) {
-        const int c = lane + 64 * i;
-        if (c < C) { const float d = v[i] - mean; var += d * d; }
-    }
+    for (int i = 0; i < ROW_MAXV4; i++)
+        if (lane + 64 * i < C4)
+#pragma unroll
+            for (int t = 0; t < 4; t++) { const float d = v[i][t] - mean; var += d * d; }
     var = wave_sum(var) / (float)C;
     if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = 1.0f / sqrtf(var + LN_EPS); }
 }
@@ -1189,33 +1436,35 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float *x, const flo
     if (m >= M) return;
     const int r2 = res / 2, T2 = r2 * r2;
     const int b = m / T2, t = m % T2, i = t / r2, j = t % r2;
-    const int C4 = 4 * C;
-    const float *xb = x + (size_t)b * res * res * C;
-    float v[ROW_MAXV];
+    const int C4 = C >> 2, D4 = C;  // float4 per source row / per output row (4C/4)
+    const f32x4 *xb = reinterpret_cast<const f32x4 *>(x + (size_t)b * res * res * C);
+    f32x4 v[ROW_MAXV4];
     float sum = 0.f;
 #pragma unroll
-    for (int q = 0; q < ROW_MAXV; q++) {
+    for (int q = 0; q < ROW_MAXV4; q++) {
         const int c = lane + 64 * q;
-        v[q] = 0.f;
-        if (c < C4) {
-            const int part = c / C, cc = c % C;
+        v[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c < D4) {
+            const int part = c / C4, cc = c % C4;
             const int di = part & 1, dj = part >> 1;
-            v[q] = xb[(size_t)((2 * i + di) * res + (2 * j + dj)) * C + cc];
-            sum += v[q];
+            v[q] = xb[(size_t)((2 * i + di) * res + (2 * j + dj)) * C4 + cc];
+            sum += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
         }
     }
-    const float mean = wave_sum(sum) / (float)C4;
+    const float mean = wave_sum(sum) / (float)(4 * C);
     float var = 0.f;
 #pragma unroll
-    for (int q = 0; q < ROW_MAXV; q++) {
-        const int c = lane + 64 * q;
-        if (c < C4) { const float d = v[q] - mean; var += d * d; }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)C4 + LN_EPS);
+    for (int q = 0; q < ROW_MAXV4; q++)
+        if (lane + 64 * q < D4)
 #pragma unroll
-    for (int q = 0; q < ROW_MAXV; q++) {
+            for (int tt = 0; tt < 4; tt++) { const float d = v[q][tt] - mean; var += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)(4 * C) + LN_EPS);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g), *b4 = reinterpret_cast<const f32x4 *>(bta);
+    f32x4 *yr = reinterpret_cast<f32x4 *>(y + (size_t)m * 4 * C);
+#pragma unroll
+    for (int q = 0; q < ROW_MAXV4; q++) {
         const int c = lane + 64 * q;
-        if (c < C4) y[(size_t)m * C4 + c] = (v[q] - mean) * rstd * g[c] + bta[c];
+        if (c < D4) yr[c] = (v[q] - mean) * rstd * g4[c] + b4[c];
     }
 }
 void launch_merge_ln(const float *x, const float *g, const float *b, float *y, int B, int res, int C, hipStream_t s) {
@@ -1230,62 +1479,71 @@ __global__ __launch_bounds__(256) void breakup_ln_kernel(const float *y, const f
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int T = res * res, b = m / T, t = m % T, i = t / res, j = t % res;
-    const int Co = D / 4, R = 2 * res;
-    const float *yr = y + (size_t)m * D;
-    float v[ROW_MAXV];
+    const int Co = D / 4, R = 2 * res, D4 = D >> 2, Co4 = Co >> 2;
+    const f32x4 *yr = reinterpret_cast<const f32x4 *>(y + (size_t)m * D);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g), *b4 = reinterpret_cast<const f32x4 *>(bta);
+    f32x4 v[ROW_MAXV4];
     float sum = 0.f;
 #pragma unroll
-    for (int q = 0; q < ROW_MAXV; q++) {
+    for (int q = 0; q < ROW_MAXV4; q++) {
         const int c = lane + 64 * q;
-        v[q] = (c < D) ? yr[c] : 0.f;
-        sum += v[q];
+        v[q] = (c < D4) ? yr[c] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        sum += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
     }
     const float mean = wave_sum(sum) / (float)D;
     float var = 0.f;
 #pragma unroll
-    for (int q = 0; q < ROW_MAXV; q++) {
-        const int c = lane + 64 * q;
-        if (c < D) { const float d = v[q] - mean; var += d * d; }
-    }
+    for (int q = 0; q < ROW_MAXV4; q++)
+        if (lane + 64 * q < D4)
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) { const float d = v[q][tt] - mean; var += d * d; }
     const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)D + LN_EPS);
-    // per-chunk statistics of the normalised row
+    // per-chunk statistics of the normalised row (a float4 never straddles a chunk: Co % 4 == 0)
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < ROW_MAXV; q++) {
+    for (int q = 0; q < ROW_MAXV4; q++) {
         const int c = lane + 64 * q;
-        if (c < D) {
-            v[q] = (v[q] - mean) * rstd * g[c] + bta[c];
-            const int part = c / Co;
+        if (c < D4) {
+            v[q] = (v[q] - mean) * rstd * g4[c] + b4[c];
+            const int part = c / Co4;
+            const float s4 = (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
 #pragma unroll
-            for (int p = 0; p < 4; p++) csum[p] += (part == p) ? v[q] : 0.f;
+            for (int p = 0; p < 4; p++) csum[p] += (part == p) ? s4 : 0.f;
         }
     }
     float cmean[4], cvar[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int p = 0; p < 4; p++) cmean[p] = wave_sum(csum[p]) / (float)Co;
 #pragma unroll
-    for (int q = 0; q < ROW_MAXV; q++) {
+    for (int q = 0; q < ROW_MAXV4; q++) {
         const int c = lane + 64 * q;
-        if (c < D) {
-            const int part = c / Co;
+        if (c < D4) {
+            const int part = c / Co4;
+            float mu = cmean[0];
 #pragma unroll
-            for (int p = 0; p < 4; p++) { const float d = v[q] - cmean[p]; cvar[p] += (part == p) ? d * d : 0.f; }
+            for (int p = 1; p < 4; p++) if (part == p) mu = cmean[p];
+            float d2 = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) { const float d = v[q][tt] - mu; d2 += d * d; }
+#pragma unroll
+            for (int p = 0; p < 4; p++) cvar[p] += (part == p) ? d2 : 0.f;
         }
     }
     float crstd[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) crstd[p] = 1.0f / sqrtf(wave_sum(cvar[p]) / (float)Co + LN_EPS);
+    const f32x4 *pg4 = reinterpret_cast<const f32x4 *>(pg), *pb4 = reinterpret_cast<const f32x4 *>(pb);
 #pragma unroll
-    for (int q = 0; q < ROW_MAXV; q++) {
+    for (int q = 0; q < ROW_MAXV4; q++) {
         const int c = lane + 64 * q;
-        if (c < D) {
-            const int part = c / Co, cc = c % Co;
+        if (c < D4) {
+            const int part = c / Co4, cc = c % Co4;
             const int di = part & 1, dj = part >> 1;
             float mu = cmean[0], rs = crstd[0];
 #pragma unroll
             for (int p = 1; p < 4; p++) if (part == p) { mu = cmean[p]; rs = crstd[p]; }
             const size_t orow = (size_t)b * 4 * T + (size_t)(2 * i + di) * R + (2 * j + dj);
-            z[orow * Co + cc] = (v[q] - mu) * rs * pg[cc] + pb[cc];
+            reinterpret_cast<f32x4 *>(z + orow * Co)[cc] = (v[q] - mu) * rs * pg4[cc] + pb4[cc];
         }
     }
 }
@@ -1448,6 +1706,13 @@ __global__ void precond_in_kernel(CStatePtrs x, const float *sigmas, StatePtrs i
     const float c_in = __fdiv_rn(1.0f, __fsqrt_rn(FADD(0.25f, FMUL(s, s))));       // objectives/edm.py:125
     if (e.is_adj) in.adj[e.off] = FMUL(c_in, x.adj[e.off]);
     else in.node[e.off] = FMUL(c_in, x.node[e.off]);
+}
+__global__ void cnoise_kernel(const float *sigmas, float *c_noise, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c_noise[i] = __fdiv_rn(logf(sigmas[i]), 4.0f);  // objectives/edm.py:126
+}
+void launch_cnoise(const float *sigmas, float *c_noise, int n, hipStream_t s) {
+    hipLaunchKernelGGL(cnoise_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sigmas, c_noise, n);
 }
 void launch_precond_in(CStatePtrs x, const float *sigmas, StatePtrs in, float *c_noise, Dims d, hipStream_t s) {
     const size_t n = total_elems(d);
