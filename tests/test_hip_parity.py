@@ -207,20 +207,13 @@ def test_init_noise_moments():
 
 
 def test_decode_bits_matches_numpy():
-    import ctypes as C
     cfg = Y.CONFIGS["vg"]()
     n, B = cfg.max_node_num, 3
     flags = W.synth_flags(B, n, [30, 64, 2])
     adj = W.normal(9, "dec/adj", (B, cfg.c_adj, n, n))
     node = W.normal(9, "dec/node", (B, n, cfg.c_node))
-    net = net_for("vg").model
-    h = net._ensure_handle()
-    oa = torch.empty((B, n, n), dtype=torch.int32, device="cuda")
-    on = torch.empty((B, n), dtype=torch.int32, device="cuda")
-    ob = torch.empty((B, n, 4), dtype=torch.float32, device="cuda")
-    ta, tn, tf = T(adj), T(node), T(flags.astype(np.uint8))
-    h.check(h.L.dsg_decode_bits(h.raw, B, ta.data_ptr(), tn.data_ptr(), tf.data_ptr(), 51, 150, 8,
-                                oa.data_ptr(), on.data_ptr(), ob.data_ptr(), None), "decode")
+    from diffusesg_amd import io as dio
+    oa, on, ob = dio.decode_bits(net_for("vg"), T(adj), T(node), T(flags), n_adj_type=51, n_node_type=150)
     torch.cuda.synchronize()
     # numpy restatement of sampler_node_adj.py:222-285 (MSB-first bin2dec, clamp, mask, no self loops)
     f = flags.astype(bool)
@@ -232,3 +225,29 @@ def test_decode_bits_matches_numpy():
     bb = (node[..., -4:] * 0.5 + 0.5) * f[..., None]
     assert np.array_equal(oa.cpu().numpy(), qa) and np.array_equal(on.cpu().numpy(), qn)
     np.testing.assert_allclose(ob.cpu().numpy(), bb, rtol=0, atol=1e-7)
+
+
+def test_end_to_end_checkpoint_sample_decode_npz(tmp_path):
+    """§8f hand-offs around the hot path: reference-format checkpoint -> strict load -> sample -> device decode -> npz."""
+    from diffusesg_amd import io as dio
+    from diffusesg_amd.model import build_network
+    cfg = Y.CONFIGS["tiny"]()
+    sd = {k: torch.from_numpy(v) for k, v in W.synth_state_dict(cfg, 0, prefix="model.").items()}
+    path = str(tmp_path / "tiny_00001.pth")
+    torch.save({"model": sd, "config": {}, "epoch": 1, "train_loss": 0.0, "test_loss": 0.0}, path)
+    net = build_network(cfg, device="cuda")
+    dio.load_model(dio.load_checkpoint(path), net, "model")
+    flags, ia, inn, na, nn, cv = Y.sampler_case(cfg, 8, 4, Y.SAMPLER_VALID, 3, "smp/t8_heun", "heun")
+    smp = make_sampler(8)
+    oa, on = smp.sample(net, T(flags), init_adjs=T(ia), init_nodes=T(inn), churn_noise=(T(na), T(nn)),
+                        coins=(cv < 0.5).astype(np.uint8), num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    assert_close(oa.numpy(), load("sampler.npz")["t8_heun_adj"], 1e-4, "ckpt-loaded net reproduces the golden trajectory")
+    qa, qn, bb = dio.decode_bits(net, oa, on, T(flags), n_adj_type=51, n_node_type=150)
+    assert qa.shape == (4, 8, 8) and qn.shape == (4, 8) and bb.shape == (4, 8, 4)
+    f = torch.from_numpy(flags).cuda()
+    assert int(qa.max()) <= 50 and int(qn.max()) <= 149 and torch.all(qa[:, torch.arange(8), torch.arange(8)] == 0)
+    assert torch.all(qn[~f] == 0) and torch.all(bb[~f] == 0)
+    p = str(tmp_path / "final_samples_array_before_eval.npz")
+    dio.save_samples_npz(p, samples_node_flags=flags, samples_a=qa, samples_x=qn, raw_a=oa, raw_x=on[..., :-4], samples_x_bbox=bb)
+    z = np.load(p, allow_pickle=True)
+    assert z["samples_a"].shape == (4, 8, 8) and z["raw_x"].shape == (4, 8, 8)

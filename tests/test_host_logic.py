@@ -92,3 +92,53 @@ def test_gather_world2_gloo():
         a, n = ddist.unpack_results(torch.from_numpy(full0[3 * r:3 * r + 3]), 3, 4, 5)
         assert np.array_equal(a.numpy(), res[r][2]) and np.array_equal(n.numpy(), res[r][3])
     assert not np.array_equal(res[0][2], res[1][2])                              # seeds differ by rank
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    """A file in the reference's checkpoint layout (trainer_utils.py:168-185), incl. DDP 'module.' keys and EMA copies."""
+    from diffusesg_amd import io as dio
+    from diffusesg_amd import weights as W
+    from diffusesg_amd.model import build_network
+    cfg = spec.tiny_config()
+    sd = {k: torch.from_numpy(v) for k, v in W.synth_state_dict(cfg, 0, prefix="model.").items()}
+    ema = {"module." + k: v * 0.5 if v.dtype == torch.float32 else v for k, v in sd.items()}
+    path = str(tmp_path / "tiny_00010.pth")
+    torch.save({"model": sd, "config": {"seed": 1234}, "epoch": 10, "train_loss": 0.1, "test_loss": 0.2,
+                "model_ema_beta_0.9990": ema}, path)
+    ck = dio.load_checkpoint(path)
+    assert dio.ema_weight_keywords(ck) == ["model"]
+    assert dio.ema_weight_keywords(ck, "all") == ["model", "model_ema_beta_0.9990"]
+    assert dio.ema_weight_keywords(ck, [1.0, 0.999]) == ["model", "model_ema_beta_0.9990"]
+    net = build_network(cfg, device="cpu")
+    dio.load_model(ck, net, "model")
+    assert torch.equal(net.state_dict()["model.norm.weight"], sd["model.norm.weight"])
+    dio.load_model(ck, net, "model_ema_beta_0.9990")
+    assert torch.allclose(net.state_dict()["model.norm.weight"], sd["model.norm.weight"] * 0.5)
+    bad = dict(sd)
+    bad.pop("model.norm.bias")
+    with pytest.raises(RuntimeError):
+        dio.load_model({"model": bad}, net, "model")        # strict=True like the reference
+
+
+def test_npz_writer_keys(tmp_path):
+    from diffusesg_amd import io as dio
+    B, n = 3, 8
+    p = str(tmp_path / "final_samples_array_before_eval.npz")
+    dio.save_samples_npz(p, samples_node_flags=torch.ones(B, n), samples_a=torch.zeros(B, n, n), samples_x=torch.zeros(B, n),
+                         raw_a=torch.zeros(B, 6, n, n), raw_x=torch.zeros(B, n, 8), samples_x_bbox=torch.zeros(B, n, 4))
+    z = np.load(p, allow_pickle=True)   # our own file; None entries are object arrays exactly as in the reference's archive
+    assert set(z.files) == {"samples_node_flags", "samples_a", "samples_x", "raw_a", "raw_x", "gt_node_flags", "gt_a", "gt_x",
+                            "samples_x_bbox", "gt_x_bbox", "gt_image_ids"}
+    assert z["samples_node_flags"].dtype == bool and z["raw_a"].shape == (B, 6, n, n)
+
+
+def test_pack_decoded_roundtrip():
+    from diffusesg_amd import io as dio
+    B, n = 4, 8
+    qa = torch.randint(0, 51, (B, n, n), dtype=torch.int32)
+    qn = torch.randint(0, 150, (B, n), dtype=torch.int32)
+    fl = torch.rand(B, n) > 0.3
+    bb = torch.rand(B, n, 4)
+    p = dio.pack_decoded(qa, qn, bb, fl)
+    a2, n2, f2, b2 = dio.unpack_decoded(p, n, True)
+    assert torch.equal(a2, qa) and torch.equal(n2, qn) and torch.equal(f2, fl) and torch.equal(b2, bb)
