@@ -143,8 +143,18 @@ def main():
         kinds = ["gemm_f32", "window_attn", "row", "elementwise"]
         breakdown = {kinds[i]: {"ms_per_forward": ms[i] / iters, "launches_per_forward": cnt[i] // iters,
                                 "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] > 0 else None} for i in range(4)}
-        roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+        # HBM traffic of that kernel: PMC counters cannot be read from inside this process; the per-launch figure comes from
+        # the committed rocprofv3 --pmc passes over this same command (tools/pmc_traffic.sh -> profiles/*/pmc_traffic.json)
+        traffic, traffic_src = None, None
+        for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
+            pj = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+            if os.path.exists(pj) and args.config == "vg" and B == 64:
+                tj = json.load(open(pj))
+                traffic = tj["kernels"]["gemm3_f32_kernel"]["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{rnd}/pmc_traffic.json"
+                break
+        roofline = {"bound": "mfma", "kernel": "gemm3_f32_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": gemm_avg_ms, "flops_per_launch": fl[0] / cnt[0], "launches_per_forward": cnt[0] // iters,
                     "forward_breakdown": breakdown}
         # whole-path achieved rate: graphs/s/GPU x forwards per graph x FLOPs per forward
