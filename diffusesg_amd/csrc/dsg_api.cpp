@@ -93,6 +93,9 @@ struct dsg_handle_s {
     float *ro_fap = nullptr, *ro_fa = nullptr, *ro_f2p = nullptr, *ro_gext = nullptr;
     std::vector<void *> derived_allocs;
     std::map<int, std::unique_ptr<Workspace>> ws;
+    // kernel-selection options (dsg_set_option); defaults may be overridden once by DSG_* environment variables
+    bool opt_fused_attn = true, opt_fused_mlp = true, opt_fused_readout = true, opt_fused_pe = true;
+    int opt_fused_mlp_maxc = 192;
     // per-step (scale,shift) table of the sampler (batch-uniform sigma): [cap][aff_n] and its staging buffers
     int tab_cap = 0;
     float *tab_sig = nullptr, *tab_cn = nullptr, *tab_pe = nullptr, *tab_e0 = nullptr, *tab_e1 = nullptr, *tab_aff = nullptr;
@@ -399,6 +402,11 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     h->Cin = (cfg->self_condition ? 2 : 1) * (h->Ca + 2 * h->Cn);
     h->Kp = ((h->Cin + 31) / 32) * 32;
     build_specs(h);
+    h->opt_fused_attn = env_on("DSG_FUSED_ATTN", true);
+    h->opt_fused_mlp = env_on("DSG_FUSED_MLP", true);
+    h->opt_fused_readout = env_on("DSG_FUSED_READOUT", true);
+    h->opt_fused_pe = env_on("DSG_FUSED_PE", true);
+    if (getenv("DSG_FUSED_MLP_MAXC")) h->opt_fused_mlp_maxc = atoi(getenv("DSG_FUSED_MLP_MAXC"));
     *out = h;
     return DSG_OK;
 }
@@ -674,9 +682,8 @@ void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStre
 void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
     const int B = w->B, T = b.res * b.res, C = b.C, M = B * T, Hd = h->cfg.mlp_ratio * C;
     const std::string &p = b.prefix;
-    static const bool fused_attn = env_on("DSG_FUSED_ATTN", true);
     GemmArgs g;
-    if (fused_attn && b.wqp) {
+    if (h->opt_fused_attn && b.wqp) {
         // modulate+SiLU, LN1, QKV, window attention, proj and the residual in one register-resident kernel
         WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
         P_KERN(PK_ATTN, 2.0 * (double)M * C * 4.0 * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C,
@@ -698,9 +705,7 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
         g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
         P_GEMM(g);
     }
-    static const bool fused_mlp = env_on("DSG_FUSED_MLP", true);
-    static const int fused_mlp_maxc = getenv("DSG_FUSED_MLP_MAXC") ? atoi(getenv("DSG_FUSED_MLP_MAXC")) : 192;
-    if (fused_mlp && b.w1p && C <= fused_mlp_maxc) {
+    if (h->opt_fused_mlp && b.w1p && C <= h->opt_fused_mlp_maxc) {
         // LN2 + fc1 + GELU + fc2 + residual in one kernel, hidden activations never leave the register file
         P_KERN(PK_GEMM, 4.0 * (double)M * (double)C * (double)Hd,
                launch_fused_mlp(w->x, WT(h, p + ".norm2.weight"), WT(h, p + ".norm2.bias"), b.w1p, WT(h, p + ".mlp.fc1.bias"), b.w2p,
@@ -750,9 +755,8 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
         embed_rows(h, w->c_noise, B, w->pe, w->emb0, w->emb, w->aff, s);
     }
     // input assembly + PatchEmbed (diffusesg.py:784-802, 562-577)
-    static const bool fused_pe = env_on("DSG_FUSED_PE", true);
     bool pe_done = false;
-    if (fused_pe && h->pe_wp) {
+    if (h->opt_fused_pe && h->pe_wp) {
         ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)B * T0 * E * h->Cin, "launch_fused_patch_embed96");
         pe_done = launch_fused_patch_embed96(w->in_adj, w->in_node, w->sc_adj, w->sc_node, w->has_sc, w->flags, h->pe_wp,
                                              WT(h, "patch_embed.proj.bias"), WT(h, "patch_embed.norm.weight"),
@@ -817,8 +821,7 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     }
     // final norm + read_out + heads
     const int M0 = B * T0;
-    static const bool fused_ro = env_on("DSG_FUSED_READOUT", true);
-    if (fused_ro && h->ro_fap && h->taps.empty()) {
+    if (h->opt_fused_readout && h->ro_fap && h->taps.empty()) {
         // one pass over x: LN, folded read_out+fc1, GELU, fc2, masked adjacency store; pooled LN(x) for the node head
         P_KERN(PK_GEMM, 2.0 * (double)M0 * E * (E + 32.0),
                launch_fused_readout96(w->x, WT(h, "norm.weight"), WT(h, "norm.bias"), h->ro_fap, h->ro_fa, h->ro_f2p,
@@ -936,6 +939,23 @@ extern "C" {
 size_t dsg_workspace_bytes(dsg_handle h, int32_t B) {
     if (!h || !h->finalized || B < 1) return 0;
     return sizeof(float) * per_sample_floats(h) * (size_t)B + (size_t)B * h->N + 16;
+}
+
+int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
+    if (!h || !name) return DSG_ERR_INVALID;
+    const std::string n(name);
+    if (n == "fused_attn") h->opt_fused_attn = value != 0;
+    else if (n == "fused_mlp") h->opt_fused_mlp = value != 0;
+    else if (n == "fused_mlp_maxc") h->opt_fused_mlp_maxc = value;
+    else if (n == "fused_readout") h->opt_fused_readout = value != 0;
+    else if (n == "fused_patch_embed") h->opt_fused_pe = value != 0;
+    else return fail(h, DSG_ERR_INVALID, "unknown option '%s'", name);
+    // captured graphs bake the kernel selection
+    for (auto &kv : h->ws) {
+        if (kv.second->graph) { (void)hipGraphExecDestroy(kv.second->graph); kv.second->graph = nullptr; }
+        if (kv.second->graph_uniform) { (void)hipGraphExecDestroy(kv.second->graph_uniform); kv.second->graph_uniform = nullptr; }
+    }
+    return DSG_OK;
 }
 
 int dsg_debug_tap(dsg_handle h, const char *stage, float *dst, int64_t capacity) {

@@ -23,7 +23,6 @@ struct GemmArgs {
     int act = ACT_NONE;
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
-extern int g_gemm_variant;  // dev switch for tools/gemm_bench
 
 // x <- x + fc2(GELU(fc1(LN(x)))) with fragment-major packed weights (pack_mlp_weights in dsg_api.cpp); C in {96,192}
 void launch_fused_mlp(float *x, const float *gam, const float *bet, const float *W1p, const float *b1, const float *W2p,

@@ -53,363 +53,12 @@ __device__ __forceinline__ float wave_sum(float v) {
 // =================================================================================================
 constexpr int GBM = 128, GBN = 96, GBK = 32, GLD = 36;
 
-template <bool LN, int ACT, bool RES>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * (GBM + GBN) * GLD];
-    float *As0 = lds, *Ws0 = lds + GBM * GLD;
-    float *As1 = lds + (GBM + GBN) * GLD, *Ws1 = As1 + GBM * GLD;
-
-    // XCD-aware tile order: blocks b and b+8 share an XCD (L2); give each XCD whole M-tiles and walk
-    // the N-tiles of one M-tile consecutively so the A rows are re-read from that XCD's L2.
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, seq = bid >> 3;
-    const int tm = (seq / tiles_n) * 8 + xcd, tn = seq % tiles_n;
-    if (tm >= tiles_m) return;
-    const int m0 = tm * GBM, n0 = tn * GBN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c4 = tid & 7;          // which float4 of the 32-wide k chunk this thread stages
-    const int r0 = tid >> 3;         // staging row (0..31), +32 per pass
-
-    // per-thread constants of the A prologue
-    float a_mean[4], a_rstd[4];
-    const float *a_row1[4], *a_row2[4];
-    bool a_ok[4];
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        int m = m0 + r0 + 32 * p;
-        a_ok[p] = m < g.M;
-        if (!a_ok[p]) m = g.M - 1;
-        a_row1[p] = g.A + (size_t)m * g.lda;
-        a_row2[p] = g.A2 ? g.A2 + (size_t)m * g.lda2 : nullptr;
-        if (LN) { a_mean[p] = g.ln_stats[2 * m]; a_rstd[p] = g.ln_stats[2 * m + 1]; }
-    }
-    const float *w_row[3];
-    bool w_ok[3];
-#pragma unroll
-    for (int p = 0; p < 3; p++) {
-        int n = n0 + r0 + 32 * p;
-        w_ok[p] = n < g.N;
-        if (!w_ok[p]) n = g.N - 1;
-        w_row[p] = g.W + (size_t)n * g.K;
-    }
-
-    // Staging is split in two so that the global-load latency of tile k+1 hides under the MFMAs of tile k:
-    // issue_loads() only issues the loads (raw values land in registers whenever they land);
-    // finish_store() applies LayerNorm / zero padding and writes LDS -- it runs AFTER the MFMA block.
-    f32x4 ra[4], rw[3], rg, rb;
-    auto issue_loads = [&](int k0) {
-        const int k = k0 + 4 * c4;
-        const bool second = g.A2 && k >= g.K1;
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const float *src = second ? a_row2[p] + (k - g.K1) : a_row1[p] + k;
-            ra[p] = *reinterpret_cast<const f32x4 *>(src);
-        }
-#pragma unroll
-        for (int p = 0; p < 3; p++) rw[p] = *reinterpret_cast<const f32x4 *>(w_row[p] + k);
-        if (LN) {
-            rg = *reinterpret_cast<const f32x4 *>(g.ln_g + k);
-            rb = *reinterpret_cast<const f32x4 *>(g.ln_b + k);
-        }
-    };
-    auto finish_store = [&](float *As, float *Ws) {
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            f32x4 v = ra[p];
-            if (LN) v = (v - a_mean[p]) * a_rstd[p] * rg + rb;
-            if (!a_ok[p]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(As + (r0 + 32 * p) * GLD + 4 * c4) = v;
-        }
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-            f32x4 v = rw[p];
-            if (!w_ok[p]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(Ws + (r0 + 32 * p) * GLD + 4 * c4) = v;
-        }
-    };
-
-    f32x16 acc[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
-
-    const int nk = g.K / GBK;
-    issue_loads(0);
-    finish_store(As0, Ws0);
-    __syncthreads();
-    const int lrow = lane & 31, lhalf = lane >> 5;
-    for (int kc = 0; kc < nk; kc++) {
-        const float *As = (kc & 1) ? As1 : As0, *Ws = (kc & 1) ? Ws1 : Ws0;
-        const bool more = kc + 1 < nk;
-        if (more) issue_loads((kc + 1) * GBK);
-        const float *ap = As + (wave * 32 + lrow) * GLD + 4 * lhalf;
-        const float *wp = Ws + lrow * GLD + 4 * lhalf;
-        // all 16 fragment reads of the chunk up front, then 48 back-to-back MFMAs
-        f32x4 a[4], b[4][3];
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-            a[s] = *reinterpret_cast<const f32x4 *>(ap + 8 * s);
-#pragma unroll
-            for (int j = 0; j < 3; j++) b[s][j] = *reinterpret_cast<const f32x4 *>(wp + 32 * j * GLD + 8 * s);
-        }
-#pragma unroll
-        for (int s = 0; s < 4; s++)
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int j = 0; j < 3; j++)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][t], b[s][j][t], acc[j], 0, 0, 0);
-        if (more) finish_store((kc & 1) ? As0 : As1, (kc & 1) ? Ws0 : Ws1);
-        __syncthreads();
-    }
-
-    // epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // For a fixed register the two half-waves write two full 128-B row segments.
-    const bool interior = (m0 + GBM <= g.M) && (n0 + GBN <= g.N);
-    const int mbase = m0 + wave * 32 + 4 * lhalf;
-    if (interior) {
-        float rres[3][16];
-        if (RES) {
-#pragma unroll
-            for (int j = 0; j < 3; j++)
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    rres[j][r] = g.res[(size_t)(mbase + (r & 3) + 8 * (r >> 2)) * g.ldres + n0 + 32 * j + lrow];
-        }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int n = n0 + 32 * j + lrow;
-            const float bias = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                float v = acc[j][r] + bias;
-                if (ACT == ACT_GELU) v = gelu_f(v);
-                else if (ACT == ACT_SILU) v = silu_exact(v);
-                if (RES) v += rres[j][r];
-                g.C[(size_t)m * g.ldc + n] = v;
-                if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int n = n0 + 32 * j + lrow;
-            const bool nok = n < g.N;
-            const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                if (!nok || m >= g.M) continue;
-                float v = acc[j][r] + bias;
-                if (ACT == ACT_GELU) v = gelu_f(v);
-                else if (ACT == ACT_SILU) v = silu_exact(v);
-                if (RES) v += g.res[(size_t)m * g.ldres + n];
-                g.C[(size_t)m * g.ldc + n] = v;
-                if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v;
-            }
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// GEMM v2: one 256-thread block per CU (one wave per SIMD, the whole 512-register file per wave),
-// block tile 256 x 96, wave tile 64 x 96 (6 accumulators).  The f32 MFMA is slow enough (64 cycles)
-// that instruction issue is never the limit; what costs time is a wave PARKING on a wait.  So the
-// K loop is arranged so that no wait is ever exposed:
-//   * 3 LDS buffers; chunk j+1 is written into LDS during the first quarter of chunk j from registers
-//     whose global loads were issued during chunk j-1; right after that write the loads of chunk j+2
-//     are issued into the same registers (most of a chunk ~ 4.5k cycles to land);
-//   * ONE barrier per chunk, in the middle of its MFMA stream: it separates the writes of chunk j+1
-//     (first quarter of chunk j) from their reads (end of chunk j) and the reads of chunk j-2 from the
-//     overwrite of their buffer -- every wave reaches it with >1k cycles of slack on both sides;
-//   * fragments of k-step s+1 are read from LDS while the 24 MFMAs of k-step s run.
-// -------------------------------------------------------------------------------------------------
-constexpr int G2M = 256;
-constexpr int G2BUF = (G2M + GBN) * GLD;  // floats per LDS buffer
-
-template <bool LN, int ACT, bool RES>
-__global__ __launch_bounds__(256, 1) void gemm2_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) float lds[3 * G2BUF];
-
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, seq = bid >> 3;
-    const int tm = (seq / tiles_n) * 8 + xcd, tn = seq % tiles_n;
-    if (tm >= tiles_m) return;
-    const int m0 = tm * G2M, n0 = tn * GBN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c4 = tid & 7, r0 = tid >> 3;
-
-    float a_mean[8], a_rstd[8];
-    const float *a_row1[8], *a_row2[8];
-    unsigned a_okmask = 0;
-#pragma unroll
-    for (int p = 0; p < 8; p++) {
-        int m = m0 + r0 + 32 * p;
-        if (m < g.M) a_okmask |= 1u << p; else m = g.M - 1;
-        a_row1[p] = g.A + (size_t)m * g.lda;
-        a_row2[p] = g.A2 ? g.A2 + (size_t)m * g.lda2 : nullptr;
-        if (LN) { a_mean[p] = g.ln_stats[2 * m]; a_rstd[p] = g.ln_stats[2 * m + 1]; }
-    }
-    const float *w_row[3];
-    unsigned w_okmask = 0;
-#pragma unroll
-    for (int p = 0; p < 3; p++) {
-        int n = n0 + r0 + 32 * p;
-        if (n < g.N) w_okmask |= 1u << p; else n = g.N - 1;
-        w_row[p] = g.W + (size_t)n * g.K;
-    }
-
-    f32x4 ra[8], rw[3], rg, rb;
-    auto stage_issue = [&](int kc) {
-        const int k = kc * GBK + 4 * c4;
-        const bool second = g.A2 && k >= g.K1;
-#pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const float *src = second ? a_row2[p] + (k - g.K1) : a_row1[p] + k;
-            ra[p] = *reinterpret_cast<const f32x4 *>(src);
-        }
-#pragma unroll
-        for (int p = 0; p < 3; p++) rw[p] = *reinterpret_cast<const f32x4 *>(w_row[p] + k);
-        if (LN) {
-            rg = *reinterpret_cast<const f32x4 *>(g.ln_g + k);
-            rb = *reinterpret_cast<const f32x4 *>(g.ln_b + k);
-        }
-    };
-    auto stage_write = [&](int buf) {
-        float *As = lds + buf * G2BUF, *Ws = As + G2M * GLD;
-#pragma unroll
-        for (int p = 0; p < 8; p++) {
-            f32x4 v = ra[p];
-            if (LN) v = (v - a_mean[p]) * a_rstd[p] * rg + rb;
-            if (!((a_okmask >> p) & 1)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(As + (r0 + 32 * p) * GLD + 4 * c4) = v;
-        }
-#pragma unroll
-        for (int p = 0; p < 3; p++) {
-            f32x4 v = rw[p];
-            if (!((w_okmask >> p) & 1)) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4 *>(Ws + (r0 + 32 * p) * GLD + 4 * c4) = v;
-        }
-    };
-    const int lrow = lane & 31, lhalf = lane >> 5;
-    const int a_off = (wave * 64 + lrow) * GLD + 4 * lhalf;
-    const int w_off = G2M * GLD + lrow * GLD + 4 * lhalf;
-    auto frag_read = [&](int buf, int s, f32x4 (&fa)[2], f32x4 (&fb)[3]) {
-        const float *base = lds + buf * G2BUF;
-#pragma unroll
-        for (int i = 0; i < 2; i++) fa[i] = *reinterpret_cast<const f32x4 *>(base + a_off + 32 * i * GLD + 8 * s);
-#pragma unroll
-        for (int j = 0; j < 3; j++) fb[j] = *reinterpret_cast<const f32x4 *>(base + w_off + 32 * j * GLD + 8 * s);
-    };
-
-    f32x16 acc[2][3];
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    auto mfma_step = [&](const f32x4 (&fa)[2], const f32x4 (&fb)[3]) {
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int i = 0; i < 2; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][t], fb[j][t], acc[i][j], 0, 0, 0);
-    };
-
-    const int nk = g.K / GBK;
-    stage_issue(0);
-    stage_write(0);
-    if (nk > 1) stage_issue(1);
-    __syncthreads();
-    f32x4 fa0[2], fb0[3], fa1[2], fb1[3];
-    frag_read(0, 0, fa0, fb0);
-    int cur = 0;
-    for (int kc = 0; kc < nk; kc++) {
-        const int nxt = (cur == 2) ? 0 : cur + 1;
-        // k-step 0 (+ stage chunk kc+1 into LDS, start the loads of chunk kc+2)
-        frag_read(cur, 1, fa1, fb1);
-        mfma_step(fa0, fb0);
-        if (kc + 1 < nk) stage_write(nxt);
-        if (kc + 2 < nk) stage_issue(kc + 2);
-        // k-step 1, then the one barrier of the chunk
-        frag_read(cur, 2, fa0, fb0);
-        mfma_step(fa1, fb1);
-        __syncthreads();
-        // k-step 2
-        frag_read(cur, 3, fa1, fb1);
-        mfma_step(fa0, fb0);
-        // k-step 3 (+ first fragments of the next chunk)
-        if (kc + 1 < nk) frag_read(nxt, 0, fa0, fb0);
-        mfma_step(fa1, fb1);
-        cur = nxt;
-    }
-
-    // epilogue (same C/D map as v1; wave tile rows = 64*wave + 32*i + ...)
-    const bool interior = (m0 + G2M <= g.M) && (n0 + GBN <= g.N);
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int mbase = m0 + wave * 64 + 32 * i + 4 * lhalf;
-        if (interior) {
-            float rres[3][16];
-            if (RES) {
-#pragma unroll
-                for (int j = 0; j < 3; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        rres[j][r] = g.res[(size_t)(mbase + (r & 3) + 8 * (r >> 2)) * g.ldres + n0 + 32 * j + lrow];
-            }
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const int n = n0 + 32 * j + lrow;
-                const float bias = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    float v = acc[i][j][r] + bias;
-                    if (ACT == ACT_GELU) v = gelu_f(v);
-                    else if (ACT == ACT_SILU) v = silu_exact(v);
-                    if (RES) v += rres[j][r];
-                    g.C[(size_t)m * g.ldc + n] = v;
-                    if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const int n = n0 + 32 * j + lrow;
-                const bool nok = n < g.N;
-                const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    if (!nok || m >= g.M) continue;
-                    float v = acc[i][j][r] + bias;
-                    if (ACT == ACT_GELU) v = gelu_f(v);
-                    else if (ACT == ACT_SILU) v = silu_exact(v);
-                    if (RES) v += g.res[(size_t)m * g.ldres + n];
-                    g.C[(size_t)m * g.ldc + n] = v;
-                    if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v;
-                }
-            }
-        }
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
-// GEMM v3: the 128 x 96 geometry of v1 (two blocks per CU, two waves per SIMD) with the staging work
-// INTERLEAVED into the MFMA stream.  A wave issues in order: once it has issued an MFMA it sits on the
-// next one for 64 cycles, so every non-MFMA instruction that is clumped between two MFMA blocks is
-// exposed time (measured on v1/v2: the matrix pipe was busy only 68-76 % of the kernel).  Here every
-// k-chunk is one basic block in which fragment reads, LDS writes of the NEXT chunk (from registers
-// loaded one chunk earlier) and the global loads of the chunk after that are spread across the 48 MFMAs
-// (sched_group_barrier pins the interleave).  Two register staging sets => the loop is unrolled by two.
+// Scheduling: a wave issues in order -- once it has issued an MFMA it sits on the next one for 64 cycles, so every
+// non-MFMA instruction clumped between two MFMA blocks is exposed time (a first version that staged a tile, then ran
+// 48 MFMAs, then wrote LDS kept the matrix pipe only 68 % busy).  Here every k-chunk is one basic block in which the
+// fragment reads, the LDS writes of the NEXT chunk (from registers loaded one chunk earlier) and the global loads of
+// the chunk after that are spread across the 48 MFMAs (sched_group_barrier pins the interleave).  Two register staging
+// sets => the loop is unrolled by two.  Two blocks per CU (two waves per SIMD) cover each other's barrier and epilogue.
 // -------------------------------------------------------------------------------------------------
 template <bool LN, int ACT, bool RES>
 __global__ __launch_bounds__(256, 2) void gemm3_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
@@ -585,20 +234,11 @@ __global__ __launch_bounds__(256, 2) void gemm3_f32_kernel(GemmArgs g, int tiles
     }
 }
 
-int g_gemm_variant = 3;  // dev switch (tools/gemm_bench): 1 = 128x96 plain, 2 = 256x96 three-buffer, 3 = 128x96 interleaved
-
 void launch_gemm(const GemmArgs &g, hipStream_t s) {
-    const bool v2 = g_gemm_variant == 2 && g.M >= 512;
-    const int bm = v2 ? G2M : GBM;
-    const int tiles_m = (g.M + bm - 1) / bm, tiles_n = (g.N + GBN - 1) / GBN;
+    const int tiles_m = (g.M + GBM - 1) / GBM, tiles_n = (g.N + GBN - 1) / GBN;
     const dim3 grid(((tiles_m + 7) / 8) * 8 * tiles_n), block(256);
     const bool ln = g.ln_stats != nullptr, res = g.res != nullptr;
-#define GEMM_CASE(L, A, R)                                                                                   \
-    do {                                                                                                     \
-        if (v2) hipLaunchKernelGGL((gemm2_f32_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n);      \
-        else if (g_gemm_variant == 3) hipLaunchKernelGGL((gemm3_f32_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n); \
-        else hipLaunchKernelGGL((gemm_f32_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n);          \
-    } while (0)
+#define GEMM_CASE(L, A, R) hipLaunchKernelGGL((gemm3_f32_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n)
     if (ln && g.act == ACT_NONE && !res) GEMM_CASE(true, ACT_NONE, false);
     else if (ln && g.act == ACT_GELU && !res) GEMM_CASE(true, ACT_GELU, false);
     else if (!ln && g.act == ACT_NONE && res) GEMM_CASE(false, ACT_NONE, true);

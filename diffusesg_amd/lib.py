@@ -14,7 +14,7 @@ MAX_LAYERS = 8
 EXPORTS = [
     "dsg_create", "dsg_destroy", "dsg_last_error", "dsg_version", "dsg_set_weight", "dsg_finalize_weights",
     "dsg_num_weight_keys", "dsg_weight_key", "dsg_workspace_bytes", "dsg_denoise", "dsg_precond", "dsg_sample",
-    "dsg_sigma_schedule", "dsg_debug_tap", "dsg_debug_clear_taps", "dsg_decode_bits", "dsg_profile_forward",
+    "dsg_sigma_schedule", "dsg_debug_tap", "dsg_debug_clear_taps", "dsg_decode_bits", "dsg_profile_forward", "dsg_set_option",
 ]
 
 
@@ -78,6 +78,7 @@ def load() -> C.CDLL:
     L.dsg_debug_tap.argtypes = [vp, C.c_char_p, vp, i64]
     L.dsg_debug_clear_taps.argtypes = [vp]
     L.dsg_debug_clear_taps.restype = None
+    L.dsg_set_option.argtypes = [vp, C.c_char_p, i32]
     L.dsg_profile_forward.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     L.dsg_decode_bits.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     _lib = L
@@ -143,6 +144,9 @@ class Handle:
         shp = (C.c_int64 * len(shape))(*shape)
         self.check(self.L.dsg_set_weight(self._h, key.encode(), C.c_void_p(ptr), shp, len(shape), int(is_device)),
                    f"dsg_set_weight({key})")
+
+    def set_option(self, name: str, value: int):
+        self.check(self.L.dsg_set_option(self._h, name.encode(), int(value)), f"dsg_set_option({name})")
 
     def finalize(self):
         self.check(self.L.dsg_finalize_weights(self._h), "dsg_finalize_weights")

@@ -128,6 +128,11 @@ int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_
 int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t_hat, float *noise_coef,
                        float *h_step);
 
+/* Kernel selection.  The narrow levels (C = 96 / 192) have register-resident fused kernels; each can be switched off to
+ * fall back to the generic GEMM + attention + row-kernel path (all combinations are parity-tested):
+ *   "fused_attn" (C=96 attention block), "fused_mlp", "fused_mlp_maxc" (96|192), "fused_readout", "fused_patch_embed". */
+int dsg_set_option(dsg_handle h, const char *name, int32_t value);
+
 /* Measurement: runs n_iters eager network forwards on the batch-B workspace (whatever inputs the last call left
  * there) with HIP events bracketing every kernel launch on `stream`, and accumulates per kernel class
  * (0 = MFMA GEMM, 1 = window attention, 2 = row kernels (LayerNorm/modulate/heads), 3 = elementwise):

@@ -21,7 +21,6 @@ int main(int argc, char **argv) {
         {262144, 288, 96, 1, 0, 0}, {262144, 96, 96, 0, 0, 1}, {4096, 3072, 768, 1, 1, 0}, {4096, 768, 3072, 0, 0, 1},
     };
     int only = argc > 1 ? atoi(argv[1]) : -1, iters = argc > 2 ? atoi(argv[2]) : 20;
-    if (argc > 3) g_gemm_variant = atoi(argv[3]);
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (size_t i = 0; i < shapes.size(); i++) {
