@@ -48,6 +48,9 @@ struct BlockPlan {
     float *biasT = nullptr;  // [nWt][heads][Wp][Wp]
     float *w1p = nullptr, *w2p = nullptr;  // fragment-major packed MLP weights (fused_mlp_kernel), narrow levels only
     float *wqp = nullptr, *wpp = nullptr;  // fragment-major packed qkv / proj weights (fused_attn96_kernel), C == 96 only
+    // LayerNorm folded into the consuming linear: W' = W.diag(gamma), b' = b + W.beta (the GEMM's A path then only
+    // applies (x-mean)*rstd)
+    float *qkv_wf = nullptr, *qkv_bf = nullptr, *fc1_wf = nullptr, *fc1_bf = nullptr;
 };
 
 struct Workspace {
@@ -91,6 +94,7 @@ struct dsg_handle_s {
     float *ro0_w = nullptr;     // read_out.0 transposed to [out,in]
     // folded read-out (E = 96): Fa = F1.W2.W1.W0^T packed fragment-major, fa; F2 padded+packed; node: Gext [E,128]
     float *ro_fap = nullptr, *ro_fa = nullptr, *ro_f2p = nullptr, *ro_gext = nullptr;
+    float *ro0_wf = nullptr, *ro0_bf = nullptr;  // read_out.0 ([out,in]) with the final norm's gamma/beta folded in
     std::vector<void *> derived_allocs;
     std::map<int, std::unique_ptr<Workspace>> ws;
     // kernel-selection options (dsg_set_option); defaults may be overridden once by DSG_* environment variables
@@ -336,6 +340,28 @@ int pack_mlp_weights(dsg_handle h, BlockPlan &bp) {
     return 0;
 }
 
+// W' = W.diag(gamma), b' = b + W.beta for a linear that consumes LayerNorm output (W device [N,K], gamma/beta [K])
+int fold_ln(dsg_handle h, const float *W, const float *bias, const float *gamma, const float *beta, int N, int K, float **Wf, float **bf) {
+    std::vector<float> w((size_t)N * K), b(N, 0.f), g(K), be(K);
+    HIP_TRY(h, hipMemcpy(w.data(), W, sizeof(float) * w.size(), hipMemcpyDeviceToHost));
+    if (bias) HIP_TRY(h, hipMemcpy(b.data(), bias, sizeof(float) * N, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(g.data(), gamma, sizeof(float) * K, hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(be.data(), beta, sizeof(float) * K, hipMemcpyDeviceToHost));
+    for (int n = 0; n < N; n++) {
+        double acc = b[n];
+        for (int k = 0; k < K; k++) { acc += (double)w[(size_t)n * K + k] * be[k]; w[(size_t)n * K + k] *= g[k]; }
+        b[n] = (float)acc;
+    }
+    void *p;
+    if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * w.size())) return rc;
+    *Wf = (float *)p;
+    HIP_TRY(h, hipMemcpy(p, w.data(), sizeof(float) * w.size(), hipMemcpyHostToDevice));
+    if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * N)) return rc;
+    *bf = (float *)p;
+    HIP_TRY(h, hipMemcpy(p, b.data(), sizeof(float) * N, hipMemcpyHostToDevice));
+    return 0;
+}
+
 // Fragment-major packing for fused_attn96_kernel (same two patterns as the MLP):
 //   Wqp[nt][s][lane][t]     = qkv.weight[32nt + (lane&31)][8s + 4(lane>>5) + t]      nt = {q,k,v} x head
 //   Wpp[hd][ct][g][lane][t] = proj.weight[32ct + (lane&31)][32hd + 8g + 4(lane>>5) + t]
@@ -506,6 +532,11 @@ int dsg_finalize_weights(dsg_handle h) {
                 if (int rc = build_bias_table(h, b)) return rc;
                 if (int rc = pack_mlp_weights(h, b)) return rc;
                 if (int rc = pack_attn_weights(h, b)) return rc;
+                const int C = b.C, Hd = h->cfg.mlp_ratio * C;
+                if (int rc = fold_ln(h, WT(h, b.prefix + ".attn.qkv.weight"), WT(h, b.prefix + ".attn.qkv.bias"), WT(h, b.prefix + ".norm1.weight"),
+                                     WT(h, b.prefix + ".norm1.bias"), 3 * C, C, &b.qkv_wf, &b.qkv_bf)) return rc;
+                if (int rc = fold_ln(h, WT(h, b.prefix + ".mlp.fc1.weight"), WT(h, b.prefix + ".mlp.fc1.bias"), WT(h, b.prefix + ".norm2.weight"),
+                                     WT(h, b.prefix + ".norm2.bias"), Hd, C, &b.fc1_wf, &b.fc1_bf)) return rc;
             }
     }
     // patch_embed.proj [E,Cin,1,1] -> [E,Kp] zero padded
@@ -540,6 +571,7 @@ int dsg_finalize_weights(dsg_handle h) {
         if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * dst.size())) return rc;
         h->ro0_w = (float *)p;
         HIP_TRY(h, hipMemcpy(h->ro0_w, dst.data(), sizeof(float) * dst.size(), hipMemcpyHostToDevice));
+        if (int rc = fold_ln(h, h->ro0_w, WT(h, "read_out.0.bias"), WT(h, "norm.weight"), WT(h, "norm.bias"), E, E, &h->ro0_wf, &h->ro0_bf)) return rc;
     }
     // Folded read-out (E = 96, C_adj <= 32): final-LN output -> read_out.0/1/2 -> readout_adj_mlp.fc1 is affine up to the
     // GELU, and the node head's pooled shared_rep is an affine image of the pooled LN output.  Fold in double precision.
@@ -693,8 +725,8 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
         // x <- silu(shift + x*(1+scale)) (also the shortcut), LayerNorm-1 statistics
         P_KERN(PK_ROW, 0.0, launch_mod_stats(w->x, w->aff, w->aff_ld, b.aff_off, w->stats, B, T, C, s));
         g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M;
-        g.ln_stats = w->stats; g.ln_g = WT(h, p + ".norm1.weight"); g.ln_b = WT(h, p + ".norm1.bias");
-        g.W = WT(h, p + ".attn.qkv.weight"); g.bias = WT(h, p + ".attn.qkv.bias"); g.N = 3 * C;
+        g.ln_stats = w->stats;   // gamma/beta of norm1 are folded into qkv_wf / qkv_bf
+        g.W = b.qkv_wf; g.bias = b.qkv_bf; g.N = 3 * C;
         g.C = w->qkv; g.ldc = 3 * C;
         P_GEMM(g);
         WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
@@ -715,8 +747,8 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
     P_KERN(PK_ROW, 0.0, launch_ln_stats(w->x, w->stats, M, C, s));
     g = GemmArgs();
     g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = Hd;
-    g.ln_stats = w->stats; g.ln_g = WT(h, p + ".norm2.weight"); g.ln_b = WT(h, p + ".norm2.bias");
-    g.W = WT(h, p + ".mlp.fc1.weight"); g.bias = WT(h, p + ".mlp.fc1.bias"); g.act = ACT_GELU;
+    g.ln_stats = w->stats;   // gamma/beta of norm2 are folded into fc1_wf / fc1_bf
+    g.W = b.fc1_wf; g.bias = b.fc1_bf; g.act = ACT_GELU;
     g.C = w->hid; g.ldc = Hd;
     P_GEMM(g);
     g = GemmArgs();
@@ -838,8 +870,8 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     P_KERN(PK_ROW, 0.0, launch_ln_stats(w->x, w->stats, M0, E, s));
     g = GemmArgs();
     g.A = w->x; g.lda = E; g.K1 = E; g.K = E; g.M = M0; g.N = E;
-    g.ln_stats = w->stats; g.ln_g = WT(h, "norm.weight"); g.ln_b = WT(h, "norm.bias");
-    g.W = h->ro0_w; g.bias = WT(h, "read_out.0.bias"); g.C = w->y; g.ldc = E;
+    g.ln_stats = w->stats;   // final norm's gamma/beta folded into ro0_wf / ro0_bf
+    g.W = h->ro0_wf; g.bias = h->ro0_bf; g.C = w->y; g.ldc = E;
     P_GEMM(g);
     g = GemmArgs();
     g.A = w->y; g.lda = E; g.K1 = E; g.K = E; g.M = M0; g.N = E;

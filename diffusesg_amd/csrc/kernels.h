@@ -14,8 +14,8 @@ struct GemmArgs {
     int K1 = 0;                                  // == K when A2 is null
     const float *W = nullptr;                    // [N, K] row-major (torch Linear layout)
     const float *bias = nullptr;                 // [N] or null
-    const float *ln_stats = nullptr;             // [M,2] (mean, rstd): LayerNorm fused into the A load
-    const float *ln_g = nullptr, *ln_b = nullptr;// [K]
+    const float *ln_stats = nullptr;             // [M,2] (mean, rstd): A is replaced by (A-mean)*rstd on the way in; the
+                                                 // LayerNorm's gamma/beta must already be folded into W / bias
     const float *res = nullptr; int ldres = 0;   // residual added after the activation, or null
     float *C = nullptr;  int ldc = 0;
     float *C2 = nullptr; int ldc2 = 0;           // optional second destination

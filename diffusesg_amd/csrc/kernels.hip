@@ -60,8 +60,38 @@ constexpr int GBM = 128, GBN = 96, GBK = 32, GLD = 36;
 // the chunk after that are spread across the 48 MFMAs (sched_group_barrier pins the interleave).  Two register staging
 // sets => the loop is unrolled by two.  Two blocks per CU (two waves per SIMD) cover each other's barrier and epilogue.
 // -------------------------------------------------------------------------------------------------
+#ifdef DSG_CLOCK_DIAG
+__device__ unsigned long long *g_diag_buf = nullptr;
+#endif
+// -------------------------------------------------------------------------------------------------
+// VALU budget.  The K loop carries (almost) no VALU
+// instructions.  Measured on gfx950: v_mfma_f32_32x32x2_f32 and ordinary VALU instructions of the same
+// SIMD do NOT overlap (the f32 MFMA runs at the vector rate; two dependent VALU ops per MFMA cost +10 cycles per MFMA
+// with one wave per SIMD, tools/mfma_rate.cpp) -- so every address add, select or LayerNorm multiply in the loop is
+// paid in matrix throughput.  Therefore:
+//   * operands are fetched with buffer loads: the per-thread byte offset is loop-invariant, the k offset is a scalar
+//     (SALU) -- no per-load address arithmetic; rows beyond M / N read as zero through the descriptor's range check,
+//     so there is no masking code either;
+//   * LayerNorm in the A path is one FMA per element (x*rstd - mean*rstd); gamma is folded into the weight columns and
+//     beta into the bias when the weights are packed (dsg_finalize_weights);
+//   * the epilogue uses buffer stores / loads with scalar row offsets.
+// -------------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load1(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store1(float v, rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 template <bool LN, int ACT, bool RES>
-__global__ __launch_bounds__(256, 2) void gemm3_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (GBM + GBN) * GLD];
     constexpr int BUF = (GBM + GBN) * GLD;
 
@@ -72,62 +102,59 @@ __global__ __launch_bounds__(256, 2) void gemm3_f32_kernel(GemmArgs g, int tiles
     const int m0 = tm * GBM, n0 = tn * GBN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, r0 = tid >> 3;
-    const bool interior = (m0 + GBM <= g.M) && (n0 + GBN <= g.N);
+    const int rows_m = min(GBM, g.M - m0), rows_n = min(GBN, g.N - n0);
 
-    float a_mean[4], a_rstd[4];
-    const float *a_row1[4], *a_row2[4];
-    float a_keep[4], w_keep[3];  // 1.0 for in-range rows, 0.0 for padding rows (multiplied in: branch-free)
+    // block-uniform descriptors: base = first row of the tile, range = the valid rows (out-of-range reads give 0)
+    const rsrc_t rsA1 = make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
+    const rsrc_t rsA2 = make_rsrc(g.A2 ? g.A2 + (size_t)m0 * g.lda2 : g.A, g.A2 ? (unsigned)rows_m * g.lda2 * 4u : 0u);
+    const rsrc_t rsW = make_rsrc(g.W + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 4u);
+    unsigned voffA1[4], voffA2[4], voffW[3];
+    float a_rstd[4], a_nmr[4];
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-        int m = m0 + r0 + 32 * p;
-        a_keep[p] = m < g.M ? 1.f : 0.f;
-        if (m >= g.M) m = g.M - 1;
-        a_row1[p] = g.A + (size_t)m * g.lda;
-        a_row2[p] = g.A2 ? g.A2 + (size_t)m * g.lda2 : nullptr;
-        if (LN) { a_mean[p] = g.ln_stats[2 * m]; a_rstd[p] = g.ln_stats[2 * m + 1]; }
-    }
-    const float *w_row[3];
-#pragma unroll
-    for (int p = 0; p < 3; p++) {
-        int n = n0 + r0 + 32 * p;
-        w_keep[p] = n < g.N ? 1.f : 0.f;
-        if (n >= g.N) n = g.N - 1;
-        w_row[p] = g.W + (size_t)n * g.K;
-    }
-    const int nk = g.K / GBK;
-
-    struct Stage { f32x4 a[4], w[3], g, b; };
-    auto issue = [&](Stage &st, int kc) {
-        kc = kc < nk ? kc : nk - 1;  // clamp: the tail iterations load a valid chunk they never use
-        const int k = kc * GBK + 4 * c4;
-        const bool second = g.A2 && k >= g.K1;
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const float *src = second ? a_row2[p] + (k - g.K1) : a_row1[p] + k;
-            st.a[p] = *reinterpret_cast<const f32x4 *>(src);
-        }
-#pragma unroll
-        for (int p = 0; p < 3; p++) st.w[p] = *reinterpret_cast<const f32x4 *>(w_row[p] + k);
+        const int r = r0 + 32 * p;
+        voffA1[p] = ((unsigned)r * g.lda + 4u * c4) * 4u;
+        voffA2[p] = ((unsigned)r * g.lda2 + 4u * c4) * 4u;
         if (LN) {
-            st.g = *reinterpret_cast<const f32x4 *>(g.ln_g + k);
-            st.b = *reinterpret_cast<const f32x4 *>(g.ln_b + k);
+            const int m = min(m0 + r, g.M - 1);
+            const float mean = g.ln_stats[2 * m], rstd = g.ln_stats[2 * m + 1];
+            a_rstd[p] = rstd;
+            a_nmr[p] = -mean * rstd;
         }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; p++) voffW[p] = ((unsigned)(r0 + 32 * p) * g.K + 4u * c4) * 4u;
+    const int nk = g.K / GBK;
+    const int nk1 = g.A2 ? g.K1 / GBK : nk;  // chunks served by the first source
+
+    struct Stage { f32x4 a[4], w[3]; };
+    auto issue = [&](Stage &st, int kc) {
+        kc = kc < nk ? kc : nk - 1;  // the tail iterations re-load a valid chunk they never use
+        const bool second = kc >= nk1;
+        const unsigned soffA = (unsigned)(second ? kc - nk1 : kc) * (GBK * 4u), soffW = (unsigned)kc * (GBK * 4u);
+        if (second) {
+#pragma unroll
+            for (int p = 0; p < 4; p++) st.a[p] = buf_load4(rsA2, voffA2[p], soffA);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; p++) st.a[p] = buf_load4(rsA1, voffA1[p], soffA);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) st.w[p] = buf_load4(rsW, voffW[p], soffW);
     };
     auto write = [&](const Stage &st, int buf) {
         float *As = lds + buf * BUF, *Ws = As + GBM * GLD;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             f32x4 v = st.a[p];
-            if (LN) v = (v - a_mean[p]) * a_rstd[p] * st.g + st.b;
-            if (!interior) v = v * a_keep[p];
+            if (LN) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = fmaf(v[t], a_rstd[p], a_nmr[p]);
+            }
             *reinterpret_cast<f32x4 *>(As + (r0 + 32 * p) * GLD + 4 * c4) = v;
         }
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
-            f32x4 v = st.w[p];
-            if (!interior) v = v * w_keep[p];
-            *reinterpret_cast<f32x4 *>(Ws + (r0 + 32 * p) * GLD + 4 * c4) = v;
-        }
+        for (int p = 0; p < 3; p++) *reinterpret_cast<f32x4 *>(Ws + (r0 + 32 * p) * GLD + 4 * c4) = st.w[p];
     };
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int a_off = (wave * 32 + lrow) * GLD + 4 * lhalf;
@@ -152,10 +179,13 @@ __global__ __launch_bounds__(256, 2) void gemm3_f32_kernel(GemmArgs g, int tiles
             for (int j = 0; j < 3; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t], f.b[j][t], acc[j], 0, 0, 0);
     };
 
+#ifdef DSG_CLOCK_DIAG
+    unsigned long long diag_t0 = 0, diag_r0 = 0;
+    if (tid == 0) { diag_t0 = __builtin_amdgcn_s_memtime(); diag_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
     Stage s0, s1;
     Frag f0, f1;
-    // chunk body: LDS buffer CUR holds chunk kc; ST_W holds chunk kc+1 (loaded a chunk ago), ST_L receives chunk kc+2
-#define GEMM3_CHUNK(CUR, ST_W, ST_L, KC)                                                               \
+#define GEMM4_CHUNK(CUR, ST_W, ST_L, KC)                                                               \
     do {                                                                                               \
         fread(f1, CUR, 1);                                                                             \
         mfma12(f0);                                                                                    \
@@ -165,14 +195,13 @@ __global__ __launch_bounds__(256, 2) void gemm3_f32_kernel(GemmArgs g, int tiles
         issue(ST_L, (KC) + 2);                                                                         \
         fread(f1, CUR, 3);                                                                             \
         mfma12(f0);                                                                                    \
-        mfma12(f1);                                                                                    \
-        /* pin the interleave: 1 MFMA, then up to 3 non-MFMA instructions, 48 times */               \
-        _Pragma("unroll") for (int q_ = 0; q_ < 48; q_++) {                                            \
+        _Pragma("unroll") for (int q_ = 0; q_ < 36; q_++) {                                            \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                         \
-            __builtin_amdgcn_sched_group_barrier(0x3f6, 3, 0);                                         \
+            __builtin_amdgcn_sched_group_barrier(0x3f6, 2, 0);                                         \
         }                                                                                              \
         __syncthreads();                                                                               \
         fread(f0, 1 - (CUR), 0);                                                                       \
+        mfma12(f1);                                                                                    \
     } while (0)
 
     issue(s0, 0);
@@ -182,54 +211,48 @@ __global__ __launch_bounds__(256, 2) void gemm3_f32_kernel(GemmArgs g, int tiles
     fread(f0, 0, 0);
     int kc = 0;
     for (; kc + 1 < nk; kc += 2) {
-        GEMM3_CHUNK(0, s1, s0, kc);
-        GEMM3_CHUNK(1, s0, s1, kc + 1);
+        GEMM4_CHUNK(0, s1, s0, kc);
+        GEMM4_CHUNK(1, s0, s1, kc + 1);
     }
-    if (kc < nk) GEMM3_CHUNK(0, s1, s0, kc);
-#undef GEMM3_CHUNK
+    if (kc < nk) GEMM4_CHUNK(0, s1, s0, kc);
+#undef GEMM4_CHUNK
+#ifdef DSG_CLOCK_DIAG
+    if (tid == 0 && g_diag_buf) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        g_diag_buf[2 * bid] = t1 - diag_t0;
+        g_diag_buf[2 * bid + 1] = r1 - diag_r0;
+    }
+#endif
 
-    const int mbase = m0 + wave * 32 + 4 * lhalf;
-    if (interior) {
-        float rres[3][16];
+    // epilogue: buffer stores; lane-dependent part of the address in voffset, (register, tile) part in a scalar offset.
+    // rows >= M fall outside the descriptor and are dropped; columns >= N get an out-of-range voffset.
+    const rsrc_t rsC = make_rsrc(g.C + (size_t)m0 * g.ldc, (unsigned)rows_m * g.ldc * 4u);
+    const rsrc_t rsC2 = make_rsrc(g.C2 ? g.C2 + (size_t)m0 * g.ldc2 : g.C, g.C2 ? (unsigned)rows_m * g.ldc2 * 4u : 0u);
+    const rsrc_t rsR = make_rsrc(RES ? g.res + (size_t)m0 * g.ldres : g.C, RES ? (unsigned)rows_m * g.ldres * 4u : 0u);
+    const unsigned rowl = (unsigned)(wave * 32 + 4 * lhalf);
+    const unsigned OOB = 0x7fffffffu;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int n = n0 + 32 * j + lrow;
+        const bool nok = n < g.N;
+        const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+        const unsigned vC = nok ? (rowl * g.ldc + (unsigned)n) * 4u : OOB;
+        const unsigned vC2 = nok ? (rowl * g.ldc2 + (unsigned)n) * 4u : OOB;
+        const unsigned vR = nok ? (rowl * g.ldres + (unsigned)n) * 4u : OOB;
+        float rres[16];
         if (RES) {
 #pragma unroll
-            for (int j = 0; j < 3; j++)
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    rres[j][r] = g.res[(size_t)(mbase + (r & 3) + 8 * (r >> 2)) * g.ldres + n0 + 32 * j + lrow];
+            for (int r = 0; r < 16; r++) rres[r] = buf_load1(rsR, vR, (unsigned)((r & 3) + 8 * (r >> 2)) * g.ldres * 4u);
         }
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int n = n0 + 32 * j + lrow;
-            const float bias = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                float v = acc[j][r] + bias;
-                if (ACT == ACT_GELU) v = gelu_f(v);
-                else if (ACT == ACT_SILU) v = silu_exact(v);
-                if (RES) v += rres[j][r];
-                g.C[(size_t)m * g.ldc + n] = v;
-                if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int n = n0 + 32 * j + lrow;
-            const bool nok = n < g.N;
-            const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mbase + (r & 3) + 8 * (r >> 2);
-                if (!nok || m >= g.M) continue;
-                float v = acc[j][r] + bias;
-                if (ACT == ACT_GELU) v = gelu_f(v);
-                else if (ACT == ACT_SILU) v = silu_exact(v);
-                if (RES) v += g.res[(size_t)m * g.ldres + n];
-                g.C[(size_t)m * g.ldc + n] = v;
-                if (g.C2) g.C2[(size_t)m * g.ldc2 + n] = v;
-            }
+        for (int r = 0; r < 16; r++) {
+            const unsigned rr = (unsigned)((r & 3) + 8 * (r >> 2));
+            float v = acc[j][r] + bias;
+            if (ACT == ACT_GELU) v = gelu_f(v);
+            else if (ACT == ACT_SILU) v = silu_exact(v);
+            if (RES) v += rres[r];
+            buf_store1(v, rsC, vC, rr * g.ldc * 4u);
+            if (g.C2) buf_store1(v, rsC2, vC2, rr * g.ldc2 * 4u);
         }
     }
 }
@@ -238,7 +261,7 @@ void launch_gemm(const GemmArgs &g, hipStream_t s) {
     const int tiles_m = (g.M + GBM - 1) / GBM, tiles_n = (g.N + GBN - 1) / GBN;
     const dim3 grid(((tiles_m + 7) / 8) * 8 * tiles_n), block(256);
     const bool ln = g.ln_stats != nullptr, res = g.res != nullptr;
-#define GEMM_CASE(L, A, R) hipLaunchKernelGGL((gemm3_f32_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n)
+#define GEMM_CASE(L, A, R) hipLaunchKernelGGL((gemm4_f32_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n)
     if (ln && g.act == ACT_NONE && !res) GEMM_CASE(true, ACT_NONE, false);
     else if (ln && g.act == ACT_GELU && !res) GEMM_CASE(true, ACT_GELU, false);
     else if (!ln && g.act == ACT_NONE && res) GEMM_CASE(false, ACT_NONE, true);
