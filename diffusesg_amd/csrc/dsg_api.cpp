@@ -99,7 +99,7 @@ struct dsg_handle_s {
     std::map<int, std::unique_ptr<Workspace>> ws;
     // kernel-selection options (dsg_set_option); defaults may be overridden once by DSG_* environment variables
     bool opt_fused_attn = true, opt_fused_mlp = true, opt_fused_readout = true, opt_fused_pe = true;
-    int opt_fused_mlp_maxc = 192;
+    int opt_fused_mlp_maxc = 96;   // at C = 192 the plain GEMM pair is faster than the one-wave-per-SIMD fused kernel
     // per-step (scale,shift) table of the sampler (batch-uniform sigma): [cap][aff_n] and its staging buffers
     int tab_cap = 0;
     float *tab_sig = nullptr, *tab_cn = nullptr, *tab_pe = nullptr, *tab_e0 = nullptr, *tab_e1 = nullptr, *tab_aff = nullptr;

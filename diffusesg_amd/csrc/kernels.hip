@@ -15,14 +15,20 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define LN_EPS 1e-5f
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+// The f32 MFMA shares the SIMD's vector ALUs, so every VALU instruction in an MFMA kernel costs matrix throughput
+// (tools/mfma_rate.cpp).  An IEEE division expands to ~10 VALU ops and precise expf to ~8: inside the network kernels
+// reciprocals, rsqrt and exp use the 1-ulp hardware instructions (v_rcp_f32 / v_rsq_f32 / v_exp_f32); the resulting
+// relative error (~1e-7) is three orders of magnitude below the fp32 parity bar.  The sampler's scalar algebra keeps
+// correctly rounded IEEE operations (precond/churn/euler/heun kernels below).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float silu_exact(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
 // exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|eps| <= 1.5e-7), evaluated so that the
 // negative tail has no cancellation: 1+erf(z) = poly*exp(-z^2) for z<0, 2 - poly*exp(-z^2) otherwise.  Measured max
 // abs error vs an fp64 GELU over [-12,12]: 4.2e-7 -- the same as the fp32 erff formula (4.5e-7); ~3x fewer VALU ops.
 __device__ __forceinline__ float gelu_f(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float t = fast_rcp(fmaf(0.3275911f, z, 1.0f));
     float p = fmaf(t, 1.061405429f, -1.453152027f);
     p = fmaf(t, p, 1.421413741f);
     p = fmaf(t, p, -0.284496736f);
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float
 #pragma unroll
         for (int t = 0; t < 4; t++) { const float d = xn[s][t] - mean; var = fmaf(d, d, var); }
     var += __shfl_xor(var, 32, 64);
-    const float rstd = 1.0f / sqrtf(var * (1.0f / C) + LN_EPS);
+    const float rstd = fast_rsqrt(var * (1.0f / C) + LN_EPS);
 #pragma unroll
     for (int s = 0; s < S; s++) {
         const f32x4 gg = *reinterpret_cast<const f32x4 *>(gam + 8 * s + 4 * lhalf);
@@ -330,11 +336,13 @@ __global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float
 #pragma unroll
         for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
 
-    const f32x4 *w1 = reinterpret_cast<const f32x4 *>(W1p) + lane;  // [NT][S][64] float4
-    const f32x4 *w2 = reinterpret_cast<const f32x4 *>(W2p) + lane;  // [NT][CT][4][64] float4
+    // packed weights via buffer loads: lane offset in the VGPR, tile / k-step offset scalar -> no address VALU
+    const rsrc_t rs1 = make_rsrc(W1p, (unsigned)(4 * C * C) * 4u);  // [NT][S][64] float4
+    const rsrc_t rs2 = make_rsrc(W2p, (unsigned)(4 * C * C) * 4u);  // [NT][CT][4][64] float4
+    const unsigned lane16 = (unsigned)lane * 16u;
     f32x4 w1f[S], w2f[CT * 4];
 #pragma unroll
-    for (int s = 0; s < S; s++) w1f[s] = w1[(size_t)s * 64];
+    for (int s = 0; s < S; s++) w1f[s] = buf_load4(rs1, lane16, (unsigned)s * 1024u);
     for (int nt = 0; nt < NT; nt++) {
         f32x16 hacc;
 #pragma unroll
@@ -344,14 +352,14 @@ __global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float
             for (int t = 0; t < 4; t++) hacc[4 * g + t] = bv[t];
         }
 #pragma unroll
-        for (int q = 0; q < CT * 4; q++) w2f[q] = w2[((size_t)nt * CT * 4 + q) * 64];
+        for (int q = 0; q < CT * 4; q++) w2f[q] = buf_load4(rs2, lane16, (unsigned)(nt * CT * 4 + q) * 1024u);
 #pragma unroll
         for (int s = 0; s < S; s++)
 #pragma unroll
             for (int t = 0; t < 4; t++) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(w1f[s][t], xn[s][t], hacc, 0, 0, 0);
         if (nt + 1 < NT) {
 #pragma unroll
-            for (int s = 0; s < S; s++) w1f[s] = w1[((size_t)(nt + 1) * S + s) * 64];
+            for (int s = 0; s < S; s++) w1f[s] = buf_load4(rs1, lane16, (unsigned)((nt + 1) * S + s) * 1024u);
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) hacc[r] = gelu_f(hacc[r]);
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
 #pragma unroll
             for (int t = 0; t < 4; t++) { const float d = xn[mb][s][t] - mean; var = fmaf(d, d, var); }
         var += __shfl_xor(var, 32, 64);
-        const float rstd = 1.0f / sqrtf(var * (1.0f / C) + LN_EPS);
+        const float rstd = fast_rsqrt(var * (1.0f / C) + LN_EPS);
 #pragma unroll
         for (int s = 0; s < S; s++) {
             const f32x4 gg = *reinterpret_cast<const f32x4 *>(gam + 8 * s + 4 * lhalf);
@@ -472,8 +480,9 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
 #pragma unroll
             for (int r = 0; r < 16; r++) yacc[mb][ct][r] = 0.f;
 
-    const f32x4 *wq = reinterpret_cast<const f32x4 *>(Wqp) + lane;  // [9 tiles][S][64] float4
-    const f32x4 *wp = reinterpret_cast<const f32x4 *>(Wpp) + lane;  // [3 heads][CT][4][64] float4
+    const rsrc_t rsq = make_rsrc(Wqp, (unsigned)(3 * C * C) * 4u);  // [9 tiles][S][64] float4
+    const rsrc_t rsp = make_rsrc(Wpp, (unsigned)(C * C) * 4u);      // [3 heads][CT][4][64] float4
+    const unsigned lane16 = (unsigned)lane * 16u;
     const float qscale = 0.17677669529663687f;                      // 32^-0.5
 
     for (int hd = 0; hd < HEADS; hd++) {
@@ -484,7 +493,7 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
             const int nt = which * 3 + hd;
             f32x4 wf[S];
 #pragma unroll
-            for (int s = 0; s < S; s++) wf[s] = wq[((size_t)nt * S + s) * 64];
+            for (int s = 0; s < S; s++) wf[s] = buf_load4(rsq, lane16, (unsigned)(nt * S + s) * 1024u);
             f32x16 init;
 #pragma unroll
             for (int gq = 0; gq < 4; gq++) {
@@ -511,7 +520,7 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
             const int nt = 6 + hd;
             f32x4 wf[S];
 #pragma unroll
-            for (int s = 0; s < S; s++) wf[s] = wq[((size_t)nt * S + s) * 64];
+            for (int s = 0; s < S; s++) wf[s] = buf_load4(rsq, lane16, (unsigned)(nt * S + s) * 1024u);
             const float bv = bqkv[32 * nt + lrow];
 #pragma unroll
             for (int mb = 0; mb < MB; mb++) {
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
         }
         f32x4 pf[CT * 4];
 #pragma unroll
-        for (int q = 0; q < CT * 4; q++) pf[q] = wp[((size_t)hd * CT * 4 + q) * 64];
+        for (int q = 0; q < CT * 4; q++) pf[q] = buf_load4(rsp, lane16, (unsigned)(hd * CT * 4 + q) * 1024u);
         const float *bias_h = bias_w + (size_t)hd * Wp * Wp;
 #pragma unroll
         for (int qb = 0; qb < MB; qb++) {
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
                     sum += e;
                 }
             sum += __shfl_xor(sum, 32, 64);
-            const float inv = 1.0f / sum;
+            const float inv = fast_rcp(sum);
             f32x16 ot;
 #pragma unroll
             for (int r = 0; r < 16; r++) ot[r] = 0.f;
@@ -646,7 +655,7 @@ __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__
 #pragma unroll
         for (int t = 0; t < 4; t++) { const float d = xn[s][t] - mean; var = fmaf(d, d, var); }
     var += __shfl_xor(var, 32, 64);
-    const float rstd = 1.0f / sqrtf(var * (1.0f / C) + LN_EPS);
+    const float rstd = fast_rsqrt(var * (1.0f / C) + LN_EPS);
 #pragma unroll
     for (int s = 0; s < S; s++) {
         const f32x4 gg = *reinterpret_cast<const f32x4 *>(gam + 8 * s + 4 * lhalf);
@@ -816,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void fused_patch_embed96_kernel(const float
 #pragma unroll
         for (int r = 0; r < 16; r++) { const float d = acc[nt][r] - mean; var = fmaf(d, d, var); }
     var += __shfl_xor(var, 32, 64);
-    const float rstd = 1.0f / sqrtf(var * (1.0f / C) + LN_EPS);
+    const float rstd = fast_rsqrt(var * (1.0f / C) + LN_EPS);
     if (!ok) return;
     const float *scale = aff + (size_t)b * aff_ld + aff_off + 4 * lhalf, *shift = scale + C;
     float *xr = x + (size_t)m * C + 4 * lhalf;
@@ -942,7 +951,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
                 sum += e;
             }
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.0f / sum;
+        const float inv = fast_rcp(sum);
 
         f32x16 oacc;
 #pragma unroll
@@ -1016,7 +1025,7 @@ __global__ __launch_bounds__(256) void mod_stats_kernel(float *x, const float *a
 #pragma unroll
             for (int t = 0; t < 4; t++) { const float d = v[i][t] - mean; var += d * d; }
     var = wave_sum(var) / (float)C;
-    if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = 1.0f / sqrtf(var + LN_EPS); }
+    if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = fast_rsqrt(var + LN_EPS); }
 }
 void launch_mod_stats(float *x, const float *aff, int aff_ld, int aff_off, float *stats, int B, int T, int C, hipStream_t s) {
     const int M = B * T;
@@ -1045,7 +1054,7 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float *x, float *st
 #pragma unroll
             for (int t = 0; t < 4; t++) { const float d = v[i][t] - mean; var += d * d; }
     var = wave_sum(var) / (float)C;
-    if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = 1.0f / sqrtf(var + LN_EPS); }
+    if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = fast_rsqrt(var + LN_EPS); }
 }
 void launch_ln_stats(const float *x, float *stats, int M, int C, hipStream_t s) {
     hipLaunchKernelGGL(ln_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, stats, C, M);
@@ -1075,7 +1084,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float *x, const float
         const int c = lane + 64 * i;
         if (c < C) { const float d = v[i] - mean; var += d * d; }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)C + LN_EPS);
+    const float rstd = fast_rsqrt(wave_sum(var) / (float)C + LN_EPS);
 #pragma unroll
     for (int i = 0; i < ROW_MAXV; i++) {
         const int c = lane + 64 * i;
@@ -1121,7 +1130,7 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float *x, const flo
         if (lane + 64 * q < D4)
 #pragma unroll
             for (int tt = 0; tt < 4; tt++) { const float d = v[q][tt] - mean; var += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)(4 * C) + LN_EPS);
+    const float rstd = fast_rsqrt(wave_sum(var) / (float)(4 * C) + LN_EPS);
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g), *b4 = reinterpret_cast<const f32x4 *>(bta);
     f32x4 *yr = reinterpret_cast<f32x4 *>(y + (size_t)m * 4 * C);
 #pragma unroll
@@ -1160,7 +1169,7 @@ __global__ __launch_bounds__(256) void breakup_ln_kernel(const float *y, const f
         if (lane + 64 * q < D4)
 #pragma unroll
             for (int tt = 0; tt < 4; tt++) { const float d = v[q][tt] - mean; var += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)D + LN_EPS);
+    const float rstd = fast_rsqrt(wave_sum(var) / (float)D + LN_EPS);
     // per-chunk statistics of the normalised row (a float4 never straddles a chunk: Co % 4 == 0)
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1194,7 +1203,7 @@ __global__ __launch_bounds__(256) void breakup_ln_kernel(const float *y, const f
     }
     float crstd[4];
 #pragma unroll
-    for (int p = 0; p < 4; p++) crstd[p] = 1.0f / sqrtf(wave_sum(cvar[p]) / (float)Co + LN_EPS);
+    for (int p = 0; p < 4; p++) crstd[p] = fast_rsqrt(wave_sum(cvar[p]) / (float)Co + LN_EPS);
     const f32x4 *pg4 = reinterpret_cast<const f32x4 *>(pg), *pb4 = reinterpret_cast<const f32x4 *>(pb);
 #pragma unroll
     for (int q = 0; q < ROW_MAXV4; q++) {
