@@ -428,6 +428,7 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     h->Cin = (cfg->self_condition ? 2 : 1) * (h->Ca + 2 * h->Cn);
     h->Kp = ((h->Cin + 31) / 32) * 32;
     build_specs(h);
+    if (!gelu_table()) { delete h; return DSG_ERR_HIP; }
     h->opt_fused_attn = env_on("DSG_FUSED_ATTN", true);
     h->opt_fused_mlp = env_on("DSG_FUSED_MLP", true);
     h->opt_fused_readout = env_on("DSG_FUSED_READOUT", true);

@@ -23,6 +23,8 @@ struct GemmArgs {
     int act = ACT_NONE;
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
+// device table of the fused MLP's table-driven GELU; must be called once (outside any stream capture) before the first launch
+const float *gelu_table();
 
 // x <- x + fc2(GELU(fc1(LN(x)))) with fragment-major packed weights (pack_mlp_weights in dsg_api.cpp); C in {96,192}
 void launch_fused_mlp(float *x, const float *gam, const float *bet, const float *W1p, const float *b1, const float *W2p,

@@ -7,6 +7,7 @@
 #include "kernels.h"
 
 #include <math.h>
+#include <cmath>
 
 namespace dsg {
 
@@ -35,6 +36,23 @@ __device__ __forceinline__ float gelu_f(float x) {
     p = fmaf(t, p, 0.254829592f);
     const float pe = p * t * __expf(-z * z);
     return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
+}
+
+// Table-driven GELU for the MFMA kernels (10 VALU + one ds_read_b128 instead of 14 VALU + 2 transcendentals).
+// Phi(x) on [-6,6], nodes every 1/64 with (Phi, phi, -x*phi/2): second-order Taylor from the nearest node,
+// |error| <= (1/128)^3/6 * max|Phi'''| = 3.2e-8; outside the range Phi is clamped (gelu error < 6e-9).
+constexpr int GELU_NODES = 769;                 // 12 * 64 + 1
+constexpr int GELU_TAB_FLOATS = GELU_NODES * 4; // float4 per node (16-B aligned LDS reads)
+__device__ __forceinline__ float gelu_lut(float x, const float *tab /* LDS */) {
+    const float t = __builtin_amdgcn_fmed3f(x + 6.0f, 0.0f, 12.0f);
+    const float r = __builtin_rintf(t * 64.0f);
+    const float d = fmaf(r, -0.015625f, t);
+    const f32x4 c = *reinterpret_cast<const f32x4 *>(tab + ((int)r << 2));
+    return x * fmaf(d, fmaf(d, c[2], c[1]), c[0]);
+}
+__device__ __forceinline__ void gelu_tab_to_lds(float *dst, const float *__restrict__ src, int tid, int nthreads) {
+    for (int i = tid; i < GELU_NODES; i += nthreads)
+        reinterpret_cast<f32x4 *>(dst)[i] = reinterpret_cast<const f32x4 *>(src)[i];
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -263,6 +281,24 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     }
 }
 
+static float *g_gelu_tab_dev = nullptr;
+const float *gelu_table() {
+    if (!g_gelu_tab_dev) {
+        static float host_tab[GELU_TAB_FLOATS];
+        for (int i = 0; i < GELU_NODES; i++) {
+            const double x = -6.0 + i / 64.0;
+            const double phi = std::exp(-0.5 * x * x) / std::sqrt(2.0 * M_PI);
+            host_tab[4 * i + 0] = (float)(0.5 * std::erfc(-x / std::sqrt(2.0)));
+            host_tab[4 * i + 1] = (float)phi;
+            host_tab[4 * i + 2] = (float)(-0.5 * x * phi);
+            host_tab[4 * i + 3] = 0.f;
+        }
+        if (hipMalloc((void **)&g_gelu_tab_dev, sizeof(host_tab)) != hipSuccess) return nullptr;
+        if (hipMemcpy(g_gelu_tab_dev, host_tab, sizeof(host_tab), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    }
+    return g_gelu_tab_dev;
+}
+
 void launch_gemm(const GemmArgs &g, hipStream_t s) {
     const int tiles_m = (g.M + GBM - 1) / GBM, tiles_n = (g.N + GBN - 1) / GBN;
     const dim3 grid(((tiles_m + 7) / 8) * 8 * tiles_n), block(256);
@@ -299,8 +335,11 @@ template <int C>
 __global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float *__restrict__ x, const float *__restrict__ gam,
                                                            const float *__restrict__ bet, const float *__restrict__ W1p,
                                                            const float *__restrict__ b1, const float *__restrict__ W2p,
-                                                           const float *__restrict__ b2, int M) {
+                                                           const float *__restrict__ b2, const float *__restrict__ gelu_tab, int M) {
     constexpr int S = C / 8, CT = C / 32, NT = 4 * C / 32;
+    __shared__ __attribute__((aligned(16))) float gtab[GELU_TAB_FLOATS];
+    gelu_tab_to_lds(gtab, gelu_tab, threadIdx.x, 256);
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int m = (blockIdx.x * 4 + wave) * 32 + lrow;
@@ -362,7 +401,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float
             for (int s = 0; s < S; s++) w1f[s] = buf_load4(rs1, lane16, (unsigned)((nt + 1) * S + s) * 1024u);
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) hacc[r] = gelu_f(hacc[r]);
+        for (int r = 0; r < 16; r++) hacc[r] = gelu_lut(hacc[r], gtab);
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
@@ -391,8 +430,8 @@ __global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float
 void launch_fused_mlp(float *x, const float *gam, const float *bet, const float *W1p, const float *b1, const float *W2p,
                       const float *b2, int M, int C, hipStream_t s) {
     const dim3 grid((M + 127) / 128), block(256);
-    if (C == 96) hipLaunchKernelGGL(fused_mlp_kernel<96>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, M);
-    else if (C == 192) hipLaunchKernelGGL(fused_mlp_kernel<192>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, M);
+    if (C == 96) hipLaunchKernelGGL(fused_mlp_kernel<96>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, g_gelu_tab_dev, M);
+    else if (C == 192) hipLaunchKernelGGL(fused_mlp_kernel<192>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, g_gelu_tab_dev, M);
 }
 
 // =================================================================================================

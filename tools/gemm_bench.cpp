@@ -26,6 +26,7 @@ int main(int argc, char **argv) {
     };
     int only = argc > 1 ? atoi(argv[1]) : -1, iters = argc > 2 ? atoi(argv[2]) : 20;
     hipStream_t s; CK(hipStreamCreate(&s));
+    if (!gelu_table()) return 1;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (size_t i = 0; i < shapes.size(); i++) {
         if (only >= 0 && (int)i != only) continue;
