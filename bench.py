@@ -134,15 +134,21 @@ def main():
         # roofline of the dominant kernel (gemm_f32_kernel): HIP events around every launch of eager forwards on the
         # state the timed run left in the workspace (random-data clocks, not zeros)
         h = net.model._ensure_handle()
-        ms, cnt, fl = (C.c_double * 4)(), (C.c_int64 * 4)(), (C.c_double * 4)()
+        ms, cnt, fl = (C.c_double * 5)(), (C.c_int64 * 5)(), (C.c_double * 5)()
+        gemm_ms = C.c_double(0.0)
         iters = 3
         st_ptr = torch.cuda.current_stream(dev).cuda_stream
-        h.check(h.L.dsg_profile_forward(h.raw, B, iters, ms, cnt, fl, C.c_void_p(st_ptr)), "dsg_profile_forward")
+        h.check(h.L.dsg_profile_forward(h.raw, B, iters, ms, cnt, fl, C.byref(gemm_ms), C.c_void_p(st_ptr)), "dsg_profile_forward")
+        # avg_launch_ms: HIP events recorded on the launch stream around every GEMM launch (eager forwards).
+        # avg_launch_ms_inkernel: first-block-start -> last-block-end stamps (100 MHz constant clock) of back-to-back
+        # launches; consecutive kernels overlap at their tails, so this one reads a few % high.
         gemm_avg_ms = ms[0] / cnt[0]
+        gemm_avg_ms_inkernel = gemm_ms.value / cnt[0]
         achieved = (fl[0] / cnt[0]) / (gemm_avg_ms * 1e-3) / 1e12
-        kinds = ["gemm_f32", "window_attn", "row", "elementwise"]
+        kinds = ["gemm_f32", "window_attn", "row", "elementwise", "fused_blocks"]
+        # per-class times are event brackets (each includes dispatch latency); class 0 also has the in-kernel figure
         breakdown = {kinds[i]: {"ms_per_forward": ms[i] / iters, "launches_per_forward": cnt[i] // iters,
-                                "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] > 0 else None} for i in range(4)}
+                                "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] > 0 else None} for i in range(5)}
         # HBM traffic of that kernel: PMC counters cannot be read from inside this process; the per-launch figure comes from
         # the committed rocprofv3 --pmc passes over this same command (tools/pmc_traffic.sh -> profiles/*/pmc_traffic.json)
         traffic, traffic_src = None, None
@@ -150,12 +156,13 @@ def main():
             pj = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
             if os.path.exists(pj) and args.config == "vg" and B == 64:
                 tj = json.load(open(pj))
-                traffic = tj["kernels"]["gemm3_f32_kernel"]["hbm_bytes_per_launch"]
+                traffic = tj["kernels"]["gemm4_f32_kernel"]["hbm_bytes_per_launch"]
                 traffic_src = f"profiles/{rnd}/pmc_traffic.json"
                 break
-        roofline = {"bound": "mfma", "kernel": "gemm3_f32_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+        roofline = {"bound": "mfma", "kernel": "gemm4_f32_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                    "avg_launch_ms": gemm_avg_ms, "flops_per_launch": fl[0] / cnt[0], "launches_per_forward": cnt[0] // iters,
+                    "avg_launch_ms": gemm_avg_ms, "avg_launch_ms_inkernel": gemm_avg_ms_inkernel,
+                    "flops_per_launch": fl[0] / cnt[0], "launches_per_forward": cnt[0] // iters,
                     "forward_breakdown": breakdown}
         # whole-path achieved rate: graphs/s/GPU x forwards per graph x FLOPs per forward
         roofline["whole_path_tflops"] = nfe * B * f_fwd / elapsed / 1e12

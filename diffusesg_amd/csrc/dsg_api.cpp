@@ -106,12 +106,16 @@ struct dsg_handle_s {
     std::vector<Tap> taps;
     dsg_sample_stats last_stats{};
     // per-kernel-class timing (dsg_profile_forward): HIP events bracketing every launch on the launch stream
-    bool prof_on = false;
+    bool prof_on = false;          // HIP-event brackets around every launch
+    bool prof_stamps = false;      // in-kernel start/end stamps of the GEMM launches (no events: launches stay back to back)
     std::vector<hipEvent_t> prof_events;
     size_t prof_used = 0;
     std::vector<int> prof_kind;
     std::vector<double> prof_flops;
     std::vector<std::string> prof_tag;
+    // in-kernel stamps of the dominant kernel (GEMM): one {start,end} pair per launch
+    unsigned long long *prof_gemm = nullptr;
+    int prof_gemm_cap = 0, prof_gemm_used = 0;
 };
 
 namespace {
@@ -132,7 +136,7 @@ int fail(dsg_handle h, int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(h, DSG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-enum ProfKind { PK_GEMM = 0, PK_ATTN = 1, PK_ROW = 2, PK_ELEM = 3, PK_COUNT = 4 };
+enum ProfKind { PK_GEMM = 0, PK_ATTN = 1, PK_ROW = 2, PK_ELEM = 3, PK_FUSED = 4, PK_COUNT = 5 };
 
 struct ProfScope {
     dsg_handle h; hipStream_t s;
@@ -443,6 +447,7 @@ void dsg_destroy(dsg_handle h) {
     for (auto &kv : h->w) (void)hipFree(kv.second.p);
     for (void *p : h->derived_allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+    if (h->prof_gemm) (void)hipFree(h->prof_gemm);
     for (float *q : {h->tab_sig, h->tab_cn, h->tab_pe, h->tab_e0, h->tab_e1, h->tab_aff}) if (q) (void)hipFree(q);
     for (auto &kv : h->ws) {
         if (kv.second->graph) (void)hipGraphExecDestroy(kv.second->graph);
@@ -707,7 +712,8 @@ void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStre
             (void)hipMemcpyAsync(t.dst, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, s);
 }
 
-#define P_GEMM(g) do { char tg_[96]; if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm M=%d N=%d K=%d ln=%d act=%d res=%d", (g).M, (g).N, (g).K, (g).ln_stats != nullptr, (g).act, (g).res != nullptr); \
+#define P_GEMM(g) do { char tg_[96]; if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) (g).prof = h->prof_gemm + 2 * (h->prof_gemm_used++); else (g).prof = nullptr; \
+    if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm M=%d N=%d K=%d ln=%d act=%d res=%d", (g).M, (g).N, (g).K, (g).ln_stats != nullptr, (g).act, (g).res != nullptr); \
     ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)(g).M * (double)(g).N * (double)(g).K, tg_); launch_gemm((g), s); } while (0)
 #define P_KERN(kind, flops, call) do { ProfScope ps_(h, s, (kind), (flops), #call); call; } while (0)
 
@@ -719,7 +725,7 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
     if (h->opt_fused_attn && b.wqp) {
         // modulate+SiLU, LN1, QKV, window attention, proj and the residual in one register-resident kernel
         WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
-        P_KERN(PK_ATTN, 2.0 * (double)M * C * 4.0 * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C,
+        P_KERN(PK_FUSED, 2.0 * (double)M * C * 4.0 * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C,
                launch_fused_attn96(w->x, w->aff, w->aff_ld, b.aff_off, WT(h, p + ".norm1.weight"), WT(h, p + ".norm1.bias"), b.wqp,
                                    WT(h, p + ".attn.qkv.bias"), b.biasT, b.wpp, WT(h, p + ".attn.proj.bias"), B, wg, s));
     } else {
@@ -740,7 +746,7 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
     }
     if (h->opt_fused_mlp && b.w1p && C <= h->opt_fused_mlp_maxc) {
         // LN2 + fc1 + GELU + fc2 + residual in one kernel, hidden activations never leave the register file
-        P_KERN(PK_GEMM, 4.0 * (double)M * (double)C * (double)Hd,
+        P_KERN(PK_FUSED, 4.0 * (double)M * (double)C * (double)Hd,
                launch_fused_mlp(w->x, WT(h, p + ".norm2.weight"), WT(h, p + ".norm2.bias"), b.w1p, WT(h, p + ".mlp.fc1.bias"), b.w2p,
                                 WT(h, p + ".mlp.fc2.bias"), M, C, s));
         return;
@@ -790,7 +796,7 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     // input assembly + PatchEmbed (diffusesg.py:784-802, 562-577)
     bool pe_done = false;
     if (h->opt_fused_pe && h->pe_wp) {
-        ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)B * T0 * E * h->Cin, "launch_fused_patch_embed96");
+        ProfScope ps_(h, s, PK_FUSED, 2.0 * (double)B * T0 * E * h->Cin, "launch_fused_patch_embed96");
         pe_done = launch_fused_patch_embed96(w->in_adj, w->in_node, w->sc_adj, w->sc_node, w->has_sc, w->flags, h->pe_wp,
                                              WT(h, "patch_embed.proj.bias"), WT(h, "patch_embed.norm.weight"),
                                              WT(h, "patch_embed.norm.bias"), w->aff, w->aff_ld, h->pe_aff_off, w->x, B, N, h->Ca, h->Cn,
@@ -856,7 +862,7 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     const int M0 = B * T0;
     if (h->opt_fused_readout && h->ro_fap && h->taps.empty()) {
         // one pass over x: LN, folded read_out+fc1, GELU, fc2, masked adjacency store; pooled LN(x) for the node head
-        P_KERN(PK_GEMM, 2.0 * (double)M0 * E * (E + 32.0),
+        P_KERN(PK_FUSED, 2.0 * (double)M0 * E * (E + 32.0),
                launch_fused_readout96(w->x, WT(h, "norm.weight"), WT(h, "norm.bias"), h->ro_fap, h->ro_fa, h->ro_f2p,
                                       WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, w->pool_ext, B, N, h->Ca, s));
         g = GemmArgs();
@@ -1177,7 +1183,7 @@ int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_
 }
 
 int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_kind, int64_t *launches_by_kind,
-                        double *flops_by_kind, void *stream) {
+                        double *flops_by_kind, double *gemm_inkernel_ms_out, void *stream) {
     if (int rc = check_ready(h, B)) return rc;
     if (!ms_by_kind || !launches_by_kind || !flops_by_kind || n_iters < 1) return fail(h, DSG_ERR_INVALID, "null argument");
     auto it = h->ws.find(B);
@@ -1185,6 +1191,26 @@ int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_
     hipStream_t s = (hipStream_t)stream;
     Workspace *w = it->second.get();
     for (int k = 0; k < PK_COUNT; k++) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; flops_by_kind[k] = 0.0; }
+    if (!h->prof_gemm) {
+        h->prof_gemm_cap = 512;
+        HIP_TRY(h, hipMalloc((void **)&h->prof_gemm, sizeof(unsigned long long) * 2 * h->prof_gemm_cap));
+    }
+    std::vector<unsigned long long> stamps(2 * h->prof_gemm_cap);
+    double gemm_inkernel_ms = 0.0;
+    // pass A: in-kernel stamps only -- the launches run back to back exactly as in the sampler loop
+    for (int iter = 0; iter < n_iters; iter++) {
+        for (int i = 0; i < h->prof_gemm_cap; i++) { stamps[2 * i] = ~0ull; stamps[2 * i + 1] = 0ull; }
+        HIP_TRY(h, hipMemcpyAsync(h->prof_gemm, stamps.data(), sizeof(unsigned long long) * stamps.size(), hipMemcpyHostToDevice, s));
+        h->prof_gemm_used = 0;
+        h->prof_stamps = true;
+        forward_fixed(h, w, s);
+        h->prof_stamps = false;
+        HIP_TRY(h, hipStreamSynchronize(s));
+        HIP_TRY(h, hipMemcpy(stamps.data(), h->prof_gemm, sizeof(unsigned long long) * stamps.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < h->prof_gemm_used; i++)
+            if (stamps[2 * i + 1] > stamps[2 * i]) gemm_inkernel_ms += (double)(stamps[2 * i + 1] - stamps[2 * i]) * 1e-5;  // 100 MHz ticks
+    }
+    // pass B: HIP-event brackets around every launch (per-class breakdown; each bracket includes dispatch latency)
     for (int iter = 0; iter < n_iters; iter++) {
         h->prof_on = true; h->prof_used = 0; h->prof_kind.clear(); h->prof_flops.clear(); h->prof_tag.clear();
         forward_fixed(h, w, s);
@@ -1202,6 +1228,7 @@ int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_
             flops_by_kind[h->prof_kind[i]] += h->prof_flops[i];
         }
     }
+    if (gemm_inkernel_ms_out) *gemm_inkernel_ms_out = gemm_inkernel_ms;
     return DSG_OK;
 }
 

@@ -21,6 +21,7 @@ struct GemmArgs {
     float *C2 = nullptr; int ldc2 = 0;           // optional second destination
     int M = 0, N = 0, K = 0;                     // K % 32 == 0
     int act = ACT_NONE;
+    unsigned long long *prof = nullptr;          // measurement mode: {min block start, max block end} in 100 MHz ticks
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
 // device table of the fused MLP's table-driven GELU; must be called once (outside any stream capture) before the first launch

@@ -127,6 +127,9 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c4 = tid & 7, r0 = tid >> 3;
     const int rows_m = min(GBM, g.M - m0), rows_n = min(GBN, g.N - n0);
+    // measurement mode (dsg_profile_forward): first-block-start / last-block-end on the 100 MHz constant clock
+    unsigned long long prof_t0 = 0;
+    if (g.prof && tid == 0) prof_t0 = __builtin_amdgcn_s_memrealtime();
 
     // block-uniform descriptors: base = first row of the tile, range = the valid rows (out-of-range reads give 0)
     const rsrc_t rsA1 = make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
@@ -278,6 +281,11 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
             buf_store1(v, rsC, vC, rr * g.ldc * 4u);
             if (g.C2) buf_store1(v, rsC2, vC2, rr * g.ldc2 * 4u);
         }
+    }
+    if (g.prof && tid == 0) {
+        __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have been issued and acknowledged
+        atomicMin(g.prof, prof_t0);
+        atomicMax(g.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
     }
 }
 

@@ -79,7 +79,7 @@ def load() -> C.CDLL:
     L.dsg_debug_clear_taps.argtypes = [vp]
     L.dsg_debug_clear_taps.restype = None
     L.dsg_set_option.argtypes = [vp, C.c_char_p, i32]
-    L.dsg_profile_forward.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    L.dsg_profile_forward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     L.dsg_decode_bits.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     _lib = L
     return L

@@ -135,10 +135,14 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value);
 
 /* Measurement: runs n_iters eager network forwards on the batch-B workspace (whatever inputs the last call left
  * there) with HIP events bracketing every kernel launch on `stream`, and accumulates per kernel class
- * (0 = MFMA GEMM, 1 = window attention, 2 = row kernels (LayerNorm/modulate/heads), 3 = elementwise):
- * total milliseconds, number of launches, algorithmic FLOPs (2*M*N*K; 4*T*W*C for attention).  Arrays of length 4. */
+ * (0 = MFMA GEMM, 1 = window attention, 2 = row kernels (LayerNorm/modulate/heads), 3 = elementwise, 4 = fused
+ * narrow-level blocks (attention / MLP / read-out / patch-embed)):
+ * total milliseconds, number of launches, algorithmic FLOPs (2*M*N*K; 4*T*W*C for attention).  Arrays of length 5.
+ * An event bracket around a single launch includes ~10-15 us of dispatch latency that back-to-back (graph) launches do
+ * not pay, so for the dominant kernel (class 0) the kernel also stamps first-block-start / last-block-end on the GPU's
+ * 100 MHz constant clock: *gemm_inkernel_ms receives the sum of those in-kernel durations (agrees with rocprofv3). */
 int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_kind, int64_t *launches_by_kind,
-                        double *flops_by_kind, void *stream);
+                        double *flops_by_kind, double *gemm_inkernel_ms, void *stream);
 
 /* Debug: copy the named stage's activation (e.g. "down0.block0") of the next dsg_denoise call to
  * `dst` (device, capacity in floats).  Token-major [B, T, C]. */
