@@ -25,6 +25,9 @@
 using namespace dsg;
 
 #define NOISE_EMB 512
+// attention scores are formed directly in the exp2 domain: q carries head_dim^-0.5 * log2(e), the bias/mask tables log2(e)
+static const double kLog2e = 1.4426950408889634;
+static const double kQScale = 0.17677669529663687 * 1.4426950408889634;
 
 namespace {
 
@@ -48,6 +51,7 @@ struct BlockPlan {
     float *biasT = nullptr;  // [nWt][heads][Wp][Wp]
     float *w1p = nullptr, *w2p = nullptr;  // fragment-major packed MLP weights (fused_mlp_kernel), narrow levels only
     float *wqp = nullptr, *wpp = nullptr;  // fragment-major packed qkv / proj weights (fused_attn96_kernel), C == 96 only
+    float *bqkv_s = nullptr;               // qkv bias with the q part pre-scaled (fused_attn96_kernel)
     // LayerNorm folded into the consuming linear: W' = W.diag(gamma), b' = b + W.beta (the GEMM's A path then only
     // applies (x-mean)*rstd)
     float *qkv_wf = nullptr, *qkv_bf = nullptr, *fc1_wf = nullptr, *fc1_bf = nullptr;
@@ -300,6 +304,7 @@ int build_bias_table(dsg_handle h, BlockPlan &bp) {
                         const int idx = (qi - ki + ws - 1) * (2 * ws - 1) + (qj - kj + ws - 1);
                         v = table[(size_t)idx * heads + hd];
                         if (shift > 0 && region[q] != region[key]) v += -100.0f;
+                        v = (float)((double)v * kLog2e);
                     }
                     o[(size_t)key * Wp + q] = v;
                 }
@@ -345,7 +350,8 @@ int pack_mlp_weights(dsg_handle h, BlockPlan &bp) {
 }
 
 // W' = W.diag(gamma), b' = b + W.beta for a linear that consumes LayerNorm output (W device [N,K], gamma/beta [K])
-int fold_ln(dsg_handle h, const float *W, const float *bias, const float *gamma, const float *beta, int N, int K, float **Wf, float **bf) {
+int fold_ln(dsg_handle h, const float *W, const float *bias, const float *gamma, const float *beta, int N, int K, float **Wf, float **bf,
+            int scaled_rows = 0, double row_scale = 1.0) {
     std::vector<float> w((size_t)N * K), b(N, 0.f), g(K), be(K);
     HIP_TRY(h, hipMemcpy(w.data(), W, sizeof(float) * w.size(), hipMemcpyDeviceToHost));
     if (bias) HIP_TRY(h, hipMemcpy(b.data(), bias, sizeof(float) * N, hipMemcpyDeviceToHost));
@@ -353,8 +359,9 @@ int fold_ln(dsg_handle h, const float *W, const float *bias, const float *gamma,
     HIP_TRY(h, hipMemcpy(be.data(), beta, sizeof(float) * K, hipMemcpyDeviceToHost));
     for (int n = 0; n < N; n++) {
         double acc = b[n];
-        for (int k = 0; k < K; k++) { acc += (double)w[(size_t)n * K + k] * be[k]; w[(size_t)n * K + k] *= g[k]; }
-        b[n] = (float)acc;
+        const double rs = n < scaled_rows ? row_scale : 1.0;
+        for (int k = 0; k < K; k++) { acc += (double)w[(size_t)n * K + k] * be[k]; w[(size_t)n * K + k] = (float)((double)w[(size_t)n * K + k] * g[k] * rs); }
+        b[n] = (float)(acc * rs);
     }
     void *p;
     if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * w.size())) return rc;
@@ -380,7 +387,11 @@ int pack_attn_weights(dsg_handle h, BlockPlan &bp) {
         for (int s = 0; s < S; s++)
             for (int lane = 0; lane < 64; lane++)
                 for (int t = 0; t < 4; t++)
-                    p1[(((size_t)nt * S + s) * 64 + lane) * 4 + t] = wq[(size_t)(32 * nt + (lane & 31)) * C + 8 * s + 4 * (lane >> 5) + t];
+                    p1[(((size_t)nt * S + s) * 64 + lane) * 4 + t] =
+                        (float)((double)wq[(size_t)(32 * nt + (lane & 31)) * C + 8 * s + 4 * (lane >> 5) + t] * (nt < HD ? kQScale : 1.0));
+    std::vector<float> bq((size_t)3 * C);
+    HIP_TRY(h, hipMemcpy(bq.data(), WT(h, bp.prefix + ".attn.qkv.bias"), sizeof(float) * bq.size(), hipMemcpyDeviceToHost));
+    for (int n = 0; n < C; n++) bq[n] = (float)((double)bq[n] * kQScale);
     for (int hd = 0; hd < HD; hd++)
         for (int ct = 0; ct < CT; ct++)
             for (int g = 0; g < 4; g++)
@@ -395,6 +406,9 @@ int pack_attn_weights(dsg_handle h, BlockPlan &bp) {
     if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * p2.size())) return rc;
     bp.wpp = (float *)p;
     HIP_TRY(h, hipMemcpy(bp.wpp, p2.data(), sizeof(float) * p2.size(), hipMemcpyHostToDevice));
+    if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * bq.size())) return rc;
+    bp.bqkv_s = (float *)p;
+    HIP_TRY(h, hipMemcpy(bp.bqkv_s, bq.data(), sizeof(float) * bq.size(), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -426,7 +440,7 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
         const int C = h->E << l, res = h->N >> l, ws = level_window(*cfg, l);
         if (cfg->num_heads[l] * 32 != C) return bad("head_dim must be 32");
         if (res % ws != 0) return bad("resolution not divisible by window");
-        if (ws * ws > 128) return bad("window larger than 128 tokens");
+        if (!(ws == 2 || ws == 4 || ws == 5 || ws == 8 || ws == 10)) return bad("window side must be one of 2, 4, 5, 8, 10");
         if (C > 1536 || (l < h->L - 1 && 4 * C > 1536)) return bad("row wider than 1536 channels");
     }
     h->Cin = (cfg->self_condition ? 2 : 1) * (h->Ca + 2 * h->Cn);
@@ -540,7 +554,7 @@ int dsg_finalize_weights(dsg_handle h) {
                 if (int rc = pack_attn_weights(h, b)) return rc;
                 const int C = b.C, Hd = h->cfg.mlp_ratio * C;
                 if (int rc = fold_ln(h, WT(h, b.prefix + ".attn.qkv.weight"), WT(h, b.prefix + ".attn.qkv.bias"), WT(h, b.prefix + ".norm1.weight"),
-                                     WT(h, b.prefix + ".norm1.bias"), 3 * C, C, &b.qkv_wf, &b.qkv_bf)) return rc;
+                                     WT(h, b.prefix + ".norm1.bias"), 3 * C, C, &b.qkv_wf, &b.qkv_bf, C, kQScale)) return rc;
                 if (int rc = fold_ln(h, WT(h, b.prefix + ".mlp.fc1.weight"), WT(h, b.prefix + ".mlp.fc1.bias"), WT(h, b.prefix + ".norm2.weight"),
                                      WT(h, b.prefix + ".norm2.bias"), Hd, C, &b.fc1_wf, &b.fc1_bf)) return rc;
             }
@@ -727,7 +741,7 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
         WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
         P_KERN(PK_FUSED, 2.0 * (double)M * C * 4.0 * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C,
                launch_fused_attn96(w->x, w->aff, w->aff_ld, b.aff_off, WT(h, p + ".norm1.weight"), WT(h, p + ".norm1.bias"), b.wqp,
-                                   WT(h, p + ".attn.qkv.bias"), b.biasT, b.wpp, WT(h, p + ".attn.proj.bias"), B, wg, s));
+                                   b.bqkv_s, b.biasT, b.wpp, WT(h, p + ".attn.proj.bias"), B, wg, s));
     } else {
         // x <- silu(shift + x*(1+scale)) (also the shortcut), LayerNorm-1 statistics
         P_KERN(PK_ROW, 0.0, launch_mod_stats(w->x, w->aff, w->aff_ld, b.aff_off, w->stats, B, T, C, s));

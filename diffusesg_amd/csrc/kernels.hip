@@ -530,7 +530,6 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
     const rsrc_t rsq = make_rsrc(Wqp, (unsigned)(3 * C * C) * 4u);  // [9 tiles][S][64] float4
     const rsrc_t rsp = make_rsrc(Wpp, (unsigned)(C * C) * 4u);      // [3 heads][CT][4][64] float4
     const unsigned lane16 = (unsigned)lane * 16u;
-    const float qscale = 0.17677669529663687f;                      // 32^-0.5
 
     for (int hd = 0; hd < HEADS; hd++) {
         f32x16 qa[MB], ka[MB], va[MB];
@@ -555,11 +554,8 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
                 for (int s = 0; s < S; s++)
 #pragma unroll
                     for (int t = 0; t < 4; t++) a = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s][t], xn[mb][s][t], a, 0, 0, 0);
-                if (which == 0) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) a[r] *= qscale;
-                    qa[mb] = a;
-                } else ka[mb] = a;
+                if (which == 0) qa[mb] = a;  // q weights/bias are pre-scaled by 32^-0.5 * log2(e) at pack time
+                else ka[mb] = a;
             }
         }
         // V tile, unswapped: lane = head dim, register = key; bias per lane
@@ -608,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
             for (int kb = 0; kb < MB; kb++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const float e = __expf(sa[kb][r] - mx);
+                    const float e = __builtin_amdgcn_exp2f(sa[kb][r] - mx);  // scores carry the log2(e) factor
                     sa[kb][r] = e;
                     sum += e;
                 }
@@ -923,62 +919,81 @@ bool launch_fused_patch_embed96(const float *adj, const float *node, const float
 // Relative-position bias and the shifted-window mask (-100) come pre-combined and transposed
 // (key-major) from a dense table built at weight-load time; padded key slots hold -1e30.
 // =================================================================================================
-template <int KT>  // number of 32-token tiles per window (Wp = 32*KT >= ws*ws)
+template <int KT, int WS>  // KT 32-token tiles per window (Wp = 32*KT >= WS*WS); WS compile-time: cheap index math
 __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ biasT,
                                                           float *__restrict__ out, int B, WinGeom g, int n_units) {
-    __shared__ int tok_lds[4][128];
+    constexpr int Wp = 32 * KT, Wt = WS * WS, VLD = 36;
+    __shared__ __attribute__((aligned(16))) float v_lds[4][Wp * VLD];  // V rows of the window, one slab per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lrow = lane & 31, lhalf = lane >> 5;
     int unit = blockIdx.x * 4 + wave;
     const bool active = unit < n_units;
-    if (!active) unit = n_units - 1;  // keep the wave alive for the block barrier; its stores are skipped
-    const int heads = g.heads, C = g.C, res = g.res, ws = g.ws;
-    const int nwr = res / ws, nW = nwr * nwr, Wt = ws * ws, T = res * res;
-    constexpr int Wp = 32 * KT;
+    if (!active) unit = n_units - 1;
+    const int heads = g.heads, C = g.C, res = g.res;
+    const int nwr = res / WS, nW = nwr * nwr, T = res * res;
     const int head = unit % heads;
     const int bw = unit / heads;
     const int w = bw % nW, b = bw / nW;
     const int wi = w / nwr, wj = w % nwr;
-    int *tok = tok_lds[wave];
-    for (int p = lane; p < Wp; p += 64) {
-        int t = 0;
-        if (p < Wt) {
-            const int si = wi * ws + p / ws, sj = wj * ws + p % ws;  // coordinates in the rolled image
-            t = ((si + g.shift) % res) * res + ((sj + g.shift) % res);
-        }
-        tok[p] = t;
-    }
-    __syncthreads();
-    const float scale = 0.17677669529663687f;  // 32^-0.5 (head_dim is 32 at every level)
-    const size_t base = (size_t)b * T * 3 * C;
-    const int lrow = lane & 31, lhalf = lane >> 5;
-    const float *bias_base = biasT + ((size_t)(g.shift > 0 ? w : 0) * heads + head) * Wp * Wp;
 
-    // K fragments for all key tiles: lane (key = 32*kt + lrow) holds d = 8s + 4*lhalf + {0..3}
-    f32x4 kf[KT][4];
+    // this lane's token per 32-position block (byte offset of its qkv row); padded positions read token 0
+    unsigned rowoff[KT];
+    int tokr[KT];
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) {
-        const float *kp = qkv + base + (size_t)tok[32 * kt + lrow] * 3 * C + C + head * 32 + 4 * lhalf;
-#pragma unroll
-        for (int s = 0; s < 4; s++) kf[kt][s] = *reinterpret_cast<const f32x4 *>(kp + 8 * s);
+        const int p = 32 * kt + lrow;
+        int t = 0;
+        if (p < Wt) {
+            const int si = wi * WS + p / WS, sj = wj * WS + p % WS;
+            int ti = si + g.shift, tj = sj + g.shift;
+            if (ti >= res) ti -= res;
+            if (tj >= res) tj -= res;
+            t = ti * res + tj;
+        }
+        tokr[kt] = t;
+        rowoff[kt] = (unsigned)t * (unsigned)(3 * C) * 4u + 16u * lhalf;
     }
+    // descriptors: the sample's qkv rows / the (window-type, head) bias tile / the sample's output rows
+    const rsrc_t rsQ = make_rsrc(qkv + (size_t)b * T * 3 * C, (unsigned)T * 3u * C * 4u);
+    const rsrc_t rsB = make_rsrc(biasT + ((size_t)(g.shift > 0 ? w : 0) * heads + head) * Wp * Wp, (unsigned)(Wp * Wp) * 4u);
+    const rsrc_t rsO = make_rsrc(out + (size_t)b * T * C, active ? (unsigned)T * C * 4u : 0u);
+    const unsigned hoff = (unsigned)head * 128u;
 
+    // K fragments (lane = key), V rows -> LDS (for the transposed read lane = head dim)
+    f32x4 kf[KT][4];
+    float *vl = v_lds[wave];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+#pragma unroll
+        for (int s = 0; s < 4; s++) kf[kt][s] = buf_load4(rsQ, rowoff[kt], (unsigned)C * 4u + hoff + 32u * s);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const f32x4 v = buf_load4(rsQ, rowoff[kt], (unsigned)C * 8u + hoff + 32u * s);
+            *reinterpret_cast<f32x4 *>(vl + (32 * kt + lrow) * VLD + 8 * s + 4 * lhalf) = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // V fragments: lane (d, half) holds V[key = 32kt + (r&3) + 8(r>>2) + 4*half][d]
+    float vf[KT][16];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) vf[kt][r] = vl[(32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * VLD + lrow];
+
+    const unsigned boff = (unsigned)(4 * lhalf * Wp + lrow) * 4u;
+#pragma unroll
     for (int qt = 0; qt < KT; qt++) {
         if (32 * qt >= Wt) break;
-        const float *qp = qkv + base + (size_t)tok[32 * qt + lrow] * 3 * C + head * 32 + 4 * lhalf;
         f32x4 qf[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const f32x4 *>(qp + 8 * s) * scale;
-
+        for (int s = 0; s < 4; s++) qf[s] = buf_load4(rsQ, rowoff[qt], hoff + 32u * s);  // pre-scaled by 32^-0.5 * log2(e)
         f32x16 sacc[KT];
         float mx = -3.0e38f;
 #pragma unroll
         for (int kt = 0; kt < KT; kt++) {
-            // start from the (bias + mask)^T tile: element [key][query]
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                sacc[kt][r] = bias_base[(size_t)key * Wp + 32 * qt + lrow];
-            }
+            for (int r = 0; r < 16; r++)
+                sacc[kt][r] = buf_load1(rsB, boff, (unsigned)((32 * kt + (r & 3) + 8 * (r >> 2)) * Wp + 32 * qt) * 4u);
 #pragma unroll
             for (int s = 0; s < 4; s++)
 #pragma unroll
@@ -987,36 +1002,34 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
 #pragma unroll
             for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // the other half-wave holds the remaining keys of this query
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; kt++)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const float e = __expf(sacc[kt][r] - mx);
+                const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - mx);  // scores carry the log2(e) factor
                 sacc[kt][r] = e;
                 sum += e;
             }
         sum += __shfl_xor(sum, 32, 64);
         const float inv = fast_rcp(sum);
-
         f32x16 oacc;
 #pragma unroll
         for (int r = 0; r < 16; r++) oacc[r] = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; kt++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                // k-step r of key tile kt: half 0 contributes key (r&3)+8(r>>2), half 1 that key + 4
-                const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-                const float v = qkv[base + (size_t)tok[key] * 3 * C + 2 * C + head * 32 + lrow];
-                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r] * inv, v, oacc, 0, 0, 0);
-            }
-        // O tile: col = d = lrow, row = query 32*qt + (r&3) + 8(r>>2) + 4*lhalf
+            for (int r = 0; r < 16; r++)
+                oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r] * inv, vf[kt][r], oacc, 0, 0, 0);
+        // O tile: col = d = lrow, row = query 32*qt + (r&3) + 8(r>>2) + 4*half; the row's token comes from the lane that owns it
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int q = 32 * qt + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-            if (q < Wt && active) out[((size_t)b * T + tok[q]) * C + head * 32 + lrow] = oacc[r];
+            const int q0 = (r & 3) + 8 * (r >> 2);
+            const int ta = __builtin_amdgcn_readlane(tokr[qt], q0), tb = __builtin_amdgcn_readlane(tokr[qt], q0 + 4);
+            const int q = 32 * qt + q0 + 4 * lhalf;
+            const unsigned voff = (q < Wt) ? ((unsigned)(lhalf ? tb : ta) * (unsigned)C + (unsigned)lrow) * 4u : 0x7fffffffu;
+            buf_store1(oacc[r], rsO, voff, hoff);
         }
     }
 }
@@ -1024,15 +1037,17 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
 void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s) {
     const int nW = (g.res / g.ws) * (g.res / g.ws);
     const int n_units = B * nW * g.heads;
-    const int Wt = g.ws * g.ws;
-    const int KT = (Wt + 31) / 32;
     const dim3 grid((n_units + 3) / 4), block(256);
-    switch (KT) {
-        case 1: hipLaunchKernelGGL(window_attn_kernel<1>, grid, block, 0, s, qkv, biasT, out, B, g, n_units); break;
-        case 2: hipLaunchKernelGGL(window_attn_kernel<2>, grid, block, 0, s, qkv, biasT, out, B, g, n_units); break;
-        case 3: hipLaunchKernelGGL(window_attn_kernel<3>, grid, block, 0, s, qkv, biasT, out, B, g, n_units); break;
-        default: hipLaunchKernelGGL(window_attn_kernel<4>, grid, block, 0, s, qkv, biasT, out, B, g, n_units); break;
+#define WA(KT_, WS_) hipLaunchKernelGGL((window_attn_kernel<KT_, WS_>), grid, block, 0, s, qkv, biasT, out, B, g, n_units)
+    switch (g.ws) {
+        case 2: WA(1, 2); break;
+        case 4: WA(1, 4); break;
+        case 5: WA(1, 5); break;
+        case 8: WA(2, 8); break;
+        case 10: WA(4, 10); break;
+        default: break;  // dsg_create only admits these window sizes
     }
+#undef WA
 }
 
 // =================================================================================================
