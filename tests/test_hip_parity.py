@@ -310,3 +310,54 @@ def test_repeatability_and_graph_equivalence():
         outs.append((oa, on))
     assert rel_err(outs[0][0].numpy(), outs[1][0].numpy()) < 1e-5 and rel_err(outs[0][0].numpy(), outs[2][0].numpy()) < 1e-5
     assert rel_err(outs[0][1].numpy(), outs[2][1].numpy()) < 1e-5
+
+
+def test_vg_full_size_short_trajectory_vs_oracle():
+    """headline configuration (VG-bits, N=64, 30 valid nodes): 6 Heun+churn steps, replayed noise and coins, vs the oracle.
+    (Shorter schedules are degenerate -- sigma falls from 80 to 0.002 in 2-3 steps, states reach 1e3 and a 3e-6
+    per-forward difference is amplified to 2e-4..9e-4 -- so 6 steps is the smallest meaningful check; measured 2e-5.)"""
+    from oracle.oracle import Oracle
+    cfg = Y.CONFIGS["vg"]()
+    T_ = 6
+    flags, ia, inn, na, nn, cv = Y.sampler_case(cfg, T_, 2, [30, 30], 17, "vg/smp3")
+    coins = np.array([1, 0, 1, 1, 0, 0, 1, 0, 1, 1, 0], np.uint8)
+    orc = Oracle(cfg, W.synth_state_dict(cfg, 0))
+    ra, rn = orc.sample(flags, ia, inn, na, nn, coins, num_steps=T_)
+    smp = make_sampler(T_)
+    oa, on = smp.sample(net_for("vg"), T(flags), init_adjs=T(ia), init_nodes=T(inn), churn_noise=(T(na), T(nn)), coins=coins,
+                        num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    assert_close(oa.numpy(), ra, 1e-4, "vg 6-step adj")
+    assert_close(on.numpy(), rn, 1e-4, "vg 6-step node")
+    assert smp.last_stats["net_forwards"] == 11 + 6
+
+
+def test_vg_batch_independence_and_masking():
+    """size-independent properties at the bench's batch (B=64): a sample's output does not depend on its batch
+    neighbours (samples never interact), padded rows/columns are exactly zero, and the result is finite"""
+    cfg = Y.CONFIGS["vg"]()
+    n = cfg.max_node_num
+    flags, adj, node, sc_adj, sc_node = Y.case_inputs(cfg, 64, [30, 64, 1, 17], 19, "vg/b64")
+    c_noise = np.linspace(-1.4, 1.1, 64).astype(np.float32)
+    net = net_for("vg").model
+    oa, on = net(T(adj), T(node), T(flags), T(c_noise), T(sc_adj), T(sc_node))
+    assert torch.isfinite(oa).all() and torch.isfinite(on).all()
+    sel = [5, 6, 63]
+    oa2, on2 = net(T(adj[sel]), T(node[sel]), T(flags[sel]), T(c_noise[sel]), T(sc_adj[sel]), T(sc_node[sel]))
+    assert_close(oa2.cpu().numpy(), oa[sel].cpu().numpy(), 2e-6, "batch independence adj")
+    assert_close(on2.cpu().numpy(), on[sel].cpu().numpy(), 2e-6, "batch independence node")
+    f = torch.from_numpy(flags).cuda()
+    assert torch.all(on[~f] == 0)
+    assert torch.all(oa.permute(0, 2, 3, 1)[~f] == 0) and torch.all(oa.permute(0, 3, 2, 1)[~f] == 0)
+
+
+def test_vg_known_answer_full_batch():
+    """sanity-check mode at the bench's shape (B=64, T=20, device-drawn noise): the loop must land on GT"""
+    cfg = Y.CONFIGS["vg"]()
+    n = cfg.max_node_num
+    flags = W.synth_flags(64, n, 30)
+    gt_adj = W.mask_adj(np.sign(W.normal(23, "vg/gt_a", (64, cfg.c_adj, n, n))).astype(np.float32), flags)
+    gt_node = W.mask_node(np.sign(W.normal(23, "vg/gt_n", (64, n, cfg.c_node))).astype(np.float32), flags)
+    smp = make_sampler(20)
+    oa, on = smp.sample(net_for("vg"), T(flags), sanity_check_gt_adjs=T(gt_adj), sanity_check_gt_nodes=T(gt_node),
+                        num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj, seed=5)
+    assert np.abs(oa.numpy() - gt_adj).max() < 1e-5 and np.abs(on.numpy() - gt_node).max() < 1e-5
