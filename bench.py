@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--config", default="vg", choices=["vg", "coco", "tiny"])
     ap.add_argument("--valid", type=int, default=None, help="valid nodes per graph (VG: 30)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="f32 (default, the BASELINE headline): exact fp32 MFMA; bf16: opt-in bf16-MFMA GEMMs with fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
@@ -91,6 +93,8 @@ def main():
     valid = args.valid if args.valid is not None else {"vg": 30, "coco": 20, "tiny": 8}[args.config]
     sd = weights.synth_state_dict(cfg, 0)
     net = build_network(cfg, sd, device=dev)
+    if args.precision == "bf16":
+        net.model._ensure_handle().set_option("gemm_bf16", 1)
     T, B = args.num_steps, args.batch
     smp = NodeAdjEDMSamplerHip(num_steps=T, solver="heun", S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
                                clip_samples=True, clip_samples_min=-1.0, clip_samples_max=1.0, clip_samples_scope="x_0",
@@ -173,7 +177,8 @@ def main():
         line = {
             "metric": "scene-graphs/sec", "value": value, "unit": "scene-graphs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "bf16 GEMM operands, f32 accumulate/activations", "data": "synthetic",
             "config": {"workload": f"{args.config}-bits N={n} valid={valid} C_adj={cfg.c_adj} C_node={cfg.c_node} "
                                    f"T={T} heun S_churn=40 self_cond={int(cfg.self_condition)}",
                        "batch_per_gpu": B, "global_batch": world * B, "num_steps": T,

@@ -103,6 +103,9 @@ struct dsg_handle_s {
     std::map<int, std::unique_ptr<Workspace>> ws;
     // kernel-selection options (dsg_set_option); defaults may be overridden once by DSG_* environment variables
     bool opt_fused_attn = true, opt_fused_mlp = true, opt_fused_readout = true, opt_fused_pe = true;
+    bool opt_gemm_bf16 = false;                                   // bf16-MFMA GEMMs (fp32 accumulate), opt-in precision mode
+    std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
+    std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
     int opt_fused_mlp_maxc = 96;   // at C = 192 the plain GEMM pair is faster than the one-wave-per-SIMD fused kernel
     // per-step (scale,shift) table of the sampler (batch-uniform sigma): [cap][aff_n] and its staging buffers
     int tab_cap = 0;
@@ -412,6 +415,24 @@ int pack_attn_weights(dsg_handle h, BlockPlan &bp) {
     return 0;
 }
 
+const void *bf16_of(dsg_handle h, const float *W) {
+    if (!h->opt_gemm_bf16) return nullptr;
+    auto it = h->w_bf16.find(W);
+    return it == h->w_bf16.end() ? nullptr : it->second;
+}
+
+int ensure_bf16_weights(dsg_handle h) {
+    for (auto &pw : h->gemm_weights) {
+        if (h->w_bf16.count(pw.first)) continue;
+        void *q;
+        HIP_TRY(h, hipMalloc(&q, pw.second * 2));
+        launch_f32_to_bf16(pw.first, q, pw.second, nullptr);
+        h->w_bf16[pw.first] = q;
+    }
+    HIP_TRY(h, hipDeviceSynchronize());
+    return 0;
+}
+
 bool env_on(const char *name, bool dflt) {
     const char *v = getenv(name);
     return v ? (v[0] != '0') : dflt;
@@ -452,6 +473,7 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     h->opt_fused_readout = env_on("DSG_FUSED_READOUT", true);
     h->opt_fused_pe = env_on("DSG_FUSED_PE", true);
     if (getenv("DSG_FUSED_MLP_MAXC")) h->opt_fused_mlp_maxc = atoi(getenv("DSG_FUSED_MLP_MAXC"));
+    h->opt_gemm_bf16 = env_on("DSG_GEMM_BF16", false);
     *out = h;
     return DSG_OK;
 }
@@ -459,6 +481,7 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
 void dsg_destroy(dsg_handle h) {
     if (!h) return;
     for (auto &kv : h->w) (void)hipFree(kv.second.p);
+    for (auto &kv : h->w_bf16) (void)hipFree(kv.second);
     for (void *p : h->derived_allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     if (h->prof_gemm) (void)hipFree(h->prof_gemm);
@@ -653,6 +676,23 @@ int dsg_finalize_weights(dsg_handle h) {
         if (kv.second->graph) { (void)hipGraphExecDestroy(kv.second->graph); kv.second->graph = nullptr; }
         if (kv.second->graph_uniform) { (void)hipGraphExecDestroy(kv.second->graph_uniform); kv.second->graph_uniform = nullptr; }
     }
+    // bf16 copies (opt-in mode): drop stale ones, list every GEMM weight, rebuild if the mode is on
+    for (auto &kv : h->w_bf16) (void)hipFree(kv.second);
+    h->w_bf16.clear();
+    h->gemm_weights.clear();
+    for (auto &kv : h->w)
+        if (kv.second.p && kv.second.shape.size() >= 2) h->gemm_weights.push_back({kv.second.p, (size_t)kv.second.numel});
+    for (int l = 0; l < L; l++)
+        for (auto *vec : {&h->down[l], &h->up[l]})
+            for (auto &b : *vec) {
+                h->gemm_weights.push_back({b.qkv_wf, (size_t)3 * b.C * b.C});
+                h->gemm_weights.push_back({b.fc1_wf, (size_t)c.mlp_ratio * b.C * b.C});
+            }
+    h->gemm_weights.push_back({h->aff_w, (size_t)h->aff_n * NOISE_EMB});
+    h->gemm_weights.push_back({h->pe_w, (size_t)E * h->Kp});
+    h->gemm_weights.push_back({h->ro0_wf, (size_t)E * E});
+    if (h->ro_gext) h->gemm_weights.push_back({h->ro_gext, (size_t)E * 128});
+    if (h->opt_gemm_bf16) if (int rc = ensure_bf16_weights(h)) return rc;
     h->finalized = true;
     return DSG_OK;
 }
@@ -726,7 +766,12 @@ void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStre
             (void)hipMemcpyAsync(t.dst, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, s);
 }
 
-#define P_GEMM(g) do { char tg_[96]; if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) (g).prof = h->prof_gemm + 2 * (h->prof_gemm_used++); else (g).prof = nullptr; \
+// P_GEMM: always exact fp32 (noise embedding / modulation parameters, patch embed, read-out and heads: small, and their
+// error would enter every block).  P_GEMM_LP: the Swin-block, PatchMerging and PatchBreakup linears, which the opt-in
+// "gemm_bf16" mode runs on bf16 MFMA.
+#define P_GEMM_LP(g) do { (g).Wb = bf16_of(h, (g).W); P_GEMM_(g); } while (0)
+#define P_GEMM(g) do { (g).Wb = nullptr; P_GEMM_(g); } while (0)
+#define P_GEMM_(g) do { char tg_[96]; if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) (g).prof = h->prof_gemm + 2 * (h->prof_gemm_used++); else (g).prof = nullptr; \
     if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm M=%d N=%d K=%d ln=%d act=%d res=%d", (g).M, (g).N, (g).K, (g).ln_stats != nullptr, (g).act, (g).res != nullptr); \
     ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)(g).M * (double)(g).N * (double)(g).K, tg_); launch_gemm((g), s); } while (0)
 #define P_KERN(kind, flops, call) do { ProfScope ps_(h, s, (kind), (flops), #call); call; } while (0)
@@ -749,14 +794,14 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
         g.ln_stats = w->stats;   // gamma/beta of norm1 are folded into qkv_wf / qkv_bf
         g.W = b.qkv_wf; g.bias = b.qkv_bf; g.N = 3 * C;
         g.C = w->qkv; g.ldc = 3 * C;
-        P_GEMM(g);
+        P_GEMM_LP(g);
         WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
         P_KERN(PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s));
         g = GemmArgs();
         g.A = w->att; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = C;
         g.W = WT(h, p + ".attn.proj.weight"); g.bias = WT(h, p + ".attn.proj.bias");
         g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
-        P_GEMM(g);
+        P_GEMM_LP(g);
     }
     if (h->opt_fused_mlp && b.w1p && C <= h->opt_fused_mlp_maxc) {
         // LN2 + fc1 + GELU + fc2 + residual in one kernel, hidden activations never leave the register file
@@ -771,12 +816,12 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
     g.ln_stats = w->stats;   // gamma/beta of norm2 are folded into fc1_wf / fc1_bf
     g.W = b.fc1_wf; g.bias = b.fc1_bf; g.act = ACT_GELU;
     g.C = w->hid; g.ldc = Hd;
-    P_GEMM(g);
+    P_GEMM_LP(g);
     g = GemmArgs();
     g.A = w->hid; g.lda = Hd; g.K1 = Hd; g.K = Hd; g.M = M; g.N = C;
     g.W = WT(h, p + ".mlp.fc2.weight"); g.bias = WT(h, p + ".mlp.fc2.bias");
     g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
-    P_GEMM(g);
+    P_GEMM_LP(g);
 }
 
 // PositionalEmbedding + map_layer0/1 + all affine linears for `rows` noise labels (diffusesg.py:768-771, :238, :574)
@@ -841,7 +886,7 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
             g = GemmArgs();
             g.A = w->y; g.lda = 4 * C; g.K1 = 4 * C; g.K = 4 * C; g.M = B * T / 4; g.N = 2 * C;
             g.W = WT(h, p + ".reduction.weight"); g.C = w->x; g.ldc = 2 * C; g.C2 = w->skips[l]; g.ldc2 = 2 * C;
-            P_GEMM(g);
+            P_GEMM_LP(g);
         }
         snprintf(name, sizeof(name), "down%d", l);
         tap(h, name, w->x, l < L - 1 ? (size_t)B * (T / 4) * 2 * C : (size_t)B * T * C, s);
@@ -856,13 +901,13 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
             g = GemmArgs();                   // pre_linear on cat([x, skip]) without materialising the concat
             g.A = w->x; g.lda = D / 2; g.K1 = D / 2; g.A2 = w->skips[l]; g.lda2 = D / 2; g.K = D; g.M = B * Tc; g.N = D;
             g.W = WT(h, p + ".pre_linear.weight"); g.C = w->hid; g.ldc = D;
-            P_GEMM(g);
+            P_GEMM_LP(g);
             P_KERN(PK_ROW, 0.0, launch_breakup_ln(w->hid, WT(h, p + ".norm.weight"), WT(h, p + ".norm.bias"), WT(h, p + ".post_norm.weight"),
                               WT(h, p + ".post_norm.bias"), w->y, B, res / 2, D, s));
             g = GemmArgs();
             g.A = w->y; g.lda = C; g.K1 = C; g.K = C; g.M = B * T; g.N = C;
             g.W = WT(h, p + ".post_linear.weight"); g.C = w->x; g.ldc = C;
-            P_GEMM(g);
+            P_GEMM_LP(g);
             snprintf(name, sizeof(name), "up%d.upsample", i);
             tap(h, name, w->x, (size_t)B * T * C, s);
         }
@@ -1002,6 +1047,10 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "fused_mlp_maxc") h->opt_fused_mlp_maxc = value;
     else if (n == "fused_readout") h->opt_fused_readout = value != 0;
     else if (n == "fused_patch_embed") h->opt_fused_pe = value != 0;
+    else if (n == "gemm_bf16") {
+        h->opt_gemm_bf16 = value != 0;
+        if (h->opt_gemm_bf16 && h->finalized) if (int rc = ensure_bf16_weights(h)) return rc;
+    }
     else return fail(h, DSG_ERR_INVALID, "unknown option '%s'", name);
     // captured graphs bake the kernel selection
     for (auto &kv : h->ws) {

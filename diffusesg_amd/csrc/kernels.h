@@ -13,6 +13,7 @@ struct GemmArgs {
     const float *A2 = nullptr; int lda2 = 0;     // optional second source (k >= K1): concat along K
     int K1 = 0;                                  // == K when A2 is null
     const float *W = nullptr;                    // [N, K] row-major (torch Linear layout)
+    const void *Wb = nullptr;                    // the same weight as bf16 [N, K]: non-null selects the bf16-MFMA kernel
     const float *bias = nullptr;                 // [N] or null
     const float *ln_stats = nullptr;             // [M,2] (mean, rstd): A is replaced by (A-mean)*rstd on the way in; the
                                                  // LayerNorm's gamma/beta must already be folded into W / bias
@@ -24,6 +25,7 @@ struct GemmArgs {
     unsigned long long *prof = nullptr;          // measurement mode: {min block start, max block end} in 100 MHz ticks
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
+void launch_f32_to_bf16(const float *src, void *dst, size_t n, hipStream_t s);
 // device table of the fused MLP's table-driven GELU; must be called once (outside any stream capture) before the first launch
 const float *gelu_table();
 

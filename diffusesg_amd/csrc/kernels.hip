@@ -289,6 +289,145 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// bf16 GEMM (opt-in precision mode, BASELINE config 5): same interface and epilogue as gemm4, operands rounded to
+// bf16 (RNE) -- A on the way into LDS (after the fp32 LayerNorm FMA), W pre-converted at pack time -- products on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Activations stay fp32 in HBM, so at these shapes the kernel is
+// bound by HBM/L2 streaming, not by the matrix pipe (16x the f32 rate): 128x96 tile, K step 64, register-staged.
+// -------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int HBK = 64, HLD = 72;  // k per chunk, LDS row stride in bf16 elements (144 B: 16-B aligned, conflict-free)
+
+template <bool LN, int ACT, bool RES>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (GBM + GBN) * HLD];
+    constexpr int BUF = (GBM + GBN) * HLD;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, seq = bid >> 3;
+    const int tm = (seq / tiles_n) * 8 + xcd, tn = seq % tiles_n;
+    if (tm >= tiles_m) return;
+    const int m0 = tm * GBM, n0 = tn * GBN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows_m = min(GBM, g.M - m0), rows_n = min(GBN, g.N - n0);
+    const rsrc_t rsA1 = make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
+    const rsrc_t rsA2 = make_rsrc(g.A2 ? g.A2 + (size_t)m0 * g.lda2 : g.A, g.A2 ? (unsigned)rows_m * g.lda2 * 4u : 0u);
+    const rsrc_t rsW = make_rsrc(static_cast<const __bf16 *>(g.Wb) + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 2u);
+    // A staging: 16 threads per row (float4 each = 64 k), rows ra + 16p; W staging: 8 threads per row (8 bf16 each)
+    const int ca = tid & 15, ra = tid >> 4, cw = tid & 7, rw = tid >> 3;
+    unsigned voffA1[8], voffA2[8], voffW[3];
+    float a_rstd[8], a_nmr[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const int r = ra + 16 * p;
+        voffA1[p] = ((unsigned)r * g.lda + 4u * ca) * 4u;
+        voffA2[p] = ((unsigned)r * g.lda2 + 4u * ca) * 4u;
+        if (LN) {
+            const int m = min(m0 + r, g.M - 1);
+            const float mean = g.ln_stats[2 * m], rstd = g.ln_stats[2 * m + 1];
+            a_rstd[p] = rstd; a_nmr[p] = -mean * rstd;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; p++) voffW[p] = ((unsigned)(rw + 32 * p) * g.K + 8u * cw) * 2u;
+    // K may be a multiple of 32 only (e.g. 96): the last chunk is then half valid; the descriptor zero-fills the rest of
+    // the row only at the buffer end, so clamp explicitly
+    const int nk = (g.K + HBK - 1) / HBK;
+    const int K1 = g.A2 ? g.K1 : g.K;
+
+    f32x4 sa[8];
+    bf16x8 sw[3];
+    auto issue = [&](int kc) {
+        const int k0 = kc * HBK, k = k0 + 4 * ca;
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < g.K) v = (k >= K1) ? buf_load4(rsA2, voffA2[p], (unsigned)(k0 - K1) * 4u) : buf_load4(rsA1, voffA1[p], (unsigned)k0 * 4u);
+            sa[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            bf16x8 v = {};
+            if (k0 + 8 * cw < g.K) v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[p], (unsigned)k0 * 2u, 0));
+            sw[p] = v;
+        }
+    };
+    auto write = [&](int buf, int kc) {
+        __bf16 *As = lds + buf * BUF, *Ws = As + GBM * HLD;
+        const bool kvalid = kc * HBK + 4 * ca < g.K;
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            f32x4 v = sa[p];
+            if (LN && kvalid) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = fmaf(v[t], a_rstd[p], a_nmr[p]);
+            }
+            const bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *reinterpret_cast<bf16x4 *>(As + (ra + 16 * p) * HLD + 4 * ca) = b;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) *reinterpret_cast<bf16x8 *>(Ws + (rw + 32 * p) * HLD + 8 * cw) = sw[p];
+    };
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    issue(0);
+    write(0, 0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; kc++) {
+        const int cur = kc & 1;
+        if (kc + 1 < nk) issue(kc + 1);
+        const __bf16 *As = lds + cur * BUF, *Ws = As + GBM * HLD;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {  // 4 MFMA k-steps of 16; lane (row, half) holds k = 16s + 8*half + 0..7
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(As + (wave * 32 + lrow) * HLD + 16 * s + 8 * lhalf);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(Ws + (32 * j + lrow) * HLD + 16 * s + 8 * lhalf);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        if (kc + 1 < nk) write(1 - cur, kc + 1);
+        __syncthreads();
+    }
+    const rsrc_t rsC = make_rsrc(g.C + (size_t)m0 * g.ldc, (unsigned)rows_m * g.ldc * 4u);
+    const rsrc_t rsC2 = make_rsrc(g.C2 ? g.C2 + (size_t)m0 * g.ldc2 : g.C, g.C2 ? (unsigned)rows_m * g.ldc2 * 4u : 0u);
+    const rsrc_t rsR = make_rsrc(RES ? g.res + (size_t)m0 * g.ldres : g.C, RES ? (unsigned)rows_m * g.ldres * 4u : 0u);
+    const unsigned rowl = (unsigned)(wave * 32 + 4 * lhalf);
+    const unsigned OOB = 0x7fffffffu;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int n = n0 + 32 * j + lrow;
+        const bool nok = n < g.N;
+        const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+        const unsigned vC = nok ? (rowl * g.ldc + (unsigned)n) * 4u : OOB;
+        const unsigned vC2 = nok ? (rowl * g.ldc2 + (unsigned)n) * 4u : OOB;
+        const unsigned vR = nok ? (rowl * g.ldres + (unsigned)n) * 4u : OOB;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const unsigned rr = (unsigned)((r & 3) + 8 * (r >> 2));
+            float v = acc[j][r] + bias;
+            if (ACT == ACT_GELU) v = gelu_f(v);
+            else if (ACT == ACT_SILU) v = silu_exact(v);
+            if (RES) v += buf_load1(rsR, vR, rr * g.ldres * 4u);
+            buf_store1(v, rsC, vC, rr * g.ldc * 4u);
+            if (g.C2) buf_store1(v, rsC2, vC2, rr * g.ldc2 * 4u);
+        }
+    }
+}
+
+// fp32 [n] -> bf16 [n] (RNE), used once per weight at pack time
+__global__ void f32_to_bf16_kernel(const float *src, __bf16 *dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (__bf16)src[i];
+}
+void launch_f32_to_bf16(const float *src, void *dst, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (__bf16 *)dst, n);
+}
+
 static float *g_gelu_tab_dev = nullptr;
 const float *gelu_table() {
     if (!g_gelu_tab_dev) {
@@ -311,7 +450,12 @@ void launch_gemm(const GemmArgs &g, hipStream_t s) {
     const int tiles_m = (g.M + GBM - 1) / GBM, tiles_n = (g.N + GBN - 1) / GBN;
     const dim3 grid(((tiles_m + 7) / 8) * 8 * tiles_n), block(256);
     const bool ln = g.ln_stats != nullptr, res = g.res != nullptr;
-#define GEMM_CASE(L, A, R) hipLaunchKernelGGL((gemm4_f32_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n)
+#define GEMM_CASE(L, A, R)                                                                                  \
+    do {                                                                                                    \
+        if (g.Wb && (!g.A2 || g.K1 % HBK == 0))                                                             \
+            hipLaunchKernelGGL((gemm_bf16_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n);          \
+        else hipLaunchKernelGGL((gemm4_f32_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n);        \
+    } while (0)
     if (ln && g.act == ACT_NONE && !res) GEMM_CASE(true, ACT_NONE, false);
     else if (ln && g.act == ACT_GELU && !res) GEMM_CASE(true, ACT_GELU, false);
     else if (!ln && g.act == ACT_NONE && res) GEMM_CASE(false, ACT_NONE, true);
