@@ -29,6 +29,7 @@ from diffusesg_amd import dist as dsg_dist  # noqa: E402
 from diffusesg_amd import spec, synth, weights  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2516.6  # same guide: ~2.5 PF dense = 16 x the fp32 matrix rate
 
 
 def cpu_baseline(cfg, sd, T, valid, budget_s=20.0):
@@ -69,8 +70,9 @@ def main():
     ap.add_argument("--config", default="vg", choices=["vg", "coco", "tiny"])
     ap.add_argument("--valid", type=int, default=None, help="valid nodes per graph (VG: 30)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
-                    help="f32 (default, the BASELINE headline): exact fp32 MFMA; bf16: opt-in bf16-MFMA GEMMs with fp32 accumulate")
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32-split", "bf16"],
+                    help="f32 (default, the BASELINE headline): fp32 MFMA; f32-split: opt-in fp32-accurate GEMMs as six bf16-MFMA "
+                         "partial products of hi/mid/lo operand splits; bf16: opt-in bf16-MFMA GEMMs with fp32 accumulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
@@ -95,6 +97,8 @@ def main():
     net = build_network(cfg, sd, device=dev)
     if args.precision == "bf16":
         net.model._ensure_handle().set_option("gemm_bf16", 1)
+    if args.precision == "f32-split":
+        net.model._ensure_handle().set_option("gemm_split", 1)
     T, B = args.num_steps, args.batch
     smp = NodeAdjEDMSamplerHip(num_steps=T, solver="heun", S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
                                clip_samples=True, clip_samples_min=-1.0, clip_samples_max=1.0, clip_samples_scope="x_0",
@@ -163,8 +167,14 @@ def main():
                 traffic = tj["kernels"]["gemm4_f32_kernel"]["hbm_bytes_per_launch"]
                 traffic_src = f"profiles/{rnd}/pmc_traffic.json"
                 break
-        roofline = {"bound": "mfma", "kernel": "gemm4_f32_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+        # peak of the pipe the dominant kernel runs on, in ALGORITHMIC (2*M*N*K) FLOP/s: the split kernel issues six bf16
+        # MFMA products per algorithmic product, so its ceiling is the bf16 dense peak / 6
+        kern, peak = {"f32": ("gemm4_f32_kernel", PEAK_F32_MFMA_TFLOPS), "bf16": ("gemm_bf16_kernel", PEAK_BF16_MFMA_TFLOPS),
+                      "f32-split": ("gemm_split_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0)}[args.precision]
+        if args.precision != "f32":
+            traffic, traffic_src, gemm_avg_ms_inkernel = None, None, None
+        roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak,
+                    "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": gemm_avg_ms, "avg_launch_ms_inkernel": gemm_avg_ms_inkernel,
                     "flops_per_launch": fl[0] / cnt[0], "launches_per_forward": cnt[0] // iters,
                     "forward_breakdown": breakdown}
@@ -178,7 +188,8 @@ def main():
             "metric": "scene-graphs/sec", "value": value, "unit": "scene-graphs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "bf16 GEMM operands, f32 accumulate/activations", "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16": "bf16 GEMM operands, f32 accumulate/activations",
+                      "f32-split": "f32 (GEMM products as 3-way bf16 operand splits, six partial products, f32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{args.config}-bits N={n} valid={valid} C_adj={cfg.c_adj} C_node={cfg.c_node} "
                                    f"T={T} heun S_churn=40 self_cond={int(cfg.self_condition)}",
                        "batch_per_gpu": B, "global_batch": world * B, "num_steps": T,

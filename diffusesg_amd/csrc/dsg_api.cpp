@@ -106,6 +106,8 @@ struct dsg_handle_s {
     bool opt_gemm_bf16 = false;                                   // bf16-MFMA GEMMs (fp32 accumulate), opt-in precision mode
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
+    bool opt_gemm_split = false;                                  // split-bf16 GEMMs (3 planes, 6 products): fp32-accurate, opt-in
+    std::map<const float *, void *> w_split;                      // [3][N][K] bf16 planes
     int opt_fused_mlp_maxc = 96;   // at C = 192 the plain GEMM pair is faster than the one-wave-per-SIMD fused kernel
     // per-step (scale,shift) table of the sampler (batch-uniform sigma): [cap][aff_n] and its staging buffers
     int tab_cap = 0;
@@ -433,6 +435,24 @@ int ensure_bf16_weights(dsg_handle h) {
     return 0;
 }
 
+const void *split_of(dsg_handle h, const float *W) {
+    if (!h->opt_gemm_split) return nullptr;
+    auto it = h->w_split.find(W);
+    return it == h->w_split.end() ? nullptr : it->second;
+}
+
+int ensure_split_weights(dsg_handle h) {
+    for (auto &pw : h->gemm_weights) {
+        if (h->w_split.count(pw.first)) continue;
+        void *q;
+        HIP_TRY(h, hipMalloc(&q, pw.second * 6));
+        launch_f32_split3(pw.first, q, pw.second, nullptr);
+        h->w_split[pw.first] = q;
+    }
+    HIP_TRY(h, hipDeviceSynchronize());
+    return 0;
+}
+
 bool env_on(const char *name, bool dflt) {
     const char *v = getenv(name);
     return v ? (v[0] != '0') : dflt;
@@ -474,6 +494,7 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     h->opt_fused_pe = env_on("DSG_FUSED_PE", true);
     if (getenv("DSG_FUSED_MLP_MAXC")) h->opt_fused_mlp_maxc = atoi(getenv("DSG_FUSED_MLP_MAXC"));
     h->opt_gemm_bf16 = env_on("DSG_GEMM_BF16", false);
+    h->opt_gemm_split = env_on("DSG_GEMM_SPLIT", false);
     *out = h;
     return DSG_OK;
 }
@@ -482,6 +503,7 @@ void dsg_destroy(dsg_handle h) {
     if (!h) return;
     for (auto &kv : h->w) (void)hipFree(kv.second.p);
     for (auto &kv : h->w_bf16) (void)hipFree(kv.second);
+    for (auto &kv : h->w_split) (void)hipFree(kv.second);
     for (void *p : h->derived_allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     if (h->prof_gemm) (void)hipFree(h->prof_gemm);
@@ -679,6 +701,8 @@ int dsg_finalize_weights(dsg_handle h) {
     // bf16 copies (opt-in mode): drop stale ones, list every GEMM weight, rebuild if the mode is on
     for (auto &kv : h->w_bf16) (void)hipFree(kv.second);
     h->w_bf16.clear();
+    for (auto &kv : h->w_split) (void)hipFree(kv.second);
+    h->w_split.clear();
     h->gemm_weights.clear();
     for (auto &kv : h->w)
         if (kv.second.p && kv.second.shape.size() >= 2) h->gemm_weights.push_back({kv.second.p, (size_t)kv.second.numel});
@@ -693,6 +717,7 @@ int dsg_finalize_weights(dsg_handle h) {
     h->gemm_weights.push_back({h->ro0_wf, (size_t)E * E});
     if (h->ro_gext) h->gemm_weights.push_back({h->ro_gext, (size_t)E * 128});
     if (h->opt_gemm_bf16) if (int rc = ensure_bf16_weights(h)) return rc;
+    if (h->opt_gemm_split) if (int rc = ensure_split_weights(h)) return rc;
     h->finalized = true;
     return DSG_OK;
 }
@@ -769,8 +794,9 @@ void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStre
 // P_GEMM: always exact fp32 (noise embedding / modulation parameters, patch embed, read-out and heads: small, and their
 // error would enter every block).  P_GEMM_LP: the Swin-block, PatchMerging and PatchBreakup linears, which the opt-in
 // "gemm_bf16" mode runs on bf16 MFMA.
-#define P_GEMM_LP(g) do { (g).Wb = bf16_of(h, (g).W); P_GEMM_(g); } while (0)
-#define P_GEMM(g) do { (g).Wb = nullptr; P_GEMM_(g); } while (0)
+// "gemm_split" (fp32-accurate split-bf16 products) applies to every GEMM and takes precedence over "gemm_bf16".
+#define P_GEMM_LP(g) do { (g).Ws3 = split_of(h, (g).W); (g).Wb = (g).Ws3 ? nullptr : bf16_of(h, (g).W); P_GEMM_(g); } while (0)
+#define P_GEMM(g) do { (g).Ws3 = split_of(h, (g).W); (g).Wb = nullptr; P_GEMM_(g); } while (0)
 #define P_GEMM_(g) do { char tg_[96]; if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) (g).prof = h->prof_gemm + 2 * (h->prof_gemm_used++); else (g).prof = nullptr; \
     if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm M=%d N=%d K=%d ln=%d act=%d res=%d", (g).M, (g).N, (g).K, (g).ln_stats != nullptr, (g).act, (g).res != nullptr); \
     ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)(g).M * (double)(g).N * (double)(g).K, tg_); launch_gemm((g), s); } while (0)
@@ -1050,6 +1076,10 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
         if (h->opt_gemm_bf16 && h->finalized) if (int rc = ensure_bf16_weights(h)) return rc;
+    }
+    else if (n == "gemm_split") {
+        h->opt_gemm_split = value != 0;
+        if (h->opt_gemm_split && h->finalized) if (int rc = ensure_split_weights(h)) return rc;
     }
     else return fail(h, DSG_ERR_INVALID, "unknown option '%s'", name);
     // captured graphs bake the kernel selection

@@ -14,6 +14,7 @@ struct GemmArgs {
     int K1 = 0;                                  // == K when A2 is null
     const float *W = nullptr;                    // [N, K] row-major (torch Linear layout)
     const void *Wb = nullptr;                    // the same weight as bf16 [N, K]: non-null selects the bf16-MFMA kernel
+    const void *Ws3 = nullptr;                   // the same weight split into three bf16 planes [3][N][K]: split-bf16 kernel
     const float *bias = nullptr;                 // [N] or null
     const float *ln_stats = nullptr;             // [M,2] (mean, rstd): A is replaced by (A-mean)*rstd on the way in; the
                                                  // LayerNorm's gamma/beta must already be folded into W / bias
@@ -22,10 +23,12 @@ struct GemmArgs {
     float *C2 = nullptr; int ldc2 = 0;           // optional second destination
     int M = 0, N = 0, K = 0;                     // K % 32 == 0
     int act = ACT_NONE;
+    const float *gelu_tab = nullptr;             // filled in by launch_gemm (table-driven GELU of the split kernel)
     unsigned long long *prof = nullptr;          // measurement mode: {min block start, max block end} in 100 MHz ticks
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
 void launch_f32_to_bf16(const float *src, void *dst, size_t n, hipStream_t s);
+void launch_f32_split3(const float *src, void *dst, size_t n, hipStream_t s);
 // device table of the fused MLP's table-driven GELU; must be called once (outside any stream capture) before the first launch
 const float *gelu_table();
 

@@ -397,3 +397,49 @@ def test_bf16_gemm_mode_vs_reference(name, fused):
     h.set_option("gemm_bf16", 0)
     oa, on = net(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
     assert_close(oa.cpu().numpy(), g["sc_adj_out"], FWD_RTOL, f"{name} adj (back to fp32)")
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "nosc", "vg", "coco"])
+@pytest.mark.parametrize("fused", [1, 0])
+def test_split_gemm_mode_vs_reference(name, fused):
+    """opt-in "gemm_split" mode: every GEMM on the bf16 matrix pipe with hi/mid/lo operand splitting (six partial
+    products, fp32 accumulate) -- must meet the SAME fp32 tolerance as the default path against the reference goldens"""
+    from diffusesg_amd.model import build_network
+    cfg, flags, adj, node, sc_adj, sc_node = Y.fwd_case(name)
+    g = load(f"fwd_{name}.npz")
+    net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda").model
+    h = net._ensure_handle()
+    for opt in ("fused_attn", "fused_mlp", "fused_readout", "fused_patch_embed"):
+        h.set_option(opt, fused)
+    args = (T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
+    oa0, on0 = [t.cpu().numpy() for t in net(*args)]
+    h.set_option("gemm_split", 1)
+    oa, on = [t.cpu().numpy() for t in net(*args)]
+    ea = assert_close(oa, g["sc_adj_out"], FWD_RTOL, f"{name} adj (split GEMMs)")
+    en = assert_close(on, g["sc_node_out"], FWD_RTOL, f"{name} node (split GEMMs)")
+    e0 = max(assert_close(oa0, g["sc_adj_out"], FWD_RTOL, "fp32 adj"), assert_close(on0, g["sc_node_out"], FWD_RTOL, "fp32 node"))
+    print(f"split {name} fused={fused}: {ea:.2e}/{en:.2e} (fp32 kernels: {e0:.2e})")
+    assert not (np.array_equal(oa, oa0) and np.array_equal(on, on0)), "split mode did not engage"
+    assert max(ea, en) <= max(4 * e0, 2e-5), "split-bf16 GEMMs are measurably less accurate than the fp32 kernels"
+    h.set_option("gemm_split", 0)
+    oa1, on1 = [t.cpu().numpy() for t in net(*args)]
+    assert np.array_equal(oa1, oa0) and np.array_equal(on1, on0)
+
+
+@pytest.mark.parametrize("tag,T_,solver,churn", Y.SAMPLER_RUNS)
+def test_split_gemm_mode_sampler_trajectory(tag, T_, solver, churn):
+    """the reference's recorded-noise trajectories hold at the same tolerance in split mode"""
+    from diffusesg_amd.model import build_network
+    g = load("sampler.npz")
+    cfg = Y.CONFIGS["tiny"]()
+    flags, ia, inn, na, nn, coin_vals = Y.sampler_case(cfg, T_, 4, Y.SAMPLER_VALID, 3, f"smp/{tag}", solver)
+    net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")
+    net.model._ensure_handle().set_option("gemm_split", 1)
+    smp = make_sampler(T_, solver, churn, True)
+    coins = (coin_vals < 0.5).astype(np.uint8)
+    oa, on = smp.sample(net, T(flags), init_adjs=T(ia), init_nodes=T(inn), churn_noise=(T(na), T(nn)),
+                        coins=coins, flag_node_multi_channel=True, flag_adj_multi_channel=True,
+                        num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    tol = 1e-4 if T_ <= 8 else 1e-3
+    assert_close(oa.numpy(), g[f"{tag}_adj"], tol, f"{tag} adj (split)")
+    assert_close(on.numpy(), g[f"{tag}_node"], tol, f"{tag} node (split)")

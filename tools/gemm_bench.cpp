@@ -6,16 +6,19 @@
 #include <vector>
 #include <random>
 #include <algorithm>
+#include <cmath>
 #include "../diffusesg_amd/csrc/kernels.h"
 using namespace dsg;
 #ifdef DSG_CLOCK_DIAG
 namespace dsg { extern __device__ unsigned long long *g_diag_buf; }
 #endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
-static float *dev_rand(size_t n, float scale, unsigned seed) {
+static float *dev_rand(size_t n, float scale, unsigned seed, std::vector<float> *keep = nullptr) {
     std::vector<float> h(n); std::mt19937 g(seed); std::normal_distribution<float> d(0.f, scale);
     for (auto &v : h) v = d(g);
-    float *p; CK(hipMalloc(&p, n * 4)); CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice)); return p;
+    float *p; CK(hipMalloc(&p, n * 4)); CK(hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice));
+    if (keep) *keep = std::move(h);
+    return p;
 }
 int main(int argc, char **argv) {
     struct S { int M, N, K, ln, act, res; };
@@ -25,20 +28,34 @@ int main(int argc, char **argv) {
         {262144, 288, 96, 1, 0, 0}, {262144, 96, 96, 0, 0, 1}, {4096, 3072, 768, 1, 1, 0}, {4096, 768, 3072, 0, 0, 1},
     };
     int only = argc > 1 ? atoi(argv[1]) : -1, iters = argc > 2 ? atoi(argv[2]) : 20;
+    const int mode = argc > 3 ? atoi(argv[3]) : 0;   // 0 fp32 MFMA, 1 bf16 MFMA, 2 split-bf16 (3 planes, 6 products)
+    setvbuf(stdout, nullptr, _IONBF, 0);
     hipStream_t s; CK(hipStreamCreate(&s));
     if (!gelu_table()) return 1;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (size_t i = 0; i < shapes.size(); i++) {
         if (only >= 0 && (int)i != only) continue;
         S sh = shapes[i];
-        float *A = dev_rand((size_t)sh.M * sh.K, 1.f, 1), *W = dev_rand((size_t)sh.N * sh.K, 0.05f, 2);
-        float *C = dev_rand((size_t)sh.M * sh.N, 1.f, 3), *bias = dev_rand(sh.N, 0.1f, 4);
+        std::vector<float> hA, hW, hb, hR;
+        float *A = dev_rand((size_t)sh.M * sh.K, 1.f, 1, &hA), *W = dev_rand((size_t)sh.N * sh.K, 0.05f, 2, &hW);
+        float *C = dev_rand((size_t)sh.M * sh.N, 1.f, 3), *bias = dev_rand(sh.N, 0.1f, 4, &hb);
         float *stats = dev_rand((size_t)sh.M * 2, 0.f, 5), *gam = dev_rand(sh.K, 1.f, 6), *bet = dev_rand(sh.K, 1.f, 7);
-        float *R = sh.res ? dev_rand((size_t)sh.M * sh.N, 1.f, 8) : nullptr;
+        {   // mean 0.1, rstd 0.9 for every row
+            std::vector<float> hs((size_t)sh.M * 2);
+            for (int m = 0; m < sh.M; m++) { hs[2 * m] = 0.1f; hs[2 * m + 1] = 0.9f; }
+            CK(hipMemcpy(stats, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+        }
+        float *R = sh.res ? dev_rand((size_t)sh.M * sh.N, 1.f, 8, &hR) : nullptr;
+        void *Wlp = nullptr;
+        if (mode == 1) { CK(hipMalloc(&Wlp, (size_t)sh.N * sh.K * 2)); launch_f32_to_bf16(W, Wlp, (size_t)sh.N * sh.K, s); }
+        if (mode == 2) { CK(hipMalloc(&Wlp, (size_t)sh.N * sh.K * 6)); launch_f32_split3(W, Wlp, (size_t)sh.N * sh.K, s); }
         GemmArgs g; g.A = A; g.lda = sh.K; g.K1 = sh.K; g.K = sh.K; g.M = sh.M; g.N = sh.N; g.W = W; g.bias = bias;
         if (sh.ln) { g.ln_stats = stats; }
+        if (mode == 1) g.Wb = Wlp;
+        if (mode == 2) g.Ws3 = Wlp;
         g.act = sh.act; if (sh.res) { g.res = R; g.ldres = sh.N; } g.C = C; g.ldc = sh.N;
         for (int w = 0; w < 3; w++) launch_gemm(g, s);
+        CK(hipGetLastError()); CK(hipStreamSynchronize(s));
         CK(hipEventRecord(e0, s));
         for (int w = 0; w < iters; w++) launch_gemm(g, s);
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
@@ -59,7 +76,48 @@ int main(int argc, char **argv) {
             unsigned long long *nul = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(dsg::g_diag_buf), &nul, sizeof(nul))); (void)hipFree(dbuf);
         }
 #endif
+        {   // accuracy on a sample of outputs against fp64
+            std::vector<float> hC((size_t)sh.M * sh.N);
+            CK(hipStreamSynchronize(s)); CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+            std::mt19937 rg(99); double maxe = 0, sumsq = 0; const int ns = 20000; int nbad = 0;
+            for (int t = 0; t < ns; t++) {
+                const int m = rg() % sh.M, n = rg() % sh.N;
+                double acc = hb[n];
+                for (int k = 0; k < sh.K; k++) {
+                    float a = hA[(size_t)m * sh.K + k];
+                    if (sh.ln) a = fmaf(a, 0.9f, -0.1f * 0.9f);
+                    acc += (double)a * (double)hW[(size_t)n * sh.K + k];
+                }
+                if (sh.act == 1) acc = 0.5 * acc * (1.0 + erf(acc / sqrt(2.0)));
+                if (sh.res) acc += hR[(size_t)m * sh.N + n];
+                const double e = fabs(acc - (double)hC[(size_t)m * sh.N + n]);
+                if (e > 1e-3 && mode != 1 && nbad++ < 4) printf("\n   bad (m=%d n=%d) ref %.6f got %.6f", m, n, acc, hC[(size_t)m * sh.N + n]);
+                maxe = std::max(maxe, e); sumsq += acc * acc;
+            }
+            printf("  | max err %.3g (rms out %.3g)", maxe, sqrt(sumsq / ns));
+        }
+        if (mode == 2 && getenv("GB_FULLDIFF")) {   // whole-matrix diff against the fp32 kernel
+            std::vector<float> h2((size_t)sh.M * sh.N), h0((size_t)sh.M * sh.N);
+            CK(hipMemcpy(h2.data(), C, h2.size() * 4, hipMemcpyDeviceToHost));
+            GemmArgs g0 = g; g0.Ws3 = nullptr; launch_gemm(g0, s); CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(h0.data(), C, h0.size() * 4, hipMemcpyDeviceToHost));
+            size_t nb = 0; int shown = 0;
+            for (int m32 = 0; m32 < sh.M; m32 += 32) {   // one row block of 32 at a time
+                unsigned mask = 0; int nmin = 1 << 30, nmax = -1, cnt = 0; double esum = 0;
+                for (int r = 0; r < 32 && m32 + r < sh.M; r++)
+                    for (int n = 0; n < sh.N; n++) {
+                        const float d = fabsf(h0[(size_t)(m32 + r) * sh.N + n] - h2[(size_t)(m32 + r) * sh.N + n]);
+                        if (d > 1e-3f) { mask |= 1u << r; nmin = std::min(nmin, n); nmax = std::max(nmax, n); cnt++; esum += d; }
+                    }
+                if (!cnt) continue;
+                nb += cnt;
+                if (shown++ < 30) printf("\n   bad block rows %d..%d (256-tile %d, wave %d, rb %d): row mask %08x, n %d..%d, %d entries, mean |err| %.4f",
+                                         m32, m32 + 31, m32 / 256, (m32 % 256) / 64, (m32 % 64) / 32, mask, nmin, nmax, cnt, esum / cnt);
+            }
+            printf("\n   total bad %zu of %zu", nb, h0.size());
+        }
         printf("\n");
+        if (Wlp) (void)hipFree(Wlp);
         for (float *q : {A, W, C, bias, stats, gam, bet, R}) if (q) (void)hipFree(q);
     }
     return 0;
