@@ -170,7 +170,7 @@ def main():
         # peak of the pipe the dominant kernel runs on, in ALGORITHMIC (2*M*N*K) FLOP/s: the split kernel issues six bf16
         # MFMA products per algorithmic product, so its ceiling is the bf16 dense peak / 6
         kern, peak = {"f32": ("gemm4_f32_kernel", PEAK_F32_MFMA_TFLOPS), "bf16": ("gemm_bf16_kernel", PEAK_BF16_MFMA_TFLOPS),
-                      "f32-split": ("gemm_split_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0)}[args.precision]
+                      "f32-split": ("gemm_split2_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0)}[args.precision]
         if args.precision != "f32":
             traffic, traffic_src, gemm_avg_ms_inkernel = None, None, None
         roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak,

@@ -1,0 +1,87 @@
+// kernels_common.hip.h -- device helpers shared by kernels.hip (fp32 MFMA path) and kernels_lp.hip (bf16-MFMA GEMMs).
+#pragma once
+#include "kernels.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <cmath>
+
+namespace dsg {
+
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LN_EPS 1e-5f
+
+// The f32 MFMA shares the SIMD's vector ALUs, so every VALU instruction in an MFMA kernel costs matrix throughput
+// (tools/mfma_rate.cpp).  An IEEE division expands to ~10 VALU ops and precise expf to ~8: inside the network kernels
+// reciprocals, rsqrt and exp use the 1-ulp hardware instructions (v_rcp_f32 / v_rsq_f32 / v_exp_f32); the resulting
+// relative error (~1e-7) is three orders of magnitude below the fp32 parity bar.  The sampler's scalar algebra keeps
+// correctly rounded IEEE operations (precond/churn/euler/heun kernels below).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float silu_exact(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
+// exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|eps| <= 1.5e-7), evaluated so that the
+// negative tail has no cancellation: 1+erf(z) = poly*exp(-z^2) for z<0, 2 - poly*exp(-z^2) otherwise.  Measured max
+// abs error vs an fp64 GELU over [-12,12]: 4.2e-7 -- the same as the fp32 erff formula (4.5e-7); ~3x fewer VALU ops.
+__device__ __forceinline__ float gelu_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = fast_rcp(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float pe = p * t * __expf(-z * z);
+    return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
+}
+
+// Table-driven GELU for the MFMA kernels (10 VALU + one ds_read_b128 instead of 14 VALU + 2 transcendentals).
+// Phi(x) on [-6,6], nodes every 1/64 with (Phi, phi, -x*phi/2): second-order Taylor from the nearest node,
+// |error| <= (1/128)^3/6 * max|Phi'''| = 3.2e-8; outside the range Phi is clamped (gelu error < 6e-9).
+constexpr int GELU_NODES = 769;                 // 12 * 64 + 1
+constexpr int GELU_TAB_FLOATS = GELU_NODES * 4; // float4 per node (16-B aligned LDS reads)
+__device__ __forceinline__ float gelu_lut(float x, const float *tab /* LDS */) {
+    const float t = __builtin_amdgcn_fmed3f(x + 6.0f, 0.0f, 12.0f);
+    const float r = __builtin_rintf(t * 64.0f);
+    const float d = fmaf(r, -0.015625f, t);
+    const f32x4 c = *reinterpret_cast<const f32x4 *>(tab + ((int)r << 2));
+    return x * fmaf(d, fmaf(d, c[2], c[1]), c[0]);
+}
+__device__ __forceinline__ void gelu_tab_to_lds(float *dst, const float *__restrict__ src, int tid, int nthreads) {
+    for (int i = tid; i < GELU_NODES; i += nthreads)
+        reinterpret_cast<f32x4 *>(dst)[i] = reinterpret_cast<const f32x4 *>(src)[i];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+constexpr int GBM = 128, GBN = 96, GBK = 32, GLD = 36;   // GEMM block tile (see kernels.hip)
+
+#ifdef DSG_CLOCK_DIAG
+extern __device__ unsigned long long *g_diag_buf;
+#endif
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_load1(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void buf_store1(float v, rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+
+// implemented in kernels_lp.hip: the bf16-MFMA GEMMs (g.Ws3: split-bf16, fp32-accurate; g.Wb: plain bf16 operands).
+// Returns false if the arguments do not select / fit one of them (the caller then runs the fp32 kernel).
+bool launch_gemm_lp(const GemmArgs &g, hipStream_t s);
+
+}  // namespace dsg

@@ -1,0 +1,441 @@
+// kernels_lp.hip -- the bf16-MFMA GEMMs of libdsg (both opt-in): "gemm_split" (fp32-accurate, six bf16 partial
+// products of hi/mid/lo operand splits) and "gemm_bf16" (operands rounded to bf16).
+//
+// This file is compiled with -fno-slp-vectorize and the build fails if its ISA contains a packed-f32 VALU instruction
+// (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32) or v_cvt_pk_bf16_f32: on MI355X those, issued next to in-flight bf16 MFMAs
+// of the same wave, produced rare wrong lanes (one 16-lane group in ~1e3 wave tiles; found and bisected with
+// tools/gemm_bench's full-matrix diff against the fp32 kernel -- the scalar-op forms of the same code are clean).  The
+// f32-MFMA kernels in kernels.hip do not co-issue VALU work with the matrix pipe and are unaffected.
+#include "kernels_common.hip.h"
+
+namespace dsg {
+
+// -------------------------------------------------------------------------------------------------
+// bf16 GEMM (opt-in precision mode, BASELINE config 5): same interface and epilogue as gemm4, operands rounded to
+// bf16 (RNE) -- A on the way into LDS (after the fp32 LayerNorm FMA), W pre-converted at pack time -- products on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Activations stay fp32 in HBM, so at these shapes the kernel is
+// bound by HBM/L2 streaming, not by the matrix pipe (16x the f32 rate): 128x96 tile, K step 64, register-staged.
+// -------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// fp32 -> bf16 on the integer pipe.  The gfx950 v_cvt_pk_bf16_f32 instruction is deliberately not used: in these kernels
+// (conversion results feeding ds_write while bf16 MFMAs of the same wave are in flight) it produced rare wrong values in
+// lanes 48..63 (about one 16-lane group in 1e5; found with tools/gemm_bench's full-matrix diff, gone with this code).
+__device__ __forceinline__ unsigned bf16_rne_hi(float x) {   // bits [31:16] = round-to-nearest-even bf16 of x
+    const unsigned u = __float_as_uint(x);
+    return u + 0x7fffu + ((u >> 16) & 1u);
+}
+__device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {   // (hi & 0xffff0000) | (lo >> 16)
+    return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+// hi + mid + lo == a to 24 bits, each term exactly representable in bf16 (truncating split; the terms share a's sign)
+__device__ __forceinline__ void split3_bits(float a, unsigned &h, unsigned &m, unsigned &l) {
+    h = __float_as_uint(a) & 0xffff0000u;
+    const float r1 = a - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xffff0000u;
+    l = __float_as_uint(r1 - __uint_as_float(m));   // bits [31:16] are used
+}
+constexpr int HBK = 64, HLD = 72;  // k per chunk, LDS row stride in bf16 elements (144 B: 16-B aligned, conflict-free)
+
+template <bool LN, int ACT, bool RES>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (GBM + GBN) * HLD];
+    constexpr int BUF = (GBM + GBN) * HLD;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, seq = bid >> 3;
+    const int tm = (seq / tiles_n) * 8 + xcd, tn = seq % tiles_n;
+    if (tm >= tiles_m) return;
+    const int m0 = tm * GBM, n0 = tn * GBN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rows_m = min(GBM, g.M - m0), rows_n = min(GBN, g.N - n0);
+    const rsrc_t rsA1 = make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
+    const rsrc_t rsA2 = make_rsrc(g.A2 ? g.A2 + (size_t)m0 * g.lda2 : g.A, g.A2 ? (unsigned)rows_m * g.lda2 * 4u : 0u);
+    const rsrc_t rsW = make_rsrc(static_cast<const __bf16 *>(g.Wb) + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 2u);
+    // A staging: 16 threads per row (float4 each = 64 k), rows ra + 16p; W staging: 8 threads per row (8 bf16 each)
+    const int ca = tid & 15, ra = tid >> 4, cw = tid & 7, rw = tid >> 3;
+    unsigned voffA1[8], voffA2[8], voffW[3];
+    float a_rstd[8], a_nmr[8];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {
+        const int r = ra + 16 * p;
+        voffA1[p] = ((unsigned)r * g.lda + 4u * ca) * 4u;
+        voffA2[p] = ((unsigned)r * g.lda2 + 4u * ca) * 4u;
+        if (LN) {
+            const int m = min(m0 + r, g.M - 1);
+            const float mean = g.ln_stats[2 * m], rstd = g.ln_stats[2 * m + 1];
+            a_rstd[p] = rstd; a_nmr[p] = -mean * rstd;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 3; p++) voffW[p] = ((unsigned)(rw + 32 * p) * g.K + 8u * cw) * 2u;
+    // K may be a multiple of 32 only (e.g. 96): the last chunk is then half valid; the descriptor zero-fills the rest of
+    // the row only at the buffer end, so clamp explicitly
+    const int nk = (g.K + HBK - 1) / HBK;
+    const int K1 = g.A2 ? g.K1 : g.K;
+
+    f32x4 sa[8];
+    bf16x8 sw[3];
+    auto issue = [&](int kc) {
+        const int k0 = kc * HBK, k = k0 + 4 * ca;
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < g.K) v = (k >= K1) ? buf_load4(rsA2, voffA2[p], (unsigned)(k0 - K1) * 4u) : buf_load4(rsA1, voffA1[p], (unsigned)k0 * 4u);
+            sa[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            bf16x8 v = {};
+            if (k0 + 8 * cw < g.K) v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[p], (unsigned)k0 * 2u, 0));
+            sw[p] = v;
+        }
+    };
+    auto write = [&](int buf, int kc) {
+        __bf16 *As = lds + buf * BUF, *Ws = As + GBM * HLD;
+        const bool kvalid = kc * HBK + 4 * ca < g.K;
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            f32x4 v = sa[p];
+            if (LN && kvalid) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = fmaf(v[t], a_rstd[p], a_nmr[p]);
+            }
+            u32x2 b;
+            b[0] = pack_hi16(bf16_rne_hi(v[0]), bf16_rne_hi(v[1]));
+            b[1] = pack_hi16(bf16_rne_hi(v[2]), bf16_rne_hi(v[3]));
+            *reinterpret_cast<u32x2 *>(As + (ra + 16 * p) * HLD + 4 * ca) = b;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) *reinterpret_cast<bf16x8 *>(Ws + (rw + 32 * p) * HLD + 8 * cw) = sw[p];
+    };
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    issue(0);
+    write(0, 0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; kc++) {
+        const int cur = kc & 1;
+        if (kc + 1 < nk) issue(kc + 1);
+        const __bf16 *As = lds + cur * BUF, *Ws = As + GBM * HLD;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {  // 4 MFMA k-steps of 16; lane (row, half) holds k = 16s + 8*half + 0..7
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(As + (wave * 32 + lrow) * HLD + 16 * s + 8 * lhalf);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(Ws + (32 * j + lrow) * HLD + 16 * s + 8 * lhalf);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+        if (kc + 1 < nk) write(1 - cur, kc + 1);
+        __syncthreads();
+    }
+    const rsrc_t rsC = make_rsrc(g.C + (size_t)m0 * g.ldc, (unsigned)rows_m * g.ldc * 4u);
+    const rsrc_t rsC2 = make_rsrc(g.C2 ? g.C2 + (size_t)m0 * g.ldc2 : g.C, g.C2 ? (unsigned)rows_m * g.ldc2 * 4u : 0u);
+    const rsrc_t rsR = make_rsrc(RES ? g.res + (size_t)m0 * g.ldres : g.C, RES ? (unsigned)rows_m * g.ldres * 4u : 0u);
+    const unsigned rowl = (unsigned)(wave * 32 + 4 * lhalf);
+    const unsigned OOB = 0x7fffffffu;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int n = n0 + 32 * j + lrow;
+        const bool nok = n < g.N;
+        const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+        const unsigned vC = nok ? (rowl * g.ldc + (unsigned)n) * 4u : OOB;
+        const unsigned vC2 = nok ? (rowl * g.ldc2 + (unsigned)n) * 4u : OOB;
+        const unsigned vR = nok ? (rowl * g.ldres + (unsigned)n) * 4u : OOB;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const unsigned rr = (unsigned)((r & 3) + 8 * (r >> 2));
+            float v = acc[j][r] + bias;
+            if (ACT == ACT_GELU) v = gelu_f(v);
+            else if (ACT == ACT_SILU) v = silu_exact(v);
+            if (RES) v += buf_load1(rsR, vR, rr * g.ldres * 4u);
+            buf_store1(v, rsC, vC, rr * g.ldc * 4u);
+            if (g.C2) buf_store1(v, rsC2, vC2, rr * g.ldc2 * 4u);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Split-bf16 GEMM (opt-in "gemm_split" mode): fp32-accurate products on the bf16 matrix pipe.
+// Every fp32 operand is written as hi + mid + lo with three bf16 values (8 + 8 + 8 = 24 mantissa bits, bf16 has the
+// fp32 exponent range so nothing can overflow or flush); a.w is accumulated in fp32 from the six partial products
+// hh, hm, mh, hl, lh, mm (the dropped ml, lm, ll terms are <= 2^-24 relative -- fp32 rounding level).  Six
+// v_mfma_f32_32x32x16_bf16 (192 cycles per 32x32x16) replace eight v_mfma_f32_32x32x2_f32 (512 cycles), and unlike the
+// f32 MFMA the bf16 MFMA overlaps with VALU work.  A is split while it is staged into LDS (after the fp32 LayerNorm
+// FMA, by truncation on the integer pipe: and / sub / and / sub / perm); weights are pre-split at pack time ([3][N][K] bf16).
+// -------------------------------------------------------------------------------------------------
+constexpr int SBK = 32, SLD = 40;  // k per chunk; LDS row stride in bf16 elements (80 B: 16-B aligned, conflict-free b128 reads)
+
+// The A operand never touches LDS.  A wave owns 64 rows x all 96 columns of the block
+// tile, so its A fragments are private: each lane loads the 16 k-values of its row half straight from global memory
+// (64 contiguous bytes per lane and chunk; the MFMA k index is a free permutation as long as the W fragment uses the
+// same one), splits them into the three bf16 planes on the integer pipe, and feeds the MFMAs.  Only the pre-split W
+// tile (shared by the block's waves) is staged through a double-buffered LDS tile: one barrier per 32-k chunk.
+// NW waves per block -> block tile (64 NW) x 96.
+template <bool LN, int ACT, bool RES, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_split2_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    constexpr int TM = 64 * NW, WROWS = 128, WPL = WROWS * SLD;   // W tile padded to 128 rows: staging is branch-free
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 3 * WPL];   // [buf][plane][128][SLD]
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, seq = bid >> 3;
+    const int tm = (seq / tiles_n) * 8 + xcd, tn = seq % tiles_n;
+    if (tm >= tiles_m) return;
+    const int m0 = tm * TM, n0 = tn * GBN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int rows_m = min(TM, g.M - m0), rows_n = min(GBN, g.N - n0);
+    const rsrc_t rsA1 = make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
+    const rsrc_t rsA2 = make_rsrc(g.A2 ? g.A2 + (size_t)m0 * g.lda2 : g.A, g.A2 ? (unsigned)rows_m * g.lda2 * 4u : 0u);
+    const __bf16 *Ws = static_cast<const __bf16 *>(g.Ws3);
+    const size_t plane = (size_t)g.N * g.K;
+    rsrc_t rsW[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) rsW[q] = make_rsrc(Ws + q * plane + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 2u);
+    unsigned voffA1[2], voffA2[2];
+    float a_rstd[2], a_nmr[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+        const int r = wave * 64 + rb * 32 + lrow;
+        const int rl = min(r, rows_m - 1);   // rows past M re-read the last valid row (never stored); see the note below
+        voffA1[rb] = ((unsigned)rl * g.lda + 16u * lhalf) * 4u;
+        voffA2[rb] = ((unsigned)rl * g.lda2 + 16u * lhalf) * 4u;
+        if (LN) {
+            const int m = min(m0 + r, g.M - 1);
+            const float mean = g.ln_stats[2 * m], rstd = g.ln_stats[2 * m + 1];
+            a_rstd[rb] = rstd; a_nmr[rb] = -mean * rstd;
+        }
+    }
+    constexpr int RP = 16 * NW, NP = WROWS / RP;   // W staging: RP rows per pass, 4 x 16 B per row and plane; rows >= rows_n
+                                                   // duplicate the last valid row (their columns are never stored)
+    const int wr = tid >> 2, wc = tid & 3;
+    unsigned voffW[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) voffW[i] = ((unsigned)min(wr + RP * i, rows_n - 1) * g.K + 8u * wc) * 2u;
+    const int nk = g.K / SBK;
+    const int nk1 = g.A2 ? g.K1 / SBK : nk;
+
+    f32x4 sw[NP][3];
+    f32x4 araw[2][4];
+    auto issueW = [&](int kc) {
+        const unsigned soff = (unsigned)kc * (SBK * 2u);
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) sw[i][q] = buf_load4(rsW[q], voffW[i], soff);
+    };
+    auto writeW = [&](int buf) {
+        __bf16 *Wp = lds + buf * 3 * WPL;
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) *reinterpret_cast<f32x4 *>(Wp + q * WPL + (wr + RP * i) * SLD + 8 * wc) = sw[i][q];
+    };
+    // raw fp32 of (row block rb, k-step s) of chunk kc -> araw[rb][2s], araw[rb][2s+1]
+    auto loadA = [&](int kc, int rb, int s2) {
+        const bool second = kc >= nk1;
+        const unsigned soff = (unsigned)(second ? kc - nk1 : kc) * (SBK * 4u);
+#pragma unroll
+        for (int t = 2 * s2; t < 2 * s2 + 2; t++)
+            araw[rb][t] = second ? buf_load4(rsA2, voffA2[rb] + 16u * t, soff) : buf_load4(rsA1, voffA1[rb] + 16u * t, soff);
+    };
+    // araw[rb][2s], araw[rb][2s+1] -> the three bf16 planes of the lane's 8 k-values (packed math: 5 VALU per element)
+    // araw[rb][2s], araw[rb][2s+1] -> dwords [e0, e1) of the three bf16 planes of the lane's 8 k-values (2 k per dword).
+    // Scalar fp32 ops on purpose: packed-f32 VALU ops (v_pk_fma_f32 / v_pk_add_f32) next to bf16 MFMAs produced rare
+    // wrong lanes on this part (see tools/gemm_bench's full-matrix diff), so nothing here may be SLP-vectorised.
+    struct Frag { u32x4 p[3]; };   // p[0] = hi, p[1] = mid, p[2] = lo
+    auto build = [&](int rb, int s2, Frag &F, int e0, int e1) {
+#pragma unroll
+        for (int e = e0; e < e1; e++) {
+            const f32x4 src = araw[rb][2 * s2 + (e >> 1)];
+            float v0 = src[2 * (e & 1)], v1 = src[2 * (e & 1) + 1];
+            if (LN) { v0 = fmaf(v0, a_rstd[rb], a_nmr[rb]); v1 = fmaf(v1, a_rstd[rb], a_nmr[rb]); }
+            unsigned h0, m0_, l0, h1, m1, l1;
+            split3_bits(v0, h0, m0_, l0);
+            split3_bits(v1, h1, m1, l1);
+            F.p[0][e] = pack_hi16(h0, h1);
+            F.p[1][e] = pack_hi16(m0_, m1);
+            F.p[2][e] = pack_hi16(l0, l1);
+        }
+    };
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[rb][j][r] = 0.f;
+    // W fragments of one k-step: three register groups of three column tiles; which group holds which plane rotates
+    // (see the chunk loop) so that a plane's registers are refilled for the next k-step as soon as its last product of
+    // the current one has been issued -- one group set instead of two, and every LDS read is ~200+ cycles ahead of its use.
+    struct WGroup { bf16x8 t[3]; };
+    auto ldW = [&](const __bf16 *Wp, int plane, int s2, WGroup &G) {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            G.t[j] = *reinterpret_cast<const bf16x8 *>(Wp + plane * WPL + (32 * j + lrow) * SLD + 16 * lhalf + 8 * s2);
+    };
+    // one product = 3 MFMAs (the three column tiles): consecutive MFMAs never share an accumulator
+    auto prod = [&](int rb, const u32x4 &a, const WGroup &G) {
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), G.t[j], acc[rb][j], 0, 0, 0);
+    };
+#define SPLIT_MIX(nmfma)                                                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < (nmfma); i_++) {                                                               \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                                 \
+    }                                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0)
+    // First unit of a k-step (its W planes arrive lo, mid, hi): products lo.. first.  F = this unit's A fragment,
+    // (nrb, ns, NF) = the fragment built meanwhile for the next unit.
+#define SPLIT_UNIT_FIRST(rb, F, LO, MID, HI, nrb, ns, NF)                                                                  \
+    prod(rb, F.p[0], LO); prod(rb, F.p[1], MID); prod(rb, F.p[0], MID); build(nrb, ns, NF, 0, 2); SPLIT_MIX(9);            \
+    prod(rb, F.p[2], HI); prod(rb, F.p[1], HI); build(nrb, ns, NF, 2, 3); SPLIT_MIX(6);                                   \
+    prod(rb, F.p[0], HI); build(nrb, ns, NF, 3, 4); SPLIT_MIX(3)
+    // Second unit (same W fragments, other row block): hi products first, so the planes free up hi, mid, lo and are
+    // refilled with the NEXT k-step's lo, mid, hi planes from Wsrc.
+#define SPLIT_UNIT_SECOND(rb, F, LO, MID, HI, nrb, ns, NF, Wsrc, ws)                                                       \
+    prod(rb, F.p[2], HI); prod(rb, F.p[1], HI); prod(rb, F.p[0], HI); build(nrb, ns, NF, 0, 2); SPLIT_MIX(9);              \
+    ldW(Wsrc, 2, ws, HI); __builtin_amdgcn_sched_barrier(0);                                                               \
+    prod(rb, F.p[1], MID); prod(rb, F.p[0], MID); build(nrb, ns, NF, 2, 3); SPLIT_MIX(6);                                 \
+    ldW(Wsrc, 1, ws, MID); __builtin_amdgcn_sched_barrier(0);                                                              \
+    prod(rb, F.p[0], LO); build(nrb, ns, NF, 3, 4); SPLIT_MIX(3);                                                          \
+    ldW(Wsrc, 0, ws, LO); __builtin_amdgcn_sched_barrier(0)
+#ifdef DSG_CLOCK_DIAG
+    unsigned long long diag_t0 = 0, diag_r0 = 0;
+    if (tid == 0) { diag_t0 = __builtin_amdgcn_s_memtime(); diag_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    Frag F0, F1;
+    WGroup G0, G1, G2;
+    issueW(0);
+    loadA(0, 0, 0); loadA(0, 1, 0); loadA(0, 0, 1); loadA(0, 1, 1);
+    writeW(0);
+    build(0, 0, F0, 0, 4);
+    loadA(min(1, nk - 1), 0, 0);
+    __syncthreads();
+    ldW(lds, 2, 0, G0); ldW(lds, 1, 0, G1); ldW(lds, 0, 0, G2);   // k-step 0 of chunk 0: lo -> G0, mid -> G1, hi -> G2
+    // Every prefetch is unconditional and in range: past the last chunk it re-reads the last chunk (never consumed), so
+    // there are no branches and the scheduler sees straight-line code per chunk.
+    for (int kc = 0; kc < nk; kc++) {
+        const int cur = kc & 1;
+        const __bf16 *Wc = lds + cur * 3 * WPL, *Wn = lds + (cur ^ 1) * 3 * WPL;
+        const int kn = min(kc + 1, nk - 1), kn2 = min(kc + 2, nk - 1);
+        issueW(kn);
+        SPLIT_UNIT_FIRST(0, F0, G0, G1, G2, 1, 0, F1);
+        loadA(kn, 1, 0);
+        SPLIT_UNIT_SECOND(1, F1, G0, G1, G2, 0, 1, F0, Wc, 1);      // refills: lo -> G2, mid -> G1, hi -> G0 (k-step 1)
+        loadA(kn, 0, 1);
+        SPLIT_UNIT_FIRST(0, F0, G2, G1, G0, 1, 1, F1);
+        loadA(kn, 1, 1);
+        writeW(cur ^ 1);
+        __syncthreads();   // the next chunk's W tile is complete; everybody is done reading this chunk's tile
+        SPLIT_UNIT_SECOND(1, F1, G2, G1, G0, 0, 0, F0, Wn, 0);      // refills: lo -> G0, mid -> G1, hi -> G2 (next chunk)
+        loadA(kn2, 0, 0);
+    }
+#ifdef DSG_CLOCK_DIAG
+    if (tid == 0 && g_diag_buf) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        g_diag_buf[2 * bid] = t1 - diag_t0;
+        g_diag_buf[2 * bid + 1] = r1 - diag_r0;
+    }
+#endif
+#undef SPLIT_UNIT_FIRST
+#undef SPLIT_UNIT_SECOND
+#undef SPLIT_MIX
+    __syncthreads();
+    const float *gtab = reinterpret_cast<const float *>(lds);   // the W tiles are dead: reuse the LDS for the GELU table
+    if (ACT == ACT_GELU && g.gelu_tab) {
+        gelu_tab_to_lds(reinterpret_cast<float *>(lds), g.gelu_tab, tid, 64 * NW);
+        __syncthreads();
+    }
+    const rsrc_t rsC = make_rsrc(g.C + (size_t)m0 * g.ldc, (unsigned)rows_m * g.ldc * 4u);
+    const rsrc_t rsC2 = make_rsrc(g.C2 ? g.C2 + (size_t)m0 * g.ldc2 : g.C, g.C2 ? (unsigned)rows_m * g.ldc2 * 4u : 0u);
+    const rsrc_t rsR = make_rsrc(RES ? g.res + (size_t)m0 * g.ldres : g.C, RES ? (unsigned)rows_m * g.ldres * 4u : 0u);
+    const unsigned OOB = 0x7fffffffu;
+#pragma unroll
+    for (int rb = 0; rb < 2; rb++) {
+        const unsigned rowl = (unsigned)(wave * 64 + rb * 32 + 4 * lhalf);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int n = n0 + 32 * j + lrow;
+            const bool nok = n < g.N;
+            const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+            const unsigned vC = nok ? (rowl * g.ldc + (unsigned)n) * 4u : OOB;
+            const unsigned vC2 = nok ? (rowl * g.ldc2 + (unsigned)n) * 4u : OOB;
+            const unsigned vR = nok ? (rowl * g.ldres + (unsigned)n) * 4u : OOB;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const unsigned rr = (unsigned)((r & 3) + 8 * (r >> 2));
+                float v = acc[rb][j][r] + bias;
+                if (ACT == ACT_GELU) v = g.gelu_tab ? gelu_lut(v, gtab) : gelu_f(v);
+                else if (ACT == ACT_SILU) v = silu_exact(v);
+                if (RES) v += buf_load1(rsR, vR, rr * g.ldres * 4u);
+                buf_store1(v, rsC, vC, rr * g.ldc * 4u);
+                if (g.C2) buf_store1(v, rsC2, vC2, rr * g.ldc2 * 4u);
+            }
+        }
+    }
+}
+
+// fp32 [n] -> three bf16 planes [3][n] with hi + mid + lo == value to 24 bits (pack time)
+__global__ void f32_split3_kernel(const float *src, __bf16 *dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        unsigned h, m, l; split3_bits(src[i], h, m, l);
+        unsigned short *d = reinterpret_cast<unsigned short *>(dst);
+        d[i] = (unsigned short)(h >> 16); d[n + i] = (unsigned short)(m >> 16); d[2 * n + i] = (unsigned short)(l >> 16);
+    }
+}
+void launch_f32_split3(const float *src, void *dst, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (__bf16 *)dst, n);
+}
+
+// fp32 [n] -> bf16 [n] (RNE), used once per weight at pack time
+__global__ void f32_to_bf16_kernel(const float *src, __bf16 *dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reinterpret_cast<unsigned short *>(dst)[i] = (unsigned short)(bf16_rne_hi(src[i]) >> 16);
+}
+void launch_f32_to_bf16(const float *src, void *dst, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (__bf16 *)dst, n);
+}
+
+
+static int round_up8(int x) { return (x + 7) / 8 * 8; }
+
+bool launch_gemm_lp(const GemmArgs &g_in, hipStream_t s) {
+    if (!g_in.Ws3 && !(g_in.Wb && (!g_in.A2 || g_in.K1 % HBK == 0))) return false;
+    GemmArgs g = g_in;
+    g.gelu_tab = gelu_table();
+    const int tiles_n = (g.N + GBN - 1) / GBN;
+    const bool split = g.Ws3 != nullptr;
+    const int tiles_m = (g.M + (split ? 256 : GBM) - 1) / (split ? 256 : GBM);
+    const dim3 grid(round_up8(tiles_m) * tiles_n), block(256);
+    const bool ln = g.ln_stats != nullptr, res = g.res != nullptr;
+#define GEMM_CASE(L, A, R)                                                                                     \
+    do {                                                                                                       \
+        if (split) hipLaunchKernelGGL((gemm_split2_kernel<L, A, R, 4>), grid, block, 0, s, g, tiles_m, tiles_n); \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n);            \
+    } while (0)
+    if (ln && g.act == ACT_NONE && !res) GEMM_CASE(true, ACT_NONE, false);
+    else if (ln && g.act == ACT_GELU && !res) GEMM_CASE(true, ACT_GELU, false);
+    else if (!ln && g.act == ACT_NONE && res) GEMM_CASE(false, ACT_NONE, true);
+    else if (!ln && g.act == ACT_NONE && !res) GEMM_CASE(false, ACT_NONE, false);
+    else if (!ln && g.act == ACT_GELU && !res) GEMM_CASE(false, ACT_GELU, false);
+    else if (!ln && g.act == ACT_SILU && !res) GEMM_CASE(false, ACT_SILU, false);
+    else if (ln && g.act == ACT_NONE && res) GEMM_CASE(true, ACT_NONE, true);
+    else if (ln && g.act == ACT_GELU && res) GEMM_CASE(true, ACT_GELU, true);
+    else if (ln && g.act == ACT_SILU && !res) GEMM_CASE(true, ACT_SILU, false);
+    else if (ln && g.act == ACT_SILU && res) GEMM_CASE(true, ACT_SILU, true);
+    else if (!ln && g.act == ACT_GELU && res) GEMM_CASE(false, ACT_GELU, true);
+    else GEMM_CASE(false, ACT_SILU, true);
+#undef GEMM_CASE
+    return true;
+}
+
+}  // namespace dsg

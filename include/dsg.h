@@ -131,9 +131,12 @@ int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t
 /* Kernel selection.  The narrow levels (C = 96 / 192) have register-resident fused kernels; each can be switched off to
  * fall back to the generic GEMM + attention + row-kernel path (all combinations are parity-tested):
  *   "fused_attn" (C=96 attention block), "fused_mlp", "fused_mlp_maxc" (96|192), "fused_readout", "fused_patch_embed".
- * Precision mode (default 0 = exact fp32 MFMA everywhere): "gemm_bf16" = 1 runs the generic GEMMs on bf16 MFMA with fp32
- * accumulation (operands rounded to bf16; activations, LayerNorm, softmax and the sampler stay fp32) -- BASELINE
- * config 5; parity against the fp32 oracle then holds to 1.5e-2 RMS / 5e-2 max-abs of the output scale, not 1e-4. */
+ * Precision modes (default: exact fp32 MFMA everywhere):
+ *   "gemm_split" = 1: every GEMM as six bf16-MFMA partial products of hi/mid/lo (3 x bf16 = 24-bit) operand splits with
+ *       fp32 accumulation -- fp32-level accuracy, the 1e-4 parity bar still holds; 1.3-1.6x faster GEMMs (power-bound).
+ *   "gemm_bf16" = 1: the block/merge/breakup GEMMs on bf16 MFMA with operands rounded to bf16 (activations, LayerNorm,
+ *       softmax and the sampler stay fp32) -- BASELINE config 5; parity against the fp32 oracle then holds to 1.5e-2 RMS /
+ *       5e-2 max-abs of the output scale, not 1e-4.  "gemm_split" takes precedence if both are set. */
 int dsg_set_option(dsg_handle h, const char *name, int32_t value);
 
 /* Measurement: runs n_iters eager network forwards on the batch-B workspace (whatever inputs the last call left

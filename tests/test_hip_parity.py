@@ -411,13 +411,16 @@ def test_split_gemm_mode_vs_reference(name, fused):
     h = net._ensure_handle()
     for opt in ("fused_attn", "fused_mlp", "fused_readout", "fused_patch_embed"):
         h.set_option(opt, fused)
-    args = (T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
+    if cfg.self_condition:
+        args, ka, kn = (T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node)), "sc_adj_out", "sc_node_out"
+    else:
+        args, ka, kn = (T(adj), T(node), T(flags), T(Y.FWD_C_NOISE)), "nosc_adj_out", "nosc_node_out"
     oa0, on0 = [t.cpu().numpy() for t in net(*args)]
     h.set_option("gemm_split", 1)
     oa, on = [t.cpu().numpy() for t in net(*args)]
-    ea = assert_close(oa, g["sc_adj_out"], FWD_RTOL, f"{name} adj (split GEMMs)")
-    en = assert_close(on, g["sc_node_out"], FWD_RTOL, f"{name} node (split GEMMs)")
-    e0 = max(assert_close(oa0, g["sc_adj_out"], FWD_RTOL, "fp32 adj"), assert_close(on0, g["sc_node_out"], FWD_RTOL, "fp32 node"))
+    ea = assert_close(oa, g[ka], FWD_RTOL, f"{name} adj (split GEMMs)")
+    en = assert_close(on, g[kn], FWD_RTOL, f"{name} node (split GEMMs)")
+    e0 = max(assert_close(oa0, g[ka], FWD_RTOL, "fp32 adj"), assert_close(on0, g[kn], FWD_RTOL, "fp32 node"))
     print(f"split {name} fused={fused}: {ea:.2e}/{en:.2e} (fp32 kernels: {e0:.2e})")
     assert not (np.array_equal(oa, oa0) and np.array_equal(on, on0)), "split mode did not engage"
     assert max(ea, en) <= max(4 * e0, 2e-5), "split-bf16 GEMMs are measurably less accurate than the fp32 kernels"

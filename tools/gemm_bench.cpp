@@ -1,5 +1,8 @@
 // gemm_bench.cpp -- micro-benchmark of libdsg's kernels on random data (dev tool; not part of the product).
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.cpp diffusesg_amd/csrc/kernels.o -o gpurun_out/gemm_bench
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -c tools/gemm_bench.cpp -o /tmp/gemm_bench.o &&
+//        hipcc --offload-arch=gfx950 /tmp/gemm_bench.o diffusesg_amd/csrc/kernels.o diffusesg_amd/csrc/kernels_lp.o -o tools/bin/gemm_bench
+// usage: gemm_bench [shape-index|-1] [iters] [mode: 0 fp32 MFMA, 1 bf16 MFMA, 2 split-bf16]; GB_FULLDIFF=1 adds a whole-matrix
+//        comparison of mode 2 against the fp32 kernel (how the packed-f32 / bf16-MFMA hazard was found)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -64,7 +67,8 @@ int main(int argc, char **argv) {
                2.0 * sh.M * sh.N * sh.K / (ms * 1e-3) / 1e12);
 #ifdef DSG_CLOCK_DIAG
         {
-            const int nb = ((sh.M + 127) / 128 + 7) / 8 * 8 * ((sh.N + 95) / 96);
+            const int tmr = mode == 2 ? 256 : 128;
+            const int nb = ((sh.M + tmr - 1) / tmr + 7) / 8 * 8 * ((sh.N + 95) / 96);
             unsigned long long *dbuf; CK(hipMalloc(&dbuf, sizeof(unsigned long long) * 2 * nb)); CK(hipMemset(dbuf, 0, sizeof(unsigned long long) * 2 * nb));
             CK(hipMemcpyToSymbol(HIP_SYMBOL(dsg::g_diag_buf), &dbuf, sizeof(dbuf)));
             for (int w = 0; w < 10; w++) launch_gemm(g, s);
@@ -72,7 +76,7 @@ int main(int argc, char **argv) {
             std::vector<unsigned long long> hb(2 * nb); CK(hipMemcpy(hb.data(), dbuf, sizeof(unsigned long long) * 2 * nb, hipMemcpyDeviceToHost));
             std::vector<double> clk, dur; for (int b = 0; b < nb; b++) if (hb[2*b+1]) { clk.push_back(100e6 * hb[2*b] / hb[2*b+1]); dur.push_back(hb[2*b]); }
             std::sort(clk.begin(), clk.end()); std::sort(dur.begin(), dur.end());
-            if (!clk.empty()) printf("  | clock median %.3f GHz, block main-loop cycles median %.0f (ideal %d)", clk[clk.size()/2] / 1e9, dur[dur.size()/2], sh.K / 32 * 6144);
+            if (!clk.empty()) printf("  | clock median %.3f GHz, block main-loop cycles median %.0f p10 %.0f p90 %.0f (MFMA-only %d)", clk[clk.size()/2] / 1e9, dur[dur.size()/2], dur[dur.size()/10], dur[dur.size()*9/10], mode == 2 ? sh.K / 32 * 2304 : sh.K / 32 * 6144);
             unsigned long long *nul = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(dsg::g_diag_buf), &nul, sizeof(nul))); (void)hipFree(dbuf);
         }
 #endif
