@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f32-split", "bf16"],
                     help="f32 (default, the BASELINE headline): fp32 MFMA; f32-split: opt-in fp32-accurate GEMMs as six bf16-MFMA "
                          "partial products of hi/mid/lo operand splits; bf16: opt-in bf16-MFMA GEMMs with fp32 accumulate")
+    ap.add_argument("--solver", default="heun", choices=["heun", "euler"], help="configs[2] variant 3b: --solver euler --s-churn 0")
+    ap.add_argument("--s-churn", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1234)
     args = ap.parse_args()
@@ -100,7 +102,7 @@ def main():
     if args.precision == "f32-split":
         net.model._ensure_handle().set_option("gemm_split", 1)
     T, B = args.num_steps, args.batch
-    smp = NodeAdjEDMSamplerHip(num_steps=T, solver="heun", S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
+    smp = NodeAdjEDMSamplerHip(num_steps=T, solver=args.solver, S_churn=args.s_churn, S_min=0.05, S_max=50, S_noise=1.003,
                                clip_samples=True, clip_samples_min=-1.0, clip_samples_max=1.0, clip_samples_scope="x_0",
                                self_condition=cfg.self_condition, dev=dev, use_graph=not args.no_graph)
     flags = torch.from_numpy(weights.synth_flags(B, n, valid)).to(dev)
@@ -134,6 +136,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert out.shape[0] == world * B and bool(torch.isfinite(out).all())
+
+    # The tail the reference pays after sampling (sampler_node_adj.py:194-345): decode the 'bits' samples, gather the
+    # decoded graphs and bring them to the host.  Reported beside `value`, never inside it.
+    from diffusesg_amd import io as dsg_io
+    n_adj_type, n_node_type = (51, 150) if args.config == "vg" else (7, 171) if args.config == "coco" else (2 ** cfg.c_adj, 2 ** (cfg.c_node - 4))
+    raw_a, raw_x = dsg_dist.unpack_results(out[rank * B:(rank + 1) * B], cfg.c_adj, n, cfg.c_node)
+    fence()
+    t1 = time.perf_counter()
+    qa, qn, bb = dsg_io.decode_bits(net, raw_a, raw_x, flags, n_adj_type, n_node_type, bbox=True)
+    dec = dsg_dist.gather_results(dsg_io.pack_decoded(qa, qn, bb, flags))
+    dec_host = dec.cpu()
+    fence()
+    tail = time.perf_counter() - t1
+    assert dec_host.shape[0] == world * B
 
     if rank == 0:
         graphs = world * B * args.steps
@@ -191,11 +207,13 @@ def main():
             "dtype": {"f32": "f32", "bf16": "bf16 GEMM operands, f32 accumulate/activations",
                       "f32-split": "f32 (GEMM products as 3-way bf16 operand splits, six partial products, f32 accumulate)"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{args.config}-bits N={n} valid={valid} C_adj={cfg.c_adj} C_node={cfg.c_node} "
-                                   f"T={T} heun S_churn=40 self_cond={int(cfg.self_condition)}",
+                                   f"T={T} {args.solver} S_churn={args.s_churn:g} self_cond={int(cfg.self_condition)}",
                        "batch_per_gpu": B, "global_batch": world * B, "num_steps": T,
                        "net_forwards_per_step": nfe / args.steps, "gflop_per_forward_per_graph": f_fwd / 1e9,
                        "hip_graph": not args.no_graph, "parallelism": f"batch-sharded x{world}, one all-gather"},
             "roofline": roofline, "cpu_baseline": cpu,
+            "tail": {"what": "on-GPU decode of the bits samples + packed all-gather + D2H of the decoded graphs (once per step)",
+                     "ms": 1e3 * tail, "value_with_tail": graphs / (elapsed + args.steps * tail)},
         }
         print(json.dumps(line))
     if world > 1:
