@@ -100,6 +100,12 @@ int main(int argc, char **argv) {
             }
             printf("  | max err %.3g (rms out %.3g)", maxe, sqrt(sumsq / ns));
         }
+        if (getenv("GB_DUMP")) {   // raw dump of C for offline whole-matrix comparisons between kernel variants
+            std::vector<float> hd((size_t)sh.M * sh.N);
+            CK(hipMemcpy(hd.data(), C, hd.size() * 4, hipMemcpyDeviceToHost));
+            char fn[256]; snprintf(fn, sizeof(fn), "%s_%zu.bin", getenv("GB_DUMP"), i);
+            FILE *f = fopen(fn, "wb"); if (f) { fwrite(hd.data(), 4, hd.size(), f); fclose(f); }
+        }
         if (mode == 2 && getenv("GB_FULLDIFF")) {   // whole-matrix diff against the fp32 kernel
             std::vector<float> h2((size_t)sh.M * sh.N), h0((size_t)sh.M * sh.N);
             CK(hipMemcpy(h2.data(), C, h2.size() * 4, hipMemcpyDeviceToHost));
