@@ -144,6 +144,9 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
 #endif
     Stage s0, s1;
     Frag f0, f1;
+#ifdef DSG_PHASE_DIAG
+    unsigned long long ph1 = 0, ph2 = 0;
+#endif
 #define GEMM4_CHUNK(CUR, ST_W, ST_L, KC)                                                               \
     do {                                                                                               \
         fread(f1, CUR, 1);                                                                             \
@@ -167,6 +170,9 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     write(s0, 0);
     issue(s1, 1);
     __syncthreads();
+#ifdef DSG_PHASE_DIAG
+    if (tid == 0) ph1 = __builtin_amdgcn_s_memrealtime();
+#endif
     fread(f0, 0, 0);
     int kc = 0;
     for (; kc + 1 < nk; kc += 2) {
@@ -175,6 +181,9 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     }
     if (kc < nk) GEMM4_CHUNK(0, s1, s0, kc);
 #undef GEMM4_CHUNK
+#ifdef DSG_PHASE_DIAG
+    if (tid == 0) ph2 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef DSG_CLOCK_DIAG
     if (tid == 0 && g_diag_buf) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -214,6 +223,15 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
             if (g.C2) buf_store1(v, rsC2, vC2, rr * g.ldc2 * 4u);
         }
     }
+#ifdef DSG_PHASE_DIAG
+    if (tid == 0 && g.prof) {   // g.prof doubles as a [4 x blocks] stamp buffer in this build
+        const unsigned long long ph3 = __builtin_amdgcn_s_memrealtime();   // all stores issued
+        __builtin_amdgcn_s_waitcnt(0);
+        g.prof[4 * bid] = ph3 - ph2; g.prof[4 * bid + 1] = ph1 - prof_t0; g.prof[4 * bid + 2] = ph2 - ph1;
+        g.prof[4 * bid + 3] = __builtin_amdgcn_s_memrealtime() - ph3;
+    }
+    return;
+#endif
     if (g.prof && tid == 0) {
         __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have been issued and acknowledged
         atomicMin(g.prof, prof_t0);

@@ -126,6 +126,19 @@ int main(int argc, char **argv) {
             }
             printf("\n   total bad %zu of %zu", nb, h0.size());
         }
+#ifdef DSG_PHASE_DIAG
+        if (mode == 0) {   // per-block phase stamps (100 MHz): entry -> first barrier -> main loop end -> stores acknowledged
+            const int nb = ((sh.M + 127) / 128 + 7) / 8 * 8 * ((sh.N + 95) / 96);
+            unsigned long long *pb; CK(hipMalloc(&pb, 32ull * nb)); CK(hipMemset(pb, 0, 32ull * nb));
+            GemmArgs gp = g; gp.prof = pb; launch_gemm(gp, s); CK(hipStreamSynchronize(s));
+            std::vector<unsigned long long> hp(4ull * nb); CK(hipMemcpy(hp.data(), pb, 32ull * nb, hipMemcpyDeviceToHost));
+            std::vector<double> a, b, c, d;
+            for (int q = 0; q < nb; q++) if (hp[4*q+2]) { a.push_back(hp[4*q+1]/100.0); b.push_back(hp[4*q+2]/100.0); c.push_back(hp[4*q]/100.0); d.push_back(hp[4*q+3]/100.0); }
+            std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end()); std::sort(c.begin(), c.end()); std::sort(d.begin(), d.end());
+            if (!a.empty()) printf("\n   phases (us, median/p90): prologue %.2f/%.2f  main loop %.2f/%.2f  epilogue issue %.2f/%.2f  store-ack wait %.2f/%.2f ; %zu blocks", a[a.size()/2], a[a.size()*9/10], b[b.size()/2], b[b.size()*9/10], c[c.size()/2], c[c.size()*9/10], d[d.size()/2], d[d.size()*9/10], a.size());
+            (void)hipFree(pb);
+        }
+#endif
         printf("\n");
         if (Wlp) (void)hipFree(Wlp);
         for (float *q : {A, W, C, bias, stats, gam, bet, R}) if (q) (void)hipFree(q);
