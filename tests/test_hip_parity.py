@@ -475,3 +475,24 @@ def test_vg_full_batch_kernel_paths_agree_everywhere():
             en = float((on - ref_n).abs().max()) / scale_n
             assert ea <= FWD_RTOL and en <= FWD_RTOL, f"iteration {it} fused={fused} split={split}: {ea:.2e}/{en:.2e}"
     run(1, 0)
+
+
+@pytest.mark.parametrize("name", ["tiny", "vg"])
+def test_empty_graph_in_batch_vs_oracle(name):
+    """a graph with no valid node at all (all flags false) next to full and ragged ones: its outputs are exactly zero,
+    nothing is NaN (the node pooling divides by the padded N, not by the valid count -- diffusesg.py:813), and the other
+    samples still match the oracle"""
+    from oracle.oracle import Oracle
+    cfg = Y.CONFIGS[name]()
+    n = cfg.max_node_num
+    flags, adj, node, sc_adj, sc_node = Y.case_inputs(cfg, 3, [n, 0, max(2, n // 4)], 29, f"empty/{name}")
+    assert not flags[1].any()
+    c_noise = np.array([0.3, -0.7, 1.0], np.float32)
+    orc = Oracle(cfg, W.synth_state_dict(cfg, 0))
+    ra, rn = orc.forward(adj, node, flags, c_noise, sc_adj, sc_node)
+    oa, on = net_for(name).model(T(adj), T(node), T(flags), T(c_noise), T(sc_adj), T(sc_node))
+    assert torch.isfinite(oa).all() and torch.isfinite(on).all()
+    assert torch.all(oa[1] == 0) and torch.all(on[1] == 0)
+    assert np.all(ra[1] == 0) and np.all(rn[1] == 0)
+    assert_close(oa.cpu().numpy(), ra, FWD_RTOL, f"{name} adj with an empty graph")
+    assert_close(on.cpu().numpy(), rn, FWD_RTOL, f"{name} node with an empty graph")
