@@ -496,3 +496,63 @@ def test_empty_graph_in_batch_vs_oracle(name):
     assert np.all(ra[1] == 0) and np.all(rn[1] == 0)
     assert_close(oa.cpu().numpy(), ra, FWD_RTOL, f"{name} adj with an empty graph")
     assert_close(on.cpu().numpy(), rn, FWD_RTOL, f"{name} node with an empty graph")
+
+
+# ---- error behaviour of the boundary (status codes + dsg_last_error; host mirrors raise like the reference) ----
+def _dev_handle(cfg):
+    from diffusesg_amd import lib as L
+    return L, L.Handle(cfg)
+
+
+def test_abi_strict_weight_loading_errors():
+    """dsg_finalize_weights mirrors load_state_dict(strict=True) (sampling_utils.py:34-42): a missing tensor, a wrong shape
+    and an unknown key are all reported by name; compute entry points refuse to run before finalize"""
+    cfg = Y.CONFIGS["tiny"]()
+    L, h = _dev_handle(cfg)
+    sd = W.synth_state_dict(cfg, 0)
+    keys = list(sd.keys())
+    with pytest.raises(L.DsgError, match="not_a_real_key"):
+        t = torch.zeros(4, 4)
+        h.set_weight("model.not_a_real_key.weight", t.data_ptr(), t.shape, False)
+    with pytest.raises(L.DsgError, match="shape"):
+        k = next(k for k in keys if k.endswith("qkv.weight"))
+        t = torch.zeros(3, 5)
+        h.set_weight(k, t.data_ptr(), t.shape, False)
+    skipped = next(k for k in keys if k.endswith("mlp.fc2.bias"))
+    for k, v in sd.items():
+        if k == skipped:
+            continue
+        t = torch.from_numpy(np.ascontiguousarray(v))
+        h.set_weight(k, t.data_ptr(), t.shape, False)
+    with pytest.raises(L.DsgError, match=skipped.split("model.", 1)[-1].replace(".", r"\.")):
+        h.finalize()
+    B, n = 2, cfg.max_node_num
+    a = torch.zeros(B, cfg.c_adj, n, n, device="cuda"); x = torch.zeros(B, n, cfg.c_node, device="cuda")
+    f = torch.ones(B, n, dtype=torch.uint8, device="cuda"); cn = torch.zeros(B, device="cuda")
+    rc = h.L.dsg_denoise(h.raw, B, a.data_ptr(), x.data_ptr(), f.data_ptr(), cn.data_ptr(), None, None, a.data_ptr(), x.data_ptr(), None)
+    assert rc == -4, "dsg_denoise before dsg_finalize_weights must return DSG_ERR_STATE"
+    with pytest.raises(L.DsgError, match="unknown option"):
+        h.set_option("no_such_option", 1)
+    h.close()
+
+
+def test_host_mirrors_reject_unsupported_reference_options():
+    """options of the reference that this path does not implement fail loudly instead of diverging silently"""
+    from diffusesg_amd.model import DiffuseSGHip, NodeAdjPrecondHip, build_network
+    from diffusesg_amd.sampler import NodeAdjEDMSamplerHip
+    cfg = Y.CONFIGS["tiny"]()
+    net = net_for("tiny")
+    with pytest.raises(NotImplementedError):
+        NodeAdjPrecondHip("vp", net.model, True)
+    with pytest.raises(NotImplementedError):
+        NodeAdjPrecondHip("edm", net.model, True, symmetric_noise=True)
+    with pytest.raises(NotImplementedError):
+        NodeAdjEDMSamplerHip(num_steps=4, dev="cuda", symmetric_noise=True)
+    with pytest.raises(NotImplementedError):
+        NodeAdjEDMSamplerHip(num_steps=4, dev="cuda", discretization="vp")
+    flags = T(W.synth_flags(2, cfg.max_node_num, 5))
+    with pytest.raises(NotImplementedError):
+        make_sampler(4).sample(net, flags, flag_use_double=True, num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    adj = torch.zeros(2, cfg.c_adj, 8, 8, device="cuda"); node = torch.zeros(2, 8, cfg.c_node, device="cuda")
+    with pytest.raises(NotImplementedError):   # [B,N,N] node flags = node-only ablation
+        net.model(adj, node, torch.ones(2, 8, 8, dtype=torch.bool, device="cuda"), torch.zeros(2, device="cuda"))
