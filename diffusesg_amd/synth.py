@@ -23,8 +23,16 @@ def nosc_config() -> S.ModelConfig:
                          window_size=4, self_condition=False)
 
 
+def onehot_config() -> S.ModelConfig:
+    """VG with the 'one_hot' encoding's channel widths (sg_utils.py:348-409: C_adj = 51, C_node = 150 + 4, 718 input
+    channels with self-conditioning) on a small grid: the widest channel counts the channel table can produce."""
+    ch = S.sg_channels("visual_genome", "one_hot")
+    return S.ModelConfig(max_node_num=8, c_adj=ch["c_adj"], c_node=ch["c_node"], depths=(1, 1), num_heads=(3, 6),
+                         window_size=4, self_condition=True)
+
+
 CONFIGS = {"tiny": S.tiny_config, "small": small_config, "nosc": nosc_config,
-           "vg": S.vg_config, "coco": S.coco_config}
+           "vg": S.vg_config, "coco": S.coco_config, "onehot": onehot_config}
 
 # ragged numbers of valid nodes per sample used by the forward / precond goldens
 VALID = {"tiny": [8, 5], "small": [16, 9], "nosc": [8, 3], "vg": [30, 11], "coco": [20, 40]}

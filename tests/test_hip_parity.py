@@ -556,3 +556,31 @@ def test_host_mirrors_reject_unsupported_reference_options():
     adj = torch.zeros(2, cfg.c_adj, 8, 8, device="cuda"); node = torch.zeros(2, 8, cfg.c_node, device="cuda")
     with pytest.raises(NotImplementedError):   # [B,N,N] node flags = node-only ablation
         net.model(adj, node, torch.ones(2, 8, 8, dtype=torch.bool, device="cuda"), torch.zeros(2, device="cuda"))
+
+
+def test_onehot_channel_widths_vs_oracle():
+    """the widest rows of the reference's channel table (VG 'one_hot': C_adj = 51, C_node = 154, 718 input channels):
+    none of the narrow-channel fused kernels apply (C_in > 64, C_adj > 32), so this is the generic assemble / GEMM / head
+    path end to end -- forward and a short Heun trajectory against the oracle"""
+    from oracle.oracle import Oracle
+    from diffusesg_amd.model import build_network
+    cfg = Y.CONFIGS["onehot"]()
+    n = cfg.max_node_num
+    sd = W.synth_state_dict(cfg, 0)
+    flags, adj, node, sc_adj, sc_node = Y.case_inputs(cfg, 3, [n, 5, 2], 31, "onehot/fwd")
+    c_noise = np.array([0.2, -0.9, 1.05], np.float32)
+    orc = Oracle(cfg, sd)
+    ra, rn = orc.forward(adj, node, flags, c_noise, sc_adj, sc_node)
+    net = build_network(cfg, sd, device="cuda")
+    oa, on = net.model(T(adj), T(node), T(flags), T(c_noise), T(sc_adj), T(sc_node))
+    assert_close(oa.cpu().numpy(), ra, FWD_RTOL, "onehot adj vs oracle")
+    assert_close(on.cpu().numpy(), rn, FWD_RTOL, "onehot node vs oracle")
+    T_ = 6   # shorter schedules are degenerate, see test_vg_full_size_short_trajectory_vs_oracle
+    fl, ia, inn, na, nn, coin_vals = Y.sampler_case(cfg, T_, 2, [n, 4], 5, "onehot/smp", "heun")
+    coins = (coin_vals < 0.5).astype(np.uint8)
+    ea, en = orc.sample(fl, ia, inn, na, nn, coins, num_steps=T_)
+    ga, gn = make_sampler(T_).sample(net, T(fl), init_adjs=T(ia), init_nodes=T(inn), churn_noise=(T(na), T(nn)), coins=coins,
+                                     flag_node_multi_channel=True, flag_adj_multi_channel=True,
+                                     num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    assert_close(ga.numpy(), ea, 1e-4, "onehot trajectory adj")
+    assert_close(gn.numpy(), en, 1e-4, "onehot trajectory node")
