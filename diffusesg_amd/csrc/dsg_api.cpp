@@ -65,7 +65,7 @@ struct Workspace {
     float *in_adj, *in_node, *sc_adj, *sc_node, *c_noise, *f_adj, *f_node;
     uint8_t *flags;
     int *has_sc;
-    float *pe, *emb0, *emb, *aff, *tok_in, *x, *y, *qkv, *att, *hid, *stats, *pool, *hn, *pool_ext;
+    float *pe, *emb0, *emb, *aff, *tok_in, *x, *y, *qkv, *att, *hid, *stats, *pool, *hn, *pool_ext, *pool_part;
     float *skips[DSG_MAX_LAYERS];
     // sampler state
     float *x_adj, *x_node, *xh_adj, *xh_node, *sig;
@@ -738,6 +738,7 @@ size_t per_sample_floats(dsg_handle h, std::vector<size_t> *parts = nullptr) {
         (size_t)h->cfg.mlp_ratio * T0 * E,       // hid
         2 * T0,                                  // stats
         (size_t)h->N * E, (size_t)h->N * E,      // pool, hn
+        (size_t)h->N * 128, (size_t)h->N * readout_pool_segments(h->N) * 96,   // pool_ext, pool_part
         sa, sn, sa, sn, 3 * sa, 3 * sn,          // sampler x, xhat, d[3]
     };
     size_t tot = 0;
@@ -771,6 +772,7 @@ int get_workspace(dsg_handle h, int B, Workspace **out) {
     ALLOC(w->hid, (size_t)B * h->cfg.mlp_ratio * T0 * E);
     ALLOC(w->stats, (size_t)B * 2 * T0);
     ALLOC(w->pool, (size_t)B * h->N * E); ALLOC(w->hn, (size_t)B * h->N * E); ALLOC(w->pool_ext, (size_t)B * h->N * 128);
+    ALLOC(w->pool_part, (size_t)B * h->N * readout_pool_segments(h->N) * 96);
     for (int l = 0; l < h->L; l++) ALLOC(w->skips[l], ((size_t)B * T0 * E) >> (l + 1 < h->L ? l + 1 : l));
     ALLOC(w->x_adj, sa); ALLOC(w->x_node, sn); ALLOC(w->xh_adj, sa); ALLOC(w->xh_node, sn);
     for (int k = 0; k < 3; k++) { ALLOC(w->d_adj[k], sa); ALLOC(w->d_node[k], sn); }
@@ -949,7 +951,7 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
         // one pass over x: LN, folded read_out+fc1, GELU, fc2, masked adjacency store; pooled LN(x) for the node head
         P_KERN(PK_FUSED, 2.0 * (double)M0 * E * (E + 32.0),
                launch_fused_readout96(w->x, WT(h, "norm.weight"), WT(h, "norm.bias"), h->ro_fap, h->ro_fa, h->ro_f2p,
-                                      WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, w->pool_ext, B, N, h->Ca, s));
+                                      WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, w->pool_part, w->pool_ext, B, N, h->Ca, s));
         g = GemmArgs();
         g.A = w->pool_ext; g.lda = 128; g.K1 = 128; g.K = 128; g.M = B * N; g.N = E; g.act = ACT_GELU;
         g.W = h->ro_gext; g.bias = WT(h, "readout_node_mlp.fc1.bias"); g.C = w->hn; g.ldc = E;
@@ -1090,6 +1092,30 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     return DSG_OK;
 }
 
+int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
+    if (!h || !name || !value) return DSG_ERR_INVALID;
+    const std::string n(name);
+    if (n == "fused_attn") *value = h->opt_fused_attn;
+    else if (n == "fused_mlp") *value = h->opt_fused_mlp;
+    else if (n == "fused_mlp_maxc") *value = h->opt_fused_mlp_maxc;
+    else if (n == "fused_readout") *value = h->opt_fused_readout;
+    else if (n == "fused_patch_embed") *value = h->opt_fused_pe;
+    else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
+    else if (n == "gemm_split") *value = h->opt_gemm_split;
+    else return fail(h, DSG_ERR_INVALID, "unknown option '%s'", name);
+    return DSG_OK;
+}
+
+int dsg_gen_noise(dsg_handle h, int32_t B, const uint8_t *flags, uint64_t seed, uint32_t noise_stream, float *out_adj,
+                  float *out_node, void *stream) {
+    if (!h || B < 1) return fail(h, DSG_ERR_INVALID, "batch must be >= 1");
+    if (!flags || !out_adj || !out_node) return fail(h, DSG_ERR_INVALID, "null tensor");
+    launch_init(CStatePtrs{nullptr, nullptr}, 1.0f, seed, noise_stream, flags, StatePtrs{out_adj, out_node}, dims_of(h, B),
+                (hipStream_t)stream);
+    HIP_TRY(h, hipGetLastError());
+    return DSG_OK;
+}
+
 int dsg_debug_tap(dsg_handle h, const char *stage, float *dst, int64_t capacity) {
     if (!h || !stage || !dst) return DSG_ERR_INVALID;
     h->taps.push_back({stage, dst, capacity});
@@ -1197,7 +1223,7 @@ int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_
     h->last_stats = dsg_sample_stats{};
     HIP_TRY(h, hipMemcpyAsync(w->flags, flags, (size_t)B * h->N, hipMemcpyDeviceToDevice, s));
     // x0 = init * sigma(t0) (edm.py:326, :346-347)
-    launch_init(CStatePtrs{init_adj, init_node}, t_steps[0], seed, w->flags, StatePtrs{w->x_adj, w->x_node}, d, s);
+    launch_init(CStatePtrs{init_adj, init_node}, t_steps[0], seed, 0u, w->flags, StatePtrs{w->x_adj, w->x_node}, d, s);
     const bool use_graph = cfg->use_graph != 0;
     // sigma is batch-uniform (edm.py:371): one noise embedding + (scale,shift) row per step, computed once for all steps
     if (!gt_adj) {

@@ -50,9 +50,11 @@ bool launch_fused_patch_embed96(const float *adj, const float *node, const float
                                 const float *aff, int aff_ld, int aff_off, float *x, int B, int N, int Ca, int Cn, int self_cond, int Kp,
                                 hipStream_t s);
 // final LN + folded read_out/adj-head chain + masked adjacency output, and the LN(x) pooling for the node head (E = 96)
+// pool_part [B*N][readout_pool_segments(N)][96]: per-tile partial sums, reduced in fixed order into pool_ext [B*N,128]
+int readout_pool_segments(int N);
 void launch_fused_readout96(const float *x, const float *gam, const float *bet, const float *Wfp, const float *fa, const float *W2p,
-                            const float *f2, const uint8_t *flags, float *out_adj, float *pool_ext, int B, int N, int Ca,
-                            hipStream_t s);
+                            const float *f2, const uint8_t *flags, float *out_adj, float *pool_part, float *pool_ext, int B, int N,
+                            int Ca, hipStream_t s);
 // whole attention half of a C=96 Swin block in one kernel (modulate+SiLU, LN1, QKV, window attention, proj, residual);
 // windows of at most 64 tokens; packed weights from pack_attn_weights in dsg_api.cpp
 void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, const float *gam, const float *bet, const float *Wqp,
@@ -102,8 +104,9 @@ void launch_precond_out(CStatePtrs x, CStatePtrs F, const float *sigmas, const u
 // x_hat = mask(x + coef*eps); eps from `noise` (if non-null) or Philox(seed, step)
 void launch_churn(CStatePtrs x, CStatePtrs noise, float coef, uint64_t seed, uint32_t step, const uint8_t *flags,
                   StatePtrs xhat, Dims d, hipStream_t s);
-// x0 = mask(eps) * scale (gen_init_sample + initial scaling)
-void launch_init(CStatePtrs init, float scale, uint64_t seed, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s);
+// x0 = mask(eps) * scale (gen_init_sample + initial scaling); eps from `init` or Philox(seed, stream): stream 0 is the
+// initial sample, stream i+1 the churn noise of step i (launch_churn)
+void launch_init(CStatePtrs init, float scale, uint64_t seed, uint32_t stream, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s);
 // Euler: x = mask(xhat + h*mask(inv*xhat - inv*D))
 void launch_euler(CStatePtrs xhat, CStatePtrs D, float inv_t, float h, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s);
 // Heun: d=mask(inv*xhat-inv*D1); xp=xhat+h*d; dp=invp*xp-invp*D2; x=mask(xhat+h*(0.5d+0.5dp))

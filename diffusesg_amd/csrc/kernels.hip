@@ -622,8 +622,8 @@ __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__
                                                                  const float *__restrict__ bet, const float *__restrict__ Wfp,
                                                                  const float *__restrict__ fa, const float *__restrict__ W2p,
                                                                  const float *__restrict__ f2, const uint8_t *__restrict__ flags,
-                                                                 float *__restrict__ out_adj, float *__restrict__ pool_ext,
-                                                                 int B, int N, int Ca) {
+                                                                 float *__restrict__ out_adj, float *__restrict__ pool_part,
+                                                                 int nseg, int B, int N, int Ca) {
     constexpr int C = 96, S = 12;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lrow = lane & 31, lhalf = lane >> 5;
@@ -658,8 +658,11 @@ __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__
     const bool fi = flags[(size_t)b * N + i] != 0, fj = flags[(size_t)b * N + j] != 0;
     const bool valid = ok && fi && fj;
 
-    // pooled LN(x): segmented sum over the tokens of this wave that share a row (b,i)
+    // pooled LN(x): segmented sum over the tokens of this wave that share a row (b,i).  No atomics: the wave stores its
+    // partial for row r into slot (tile - first tile of r) of pool_part[r]; pool_finish_kernel adds a row's slots in slot
+    // order, so the node head is bitwise reproducible.
     {
+        const int tile = blockIdx.x * 4 + wave;
         const int rowid = ok ? b * N + i : -1;
         const int r_first = __shfl(rowid, 0, 64);
         int r_last = __shfl(rowid, 31, 64);
@@ -667,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__
         const float wgt = valid ? 1.0f / (float)N : 0.f;
         for (int r = r_first; r <= r_last; r++) {
             const float sel = (rowid == r) ? wgt : 0.f;
-            if (__ballot(sel != 0.f) == 0ull) continue;
+            float *dst = pool_part + ((size_t)r * nseg + (tile - (r * N) / 32)) * C;
 #pragma unroll
             for (int s = 0; s < S; s++)
 #pragma unroll
@@ -675,7 +678,7 @@ __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__
                     float v = sel * xn[s][t];
 #pragma unroll
                     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                    if (lrow == 0) atomicAdd(pool_ext + (size_t)r * 128 + 8 * s + 4 * lhalf + t, v);
+                    if (lrow == 0) dst[8 * s + 4 * lhalf + t] = v;
                 }
         }
     }
@@ -718,13 +721,17 @@ __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__
     }
 }
 
-// pool_ext [B*N,128]: zero, and column 96 = f_i * (#valid nodes) / N (the factor of the folded constant term)
-__global__ void pool_init_kernel(const uint8_t *flags, float *pool_ext, int B, int N) {
+// pool_ext [B*N,128]: columns 0..95 = the row's partial sums added in slot order (row r spans the 32-token tiles
+// (r*N)/32 .. (r*N+N-1)/32), column 96 = f_i * (#valid nodes) / N (the factor of the folded constant term), rest zero
+__global__ void pool_finish_kernel(const uint8_t *flags, const float *pool_part, int nseg, float *pool_ext, int B, int N) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B * N * 128) return;
     const int col = idx & 127, row = idx >> 7, b = row / N;
     float v = 0.f;
-    if (col == 96 && flags[row]) {
+    if (col < 96) {
+        const int segs = (row * N + N - 1) / 32 - (row * N) / 32 + 1;
+        for (int sg = 0; sg < segs; sg++) v += pool_part[((size_t)row * nseg + sg) * 96 + col];
+    } else if (col == 96 && flags[row]) {
         int cnt = 0;
         for (int jj = 0; jj < N; jj++) cnt += flags[(size_t)b * N + jj] ? 1 : 0;
         v = (float)cnt / (float)N;
@@ -732,14 +739,16 @@ __global__ void pool_init_kernel(const uint8_t *flags, float *pool_ext, int B, i
     pool_ext[idx] = v;
 }
 
+int readout_pool_segments(int N) { return (N + 30) / 32 + 1; }  // most 32-token tiles a row of N tokens can touch
+
 void launch_fused_readout96(const float *x, const float *gam, const float *bet, const float *Wfp, const float *fa, const float *W2p,
-                            const float *f2, const uint8_t *flags, float *out_adj, float *pool_ext, int B, int N, int Ca,
-                            hipStream_t s) {
-    const int n = B * N * 128;
-    hipLaunchKernelGGL(pool_init_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flags, pool_ext, B, N);
-    const int M = B * N * N;
+                            const float *f2, const uint8_t *flags, float *out_adj, float *pool_part, float *pool_ext, int B, int N,
+                            int Ca, hipStream_t s) {
+    const int M = B * N * N, nseg = readout_pool_segments(N);
     hipLaunchKernelGGL(fused_readout96_kernel, dim3((M + 127) / 128), dim3(256), 0, s, x, gam, bet, Wfp, fa, W2p, f2, flags, out_adj,
-                       pool_ext, B, N, Ca);
+                       pool_part, nseg, B, N, Ca);
+    const int n = B * N * 128;
+    hipLaunchKernelGGL(pool_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flags, pool_part, nseg, pool_ext, B, N);
 }
 
 // =================================================================================================
@@ -1461,19 +1470,19 @@ void launch_churn(CStatePtrs x, CStatePtrs noise, float coef, uint64_t seed, uin
     hipLaunchKernelGGL(churn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, noise, coef, seed, step, flags, xhat, d);
 }
 
-__global__ void init_kernel(CStatePtrs init, float scale, uint64_t seed, const uint8_t *flags, StatePtrs x, Dims d) {
+__global__ void init_kernel(CStatePtrs init, float scale, uint64_t seed, uint32_t stream, const uint8_t *flags, StatePtrs x, Dims d) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total_elems(d)) return;
     const ElemIdx e = elem_index(idx, d, flags);
     float v;
     if (init.adj) v = e.is_adj ? init.adj[e.off] : init.node[e.off];
-    else v = philox_normal(seed, 0u, idx);                       // gen_init_sample, edm.py:279,285
+    else v = philox_normal(seed, stream, idx);                   // stream 0: gen_init_sample, edm.py:279,285
     v = e.valid ? FMUL(v, scale) : 0.f;                          // edm.py:346-347
     if (e.is_adj) x.adj[e.off] = v; else x.node[e.off] = v;
 }
-void launch_init(CStatePtrs init, float scale, uint64_t seed, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s) {
+void launch_init(CStatePtrs init, float scale, uint64_t seed, uint32_t stream, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s) {
     const size_t n = total_elems(d);
-    hipLaunchKernelGGL(init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, init, scale, seed, flags, x, d);
+    hipLaunchKernelGGL(init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, init, scale, seed, stream, flags, x, d);
 }
 
 __global__ void euler_kernel(CStatePtrs xhat, CStatePtrs D, float inv_t, float h, const uint8_t *flags, StatePtrs x, Dims d) {

@@ -15,6 +15,7 @@ EXPORTS = [
     "dsg_create", "dsg_destroy", "dsg_last_error", "dsg_version", "dsg_set_weight", "dsg_finalize_weights",
     "dsg_num_weight_keys", "dsg_weight_key", "dsg_workspace_bytes", "dsg_denoise", "dsg_precond", "dsg_sample",
     "dsg_sigma_schedule", "dsg_debug_tap", "dsg_debug_clear_taps", "dsg_decode_bits", "dsg_profile_forward", "dsg_set_option",
+    "dsg_get_option", "dsg_gen_noise",
 ]
 
 
@@ -79,6 +80,8 @@ def load() -> C.CDLL:
     L.dsg_debug_clear_taps.argtypes = [vp]
     L.dsg_debug_clear_taps.restype = None
     L.dsg_set_option.argtypes = [vp, C.c_char_p, i32]
+    L.dsg_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i32)]
+    L.dsg_gen_noise.argtypes = [vp, i32, vp, C.c_uint64, C.c_uint32, vp, vp, vp]
     L.dsg_profile_forward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     L.dsg_decode_bits.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     _lib = L
@@ -147,6 +150,15 @@ class Handle:
 
     def set_option(self, name: str, value: int):
         self.check(self.L.dsg_set_option(self._h, name.encode(), int(value)), f"dsg_set_option({name})")
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int32(0)
+        self.check(self.L.dsg_get_option(self._h, name.encode(), C.byref(v)), f"dsg_get_option({name})")
+        return int(v.value)
+
+    def precision_mode(self) -> str:
+        """'f32' | 'f32-split' | 'bf16': the GEMM arithmetic the handle will actually run (options or DSG_* env defaults)."""
+        return "f32-split" if self.get_option("gemm_split") else ("bf16" if self.get_option("gemm_bf16") else "f32")
 
     def finalize(self):
         self.check(self.L.dsg_finalize_weights(self._h), "dsg_finalize_weights")

@@ -72,6 +72,21 @@ class NodeAdjEDMSamplerHip(object):
         return np.array([np.random.rand() < 0.5 for _ in range(n_calls)], dtype=np.uint8)
 
     @torch.no_grad()
+    def device_noise(self, model, node_flags, stream: int = 0, seed=None):
+        """The library's Philox stream `stream` for this batch, on the device: stream 0 is what `sample()` uses as
+        gen_init_sample (edm.py:257-289: masked, unscaled), stream i+1 its churn noise of step i (edm.py:361-364)."""
+        net = getattr(model, "module", model).model
+        h, cfg, dev = net._ensure_handle(), net.config, net._dev
+        B, n = node_flags.shape[0], cfg.max_node_num
+        fl = node_flags.to(device=dev).to(torch.uint8).contiguous()
+        a = torch.empty((B, cfg.c_adj, n, n), dtype=torch.float32, device=dev)
+        x = torch.empty((B, n, cfg.c_node), dtype=torch.float32, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        h.check(h.L.dsg_gen_noise(h.raw, B, C.c_void_p(fl.data_ptr()), C.c_uint64(self.seed if seed is None else int(seed)),
+                                  int(stream), C.c_void_p(a.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(st)), "dsg_gen_noise")
+        return a, x
+
+    @torch.no_grad()
     def sample(self, model, node_flags, init_adjs=None, init_nodes=None,
                sanity_check_gt_adjs=None, sanity_check_gt_nodes=None,
                flag_interim_adjs=False, max_num_interim_adjs=None, flag_use_double=False,
@@ -79,7 +94,8 @@ class NodeAdjEDMSamplerHip(object):
                num_node_chan=150, num_edge_chan=51, churn_noise=None, coins=None, seed=None, return_device=False):
         """See NodeAdjEDMSampler.sample (edm.py:291).  Extra keyword-only knobs (not in the reference):
         `churn_noise=(adj [T,B,..], node [T,B,..])` and `coins` replay recorded randomness (parity tests);
-        `seed` seeds the on-device Philox streams; `return_device=True` skips the final `.cpu()`."""
+        `seed` seeds the on-device Philox streams (default self.seed; the reference seeds torch per rank,
+        arg_parser.py:293-294 -- set `sampler.seed = base_seed + rank`); `return_device=True` skips the final `.cpu()`."""
         if flag_use_double:
             raise NotImplementedError("flag_use_double: the HIP path computes in fp32 (the reference default)")
         if isinstance(model, (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel)):
@@ -127,11 +143,17 @@ class NodeAdjEDMSamplerHip(object):
         scfg = self._cfg()
         st = torch.cuda.current_stream(dev).cuda_stream
         p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
-        init_keep = None
+        seed_v = self.seed if seed is None else int(seed)
         if flag_interim_adjs and ia is None:
-            raise NotImplementedError("interim snapshots with library-drawn initial noise: pass init_adjs/init_nodes")
+            # The reference's own call (sampler_node_adj.py:166-177) passes init_adjs=None with flag_interim_adjs=True and
+            # reads slot 0 of the snapshot list as the UNSCALED initial sample (edm.py:326-337).  Draw the library's
+            # init stream (noise stream 0) into caller-visible buffers first; handing them back in is bit-identical
+            # to letting dsg_sample draw them itself.
+            ia = torch.empty(sa, dtype=torch.float32, device=dev)
+            inn = torch.empty(sn, dtype=torch.float32, device=dev)
+            h.check(h.L.dsg_gen_noise(h.raw, B, p(fl), C.c_uint64(seed_v), 0, p(ia), p(inn), C.c_void_p(st)), "dsg_gen_noise")
         h.check(h.L.dsg_sample(h.raw, C.byref(scfg), B, p(fl), p(ia), p(inn), p(na), p(nn_),
-                               C.c_void_p(coins.ctypes.data), C.c_uint64(self.seed if seed is None else int(seed)),
+                               C.c_void_p(coins.ctypes.data), C.c_uint64(seed_v),
                                p(ga), p(gn),
                                C.c_void_p(0 if snap_steps is None else snap_steps.ctypes.data),
                                0 if snap_steps is None else len(snap_steps), p(snap_a), p(snap_n),
@@ -147,9 +169,12 @@ class NodeAdjEDMSamplerHip(object):
             return oa, on
         adjs, nodes = oa.cpu(), on.cpu()
         if flag_interim_adjs:
-            nodes_ls = torch.cat([inn.cpu().reshape((1,) + sn), snap_n.cpu()])
+            # torch.stack(nodes_ls) of edm.py:441-443: slot 0 = unscaled init, then one entry per snapshot step
+            sq_n = (lambda t: t[..., 0]) if cfg.c_node == 1 else (lambda t: t)
+            sq_a = (lambda t: t[:, :, 0]) if cfg.c_adj == 1 else (lambda t: t)
+            nodes_ls = sq_n(torch.cat([inn.cpu().reshape((1,) + sn), snap_n.cpu()]))
             if flag_adj_multi_channel:
                 return adjs, nodes, [None], nodes_ls
-            adjs_ls = torch.cat([ia.cpu().reshape((1,) + sa), snap_a.cpu()])
+            adjs_ls = sq_a(torch.cat([ia.cpu().reshape((1,) + sa), snap_a.cpu()]))
             return adjs, nodes, adjs_ls, nodes_ls
         return adjs, nodes

@@ -35,7 +35,7 @@ CONFIGS = {"tiny": S.tiny_config, "small": small_config, "nosc": nosc_config,
            "vg": S.vg_config, "coco": S.coco_config, "onehot": onehot_config}
 
 # ragged numbers of valid nodes per sample used by the forward / precond goldens
-VALID = {"tiny": [8, 5], "small": [16, 9], "nosc": [8, 3], "vg": [30, 11], "coco": [20, 40]}
+VALID = {"tiny": [8, 5], "small": [16, 9], "nosc": [8, 3], "vg": [30, 11], "coco": [20, 40], "onehot": [8, 5]}
 
 FWD_C_NOISE = np.array([0.35, -1.2], dtype=np.float32)
 PRECOND_SIGMAS = (80.0, 1.5, 0.002)
@@ -88,3 +88,22 @@ def gt_case(cfg: S.ModelConfig, B: int, valid, seed: int = 3):
 # (name in sampler.npz, T, solver, S_churn)
 SAMPLER_RUNS = (("t8_heun", 8, "heun", 40.0), ("t50_heun", 50, "heun", 40.0), ("t8_euler", 8, "euler", 0.0))
 SAMPLER_VALID = [8, 5, 3, 8]
+
+
+# ---- post-decode fixture (sampler_node_adj.py:222-285): 'bits' samples -> integer graphs + bbox ----
+# (dataset name, raw #edge types, raw #node types) per config; B = 3 with full / ragged / nearly-empty flags
+DECODE_CASES = {"vg": ("visual_genome", 51, 150, [30, 64, 2]), "coco": ("coco_stuff", 7, 171, [20, 40, 1])}
+
+
+def decode_case(name: str):
+    """flags, raw adj [B,C_adj,N,N], raw node [B,N,C_node] as the sampler would return them: values beyond [-1,1] (the
+    decode clamps first), exact zeros on valid entries (0 is NOT > 0: bit 0) and every bit pattern, so codes above
+    n_type-1 occur (6 adjacency bits reach 63 > 50, 8 node bits reach 255 > 149) and must be clamped."""
+    cfg = CONFIGS[name]()
+    n, B = cfg.max_node_num, 3
+    flags = W.synth_flags(B, n, DECODE_CASES[name][3])
+    adj = (W.normal(9, f"dec/{name}/adj", (B, cfg.c_adj, n, n)) * np.float32(1.5)).astype(np.float32)
+    node = (W.normal(9, f"dec/{name}/node", (B, n, cfg.c_node)) * np.float32(1.5)).astype(np.float32)
+    adj.reshape(-1)[::7] = 0.0
+    node.reshape(-1)[::5] = 0.0
+    return cfg, flags, adj, node

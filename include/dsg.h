@@ -123,6 +123,15 @@ int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_
                const int32_t *snap_steps, int32_t n_snap, float *snap_adj, float *snap_node,
                float *out_adj, float *out_node, dsg_sample_stats *stats, void *stream);
 
+/* The library's device noise streams (Philox4x32-10 keyed by `seed`, Box-Muller): what dsg_sample draws when it is handed
+ * NULL init / NULL churn noise.  noise_stream 0 = the initial sample of gen_init_sample (edm.py:257-289: randn, rows and
+ * columns of padded nodes zeroed, NOT yet scaled by sigma(t0)); noise_stream i+1 = the churn noise of step i (the
+ * randn_like draws of edm.py:361-364).  Writes mask(eps) in the layouts above.  dsg_sample(init = this output) is
+ * bit-identical to dsg_sample(init = NULL) with the same seed, so a caller that needs the unscaled init back
+ * (nodes_ls[0] of edm.py:326-337) draws it here first. */
+int dsg_gen_noise(dsg_handle h, int32_t B, const uint8_t *flags, uint64_t seed, uint32_t noise_stream,
+                  float *out_adj, float *out_node, void *stream);
+
 /* sigma_steps (fp64, edm.py:84-88) and the fp32 per-step scalars the loop uses; out arrays of
  * length num_steps.  Host-only helper, exposed so bindings/tests can inspect the schedule. */
 int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t_hat, float *noise_coef,
@@ -138,6 +147,9 @@ int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t
  *       softmax and the sampler stay fp32) -- BASELINE config 5; parity against the fp32 oracle then holds to 1.5e-2 RMS /
  *       5e-2 max-abs of the output scale, not 1e-4.  "gemm_split" takes precedence if both are set. */
 int dsg_set_option(dsg_handle h, const char *name, int32_t value);
+/* The value an option currently has on this handle (what the next forward will run with), whichever way it was set
+ * (dsg_set_option or a DSG_* environment default): measurement code reports the precision mode from here. */
+int dsg_get_option(dsg_handle h, const char *name, int32_t *value);
 
 /* Measurement: runs n_iters eager network forwards on the batch-B workspace (whatever inputs the last call left
  * there) with HIP events bracketing every kernel launch on `stream`, and accumulates per kernel class

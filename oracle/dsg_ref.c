@@ -673,3 +673,54 @@ NO_FMA int dsgref_sample(dsgref *h, const dsgref_sampler_cfg *c, int B, const ui
     free(dca); free(dcn); free(sca); free(scn); free(sig_b);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* post-decode of 'bits' samples                                                */
+/* ------------------------------------------------------------------------------------------ */
+/* R/runner/sampler/sampler_node_adj.py:222-285 ('bits' branches of _decode_node / _decode_adj) with
+ * bin2dec of R/utils/attribute_code.py:319-328 (channel 0 is the most significant bit) and the bbox
+ * handling of :201-209.  Step by step as the reference: clamp(-1,1); > 0 -> bit; mask; sum(bit * 2^k);
+ * mask; clamp to [0, n_type-1]; zero the adjacency diagonal.  node_bits = C_node - 4 when the last four
+ * node channels are the bounding box (out_bbox != NULL), else C_node.
+ * Pinned by tests/golden/decode.npz (tests/test_oracle_golden.py::test_decode_bits_matches_reference). */
+int dsgref_decode_bits(dsgref *h, int B, const float *adj, const float *node, const uint8_t *flags, int n_adj_type,
+                       int n_node_type, int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox) {
+    const int N = h->N, Ca = h->c_adj, Cn = h->c_node;
+    for (int b = 0; b < B; b++) {
+        const uint8_t *f = flags + (size_t)b * N;
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < N; j++) {
+                long v = 0;
+                for (int c = 0; c < Ca; c++) {
+                    float x = adj[(((size_t)b * Ca + c) * N + i) * N + j];
+                    x = fminf(fmaxf(x, -1.0f), 1.0f);                       /* :243 clamp */
+                    const int bit = (x > 0.0f) && f[i] && f[j];             /* :245-247, :268-269 */
+                    v += (long)bit << (Ca - 1 - c);                         /* bin2dec: mask = 2^(num_bits-1 .. 0) */
+                }
+                if (!(f[i] && f[j])) v = 0;                                 /* :275 mask_adjs */
+                if (v < 0) v = 0;
+                if (v > n_adj_type - 1) v = n_adj_type - 1;                 /* :275 clamp */
+                if (i == j) v = 0;                                          /* :281 remove self loops */
+                out_adj[((size_t)b * N + i) * N + j] = (int32_t)v;
+            }
+        for (int i = 0; i < N; i++) {
+            long v = 0;
+            for (int c = 0; c < node_bits; c++) {
+                float x = node[((size_t)b * N + i) * Cn + c];
+                x = fminf(fmaxf(x, -1.0f), 1.0f);                           /* :223 */
+                const int bit = (x > 0.0f) && f[i];                         /* :225-230 */
+                v += (long)bit << (node_bits - 1 - c);
+            }
+            if (!f[i]) v = 0;
+            if (v < 0) v = 0;
+            if (v > n_node_type - 1) v = n_node_type - 1;                   /* :232 */
+            out_node[(size_t)b * N + i] = (int32_t)v;
+            if (out_bbox)
+                for (int c = 0; c < 4; c++) {                               /* :201-209 */
+                    const float x = node[((size_t)b * N + i) * Cn + (Cn - 4) + c];
+                    out_bbox[((size_t)b * N + i) * 4 + c] = f[i] ? x * 0.5f + 0.5f : 0.0f;
+                }
+        }
+    }
+    return 0;
+}

@@ -48,6 +48,7 @@ def lib():
         L.dsgref_precond.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 2
         L.dsgref_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10
         L.dsgref_sigma_steps.argtypes = [C.c_void_p, C.c_void_p]
+        L.dsgref_decode_bits.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 3
         _lib = L
     return _lib
 
@@ -150,3 +151,17 @@ class Oracle:
         lib().dsgref_sample(self._h, C.byref(c), B, _p(fl), _p(init_adj), _p(init_node), _p(noise_adj), _p(noise_node),
                             _p(co), _p(gt_adj), _p(gt_node), _p(oa), _p(on))
         return oa, on
+
+    def decode_bits(self, adj, node, flags, n_adj_type, n_node_type, bbox=True):
+        """'bits' samples -> (q_adj [B,N,N] int32, q_node [B,N] int32, bbox [B,N,4] | None); sampler_node_adj.py:222-285"""
+        B = flags.shape[0]
+        sa, sn = self._shapes(B)
+        c = self.cfg
+        adj, node = _f32(adj).reshape(sa), _f32(node).reshape(sn)
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        qa = np.empty((B, c.max_node_num, c.max_node_num), np.int32)
+        qn = np.empty((B, c.max_node_num), np.int32)
+        bb = np.empty((B, c.max_node_num, 4), np.float32) if bbox else None
+        lib().dsgref_decode_bits(self._h, B, _p(adj), _p(node), _p(fl), int(n_adj_type), int(n_node_type),
+                                 c.c_node - 4 if bbox else c.c_node, _p(qa), _p(qn), _p(bb))
+        return qa, qn, bb

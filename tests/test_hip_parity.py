@@ -26,7 +26,7 @@ def T(x):
     return None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()
 
 
-@pytest.mark.parametrize("name", ["tiny", "small", "nosc", "vg", "coco"])
+@pytest.mark.parametrize("name", ["tiny", "small", "nosc", "vg", "coco", "onehot"])
 def test_forward_vs_reference_golden(name):
     cfg, flags, adj, node, sc_adj, sc_node = Y.fwd_case(name)
     g = load(f"fwd_{name}.npz")
@@ -188,43 +188,140 @@ def test_sampler_device_rng_statistics():
     assert (a1 - a2).abs().max() > 1e-3
 
 
-def test_init_noise_moments():
-    """Philox N(0,1): with GT bypass and T=1 Euler the state after init is not observable, so check the
-    churn-free 1-step identity instead: x0 = eps*80 must have ~unit variance / 80^2 on valid entries."""
+def test_reference_caller_form_verbatim():
+    """The call sg_go_sampling makes (sampler_node_adj.py:166-177), keyword for keyword: init None, interim snapshots on,
+    max_num_interim_adjs=10, multi-channel flags, channel counts from get_node_adj_num_type (bits + bbox: 12 / 6).
+    Returns the 4-tuple of edm.py:439-443 with nodes_ls[0] = the UNSCALED init (edm.py:326-337)."""
     cfg = Y.CONFIGS["tiny"]()
-    B = 256
-    flags = W.synth_flags(B, cfg.max_node_num, 8)
-    zero_a = np.zeros((B, cfg.c_adj, 8, 8), np.float32)
-    zero_n = np.zeros((B, 8, cfg.c_node), np.float32)
-    smp = make_sampler(2, solver="euler", S_churn=0.0)
-    # with D == 0 one Euler step gives x1 = x0*(t1/t0); the second (last) step gives exactly 0, so look at snapshots
-    from diffusesg_amd import lib as L
-    th = L.sigma_schedule(smp._cfg())[1]
-    with pytest.raises(NotImplementedError):
-        smp.sample(net_for("tiny"), T(flags), sanity_check_gt_adjs=T(zero_a), sanity_check_gt_nodes=T(zero_n),
-                   flag_interim_adjs=True, num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
-    assert th[0] == 80.0
+    B, n, T_ = 4, cfg.max_node_num, 20
+    model, mc_sampler = net_for("tiny"), make_sampler(T_)
+    mc_sampler.seed = 1234 + 0          # arg_parser.py:293-294: seed += rank
+    sample_node_flags = torch.from_numpy(W.synth_flags(B, n, Y.SAMPLER_VALID)).cuda()
+    init_adjs_sampler = init_nodes_sampler = None
+    sanity_check, max_num_interim_adjs = False, 10
+    test_adjs_gt = test_nodes_gt = None   # only read when sanity_check is on
+    flag_node_multi_channel = flag_edge_multi_channel = True
+    num_node_type, num_adj_type = 12, 6
+    np.random.seed(5)
+    final_samples_adjs, final_samples_nodes, interim_samples_adjs, interim_samples_nodes = mc_sampler.sample(
+        model=model, node_flags=sample_node_flags,
+        init_adjs=init_adjs_sampler, init_nodes=init_nodes_sampler,
+        flag_interim_adjs=True,
+        sanity_check_gt_adjs=test_adjs_gt if sanity_check else None,
+        sanity_check_gt_nodes=test_nodes_gt if sanity_check else None,
+        max_num_interim_adjs=max_num_interim_adjs,
+        flag_node_multi_channel=flag_node_multi_channel,
+        flag_adj_multi_channel=flag_edge_multi_channel,
+        num_node_chan=num_node_type,
+        num_edge_chan=num_adj_type,
+    )
+    steps = np.unique(np.linspace(0, T_, max_num_interim_adjs).astype(int).clip(max=T_ - 1))
+    assert not final_samples_adjs.is_cuda and not interim_samples_nodes.is_cuda
+    assert final_samples_adjs.shape == (B, 6, n, n) and final_samples_nodes.shape == (B, n, 12)
+    assert interim_samples_adjs == [None]                                     # edm.py:440-441
+    assert interim_samples_nodes.shape == (1 + len(steps), B, n, 12) and len(steps) <= max_num_interim_adjs
+    assert torch.equal(interim_samples_nodes[-1], final_samples_nodes)        # step T-1 is always a snapshot step
+    ia, inn = mc_sampler.device_noise(model, sample_node_flags, stream=0)
+    assert torch.equal(interim_samples_nodes[0], inn.cpu())                   # unscaled init, not init * sigma_max
+    f = sample_node_flags.cpu()
+    assert 0.5 < float(interim_samples_nodes[0][f].std()) < 1.5 and torch.all(interim_samples_nodes[0][~f] == 0)
+    # handing the same init back explicitly, with the same coin stream, is the same run bit for bit
+    np.random.seed(5)
+    a2, n2, adjs_ls, nodes_ls = mc_sampler.sample(model=model, node_flags=sample_node_flags, init_adjs=ia, init_nodes=inn,
+                                                  flag_interim_adjs=True, max_num_interim_adjs=max_num_interim_adjs,
+                                                  flag_node_multi_channel=True, flag_adj_multi_channel=False,
+                                                  num_node_chan=12, num_edge_chan=6)
+    assert torch.equal(a2, final_samples_adjs) and torch.equal(n2, final_samples_nodes)
+    assert torch.equal(nodes_ls, interim_samples_nodes)
+    assert adjs_ls.shape == (1 + len(steps), B, 6, n, n) and torch.equal(adjs_ls[0], ia.cpu()) and torch.equal(adjs_ls[-1], a2)
+    # and without snapshots the library draws the init itself: same result again
+    np.random.seed(5)
+    a3, n3 = mc_sampler.sample(model, sample_node_flags, num_node_chan=12, num_edge_chan=6)
+    assert torch.equal(a3, final_samples_adjs) and torch.equal(n3, final_samples_nodes)
 
 
-def test_decode_bits_matches_numpy():
-    cfg = Y.CONFIGS["vg"]()
-    n, B = cfg.max_node_num, 3
-    flags = W.synth_flags(B, n, [30, 64, 2])
-    adj = W.normal(9, "dec/adj", (B, cfg.c_adj, n, n))
-    node = W.normal(9, "dec/node", (B, n, cfg.c_node))
+def _moments(x):
+    x = np.asarray(x, np.float64).ravel()
+    m = x.mean()
+    v = x.var()
+    return m, v, ((x - m) ** 4).mean() / v ** 2
+
+
+def _corr(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.corrcoef(a, b)[0, 1])
+
+
+@pytest.mark.parametrize("name,B", [("tiny", 256), ("vg", 8)])
+def test_device_noise_is_standard_normal_and_streams_are_independent(name, B):
+    """The Philox/Box-Muller streams the throughput path draws from (init = stream 0, churn of step i = stream i+1):
+    mean / variance / kurtosis of N(0,1) within 4 standard errors, no correlation across seeds (= ranks: seed + rank,
+    arg_parser.py:293-294), across streams (= steps), between neighbouring elements, and exact zeros on padded nodes."""
+    cfg = Y.CONFIGS[name]()
+    n = cfg.max_node_num
+    smp = make_sampler(4)
+    net = net_for(name)
+    full = torch.ones(B, n, dtype=torch.bool, device="cuda")
+    draws = {}
+    for seed, stream in ((1234, 0), (1235, 0), (1234, 1), (1234, 2), (99991, 7)):
+        a, x = smp.device_noise(net, full, stream=stream, seed=seed)
+        draws[(seed, stream)] = np.concatenate([a.cpu().numpy().ravel(), x.cpu().numpy().ravel()])
+    cnt = draws[(1234, 0)].size
+    se = 1.0 / np.sqrt(cnt)
+    for key, v in draws.items():
+        m, var, kurt = _moments(v)
+        assert abs(m) < 4 * se, f"{key}: mean {m:.4f}"
+        assert abs(var - 1.0) < 4 * np.sqrt(2.0) * se, f"{key}: variance {var:.4f}"
+        assert abs(kurt - 3.0) < 4 * np.sqrt(24.0) * se, f"{key}: kurtosis {kurt:.4f}"
+        assert abs(_corr(v[:-1], v[1:])) < 4 * se, f"{key}: lag-1 autocorrelation"
+        assert np.abs(v).max() < 6.5 and np.isfinite(v).all()
+    base = draws[(1234, 0)]
+    for key in ((1235, 0), (1234, 1), (1234, 2), (99991, 7)):
+        assert abs(_corr(base, draws[key])) < 4 * se, f"stream (1234,0) vs {key} correlated"
+        assert not np.array_equal(base, draws[key])
+    assert abs(_corr(draws[(1234, 1)], draws[(1234, 2)])) < 4 * se
+    # deterministic per (seed, stream); padded rows / columns exactly zero; valid entries unchanged by the mask
+    ragged = torch.from_numpy(W.synth_flags(B, n, [n, max(1, n // 2), 1])).cuda()
+    a, x = smp.device_noise(net, ragged, stream=0, seed=1234)
+    a2, x2 = smp.device_noise(net, ragged, stream=0, seed=1234)
+    assert torch.equal(a, a2) and torch.equal(x, x2)
+    assert torch.all(x[~ragged] == 0) and torch.all(a.permute(0, 2, 3, 1)[~ragged] == 0) and torch.all(a.permute(0, 3, 2, 1)[~ragged] == 0)
+    af, xf = smp.device_noise(net, full, stream=0, seed=1234)
+    assert torch.equal(x[ragged], xf[ragged])
+
+
+def test_sampler_device_streams_are_the_ones_exposed():
+    """dsg_sample with NULL init / NULL churn noise == dsg_sample fed stream 0 as init and stream i+1 as step i's churn noise"""
+    cfg = Y.CONFIGS["tiny"]()
+    T_, B = 6, 4
+    flags = torch.from_numpy(W.synth_flags(B, cfg.max_node_num, Y.SAMPLER_VALID)).cuda()
+    smp = make_sampler(T_)
+    coins = np.array([1, 0, 0, 1, 1, 0, 1, 0, 0, 1, 1], np.uint8)
+    a0, n0 = smp.sample(net_for("tiny"), flags, coins=coins, seed=77, num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    ia, inn = smp.device_noise(net_for("tiny"), flags, stream=0, seed=77)
+    ch = [smp.device_noise(net_for("tiny"), flags, stream=i + 1, seed=77) for i in range(T_)]
+    na, nn = torch.stack([c[0] for c in ch]), torch.stack([c[1] for c in ch])
+    a1, n1 = smp.sample(net_for("tiny"), flags, init_adjs=ia, init_nodes=inn, churn_noise=(na, nn), coins=coins, seed=1,
+                        num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    assert torch.equal(a0, a1) and torch.equal(n0, n1)
+
+
+@pytest.mark.parametrize("name", ["vg", "coco"])
+def test_decode_bits_vs_reference_fixture(name):
+    """dsg_decode_bits against tests/golden/decode.npz (the reference's _decode_node/_decode_adj 'bits' branch around its own
+    bin2dec, tools/gen_golden.py::gen_decode): BIT-EXACT on integer graphs and bbox; inputs hold values beyond [-1,1],
+    exact zeros and bit patterns above n_type-1"""
     from diffusesg_amd import io as dio
-    oa, on, ob = dio.decode_bits(net_for("vg"), T(adj), T(node), T(flags), n_adj_type=51, n_node_type=150)
-    torch.cuda.synchronize()
-    # numpy restatement of sampler_node_adj.py:222-285 (MSB-first bin2dec, clamp, mask, no self loops)
-    f = flags.astype(bool)
-    bits_a = (adj > 0).astype(np.int64)
-    qa = sum(bits_a[:, c] << (cfg.c_adj - 1 - c) for c in range(cfg.c_adj)).clip(0, 50)
-    qa = qa * (f[:, :, None] & f[:, None, :]) * (1 - np.eye(n, dtype=np.int64))[None]
-    bits_n = (node[..., :8] > 0).astype(np.int64)
-    qn = (sum(bits_n[..., c] << (7 - c) for c in range(8)).clip(0, 149)) * f
-    bb = (node[..., -4:] * 0.5 + 0.5) * f[..., None]
-    assert np.array_equal(oa.cpu().numpy(), qa) and np.array_equal(on.cpu().numpy(), qn)
-    np.testing.assert_allclose(ob.cpu().numpy(), bb, rtol=0, atol=1e-7)
+    g = load("decode.npz")
+    cfg, flags, adj, node = Y.decode_case(name)
+    _, n_adj, n_node, _ = Y.DECODE_CASES[name]
+    oa, on, ob = dio.decode_bits(net_for(name), T(adj), T(node), T(flags), n_adj_type=n_adj, n_node_type=n_node)
+    assert np.array_equal(oa.cpu().numpy(), g[f"{name}_q_adj"].astype(np.int32)), "q_adj"
+    assert np.array_equal(on.cpu().numpy(), g[f"{name}_q_node"].astype(np.int32)), "q_node"
+    assert np.array_equal(ob.cpu().numpy(), g[f"{name}_bbox"]), "bbox"
+    # the packed int16 hand-off of the decoded graphs is lossless
+    a2, n2, f2, b2 = dio.unpack_decoded(dio.pack_decoded(oa, on, ob, T(flags)), cfg.max_node_num, True)
+    assert torch.equal(a2, oa) and torch.equal(n2, on) and torch.equal(b2, ob) and torch.equal(f2.cpu(), torch.from_numpy(flags))
 
 
 def test_end_to_end_checkpoint_sample_decode_npz(tmp_path):
@@ -232,11 +329,17 @@ def test_end_to_end_checkpoint_sample_decode_npz(tmp_path):
     from diffusesg_amd import io as dio
     from diffusesg_amd.model import build_network
     cfg = Y.CONFIGS["tiny"]()
-    sd = {k: torch.from_numpy(v) for k, v in W.synth_state_dict(cfg, 0, prefix="model.").items()}
+    from test_host_logic import reference_style_checkpoint
     path = str(tmp_path / "tiny_00001.pth")
-    torch.save({"model": sd, "config": {}, "epoch": 1, "train_loss": 0.0, "test_loss": 0.0}, path)
+    reference_style_checkpoint(cfg, path, numpy1_names=True)   # np.float64 losses, nested config, 'module.'-prefixed EMA copy
     net = build_network(cfg, device="cuda")
-    dio.load_model(dio.load_checkpoint(path), net, "model")
+    ck = dio.load_checkpoint(path)
+    dio.load_model(ck, net, "model_ema_beta_0.9990")           # the DDP-prefixed EMA copy (weights * 0.5): must NOT match the golden
+    flags, ia, inn, na, nn, cv = Y.sampler_case(cfg, 8, 4, Y.SAMPLER_VALID, 3, "smp/t8_heun", "heun")
+    o_ema, _ = make_sampler(8).sample(net, T(flags), init_adjs=T(ia), init_nodes=T(inn), churn_noise=(T(na), T(nn)),
+                                      coins=(cv < 0.5).astype(np.uint8), num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    assert rel_err(o_ema.numpy(), load("sampler.npz")["t8_heun_adj"]) > 1e-2
+    dio.load_model(ck, net, "model")
     flags, ia, inn, na, nn, cv = Y.sampler_case(cfg, 8, 4, Y.SAMPLER_VALID, 3, "smp/t8_heun", "heun")
     smp = make_sampler(8)
     oa, on = smp.sample(net, T(flags), init_adjs=T(ia), init_nodes=T(inn), churn_noise=(T(na), T(nn)),
@@ -296,20 +399,23 @@ def test_odd_batch_sizes_vs_oracle(name, B):
     assert_close(on.cpu().numpy(), rn, FWD_RTOL, f"{name} B={B} node")
 
 
-def test_repeatability_and_graph_equivalence():
-    """same inputs twice -> bitwise identical outputs (no atomics-order dependence in the forward except the pooled
-    node head, which is checked to tolerance), eager vs hipGraph replay identical"""
-    cfg = Y.CONFIGS["tiny"]()
-    flags, ia, inn, na, nn, cv = Y.sampler_case(cfg, 8, 4, Y.SAMPLER_VALID, 3, "smp/t8_heun", "heun")
+@pytest.mark.parametrize("name", ["tiny", "coco"])
+def test_repeatability_and_graph_equivalence(name):
+    """same inputs twice -> BITWISE identical outputs (the forward has no atomics: the node head's pooling is a
+    fixed-order reduction), and eager launches vs hipGraph replay are bitwise identical too.  'coco' (N = 40) is the
+    case where a pooled row straddles up to three 32-token tiles."""
+    cfg = Y.CONFIGS[name]()
+    n = cfg.max_node_num
+    flags, ia, inn, na, nn, cv = Y.sampler_case(cfg, 6, 4, [n, max(2, n // 2), 3, n], 3, f"rep/{name}", "heun")
     coins = (cv < 0.5).astype(np.uint8)
     outs = []
     for use_graph in (True, True, False):
-        smp = make_sampler(8, use_graph=use_graph)
-        oa, on = smp.sample(net_for("tiny"), T(flags), init_adjs=T(ia), init_nodes=T(inn), churn_noise=(T(na), T(nn)), coins=coins,
+        smp = make_sampler(6, use_graph=use_graph)
+        oa, on = smp.sample(net_for(name), T(flags), init_adjs=T(ia), init_nodes=T(inn), churn_noise=(T(na), T(nn)), coins=coins,
                             num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
-        outs.append((oa, on))
-    assert rel_err(outs[0][0].numpy(), outs[1][0].numpy()) < 1e-5 and rel_err(outs[0][0].numpy(), outs[2][0].numpy()) < 1e-5
-    assert rel_err(outs[0][1].numpy(), outs[2][1].numpy()) < 1e-5
+        outs.append((oa.numpy(), on.numpy()))
+    for k in (1, 2):
+        assert np.array_equal(outs[0][0], outs[k][0]) and np.array_equal(outs[0][1], outs[k][1]), f"run {k} differs from run 0"
 
 
 def test_vg_full_size_short_trajectory_vs_oracle():

@@ -94,18 +94,50 @@ def test_gather_world2_gloo():
     assert not np.array_equal(res[0][2], res[1][2])                              # seeds differ by rank
 
 
-def test_checkpoint_roundtrip(tmp_path):
-    """A file in the reference's checkpoint layout (trainer_utils.py:168-185), incl. DDP 'module.' keys and EMA copies."""
-    from diffusesg_amd import io as dio
+def reference_style_checkpoint(cfg, path, numpy1_names=False):
+    """A file shaped like the one `get_ckpt_data` writes (trainer_utils.py:168-185): 'model' keys carry the precond
+    wrapper's 'model.' prefix, `config` is the nested `config.to_dict()` (incl. the torch.device of arg_parser.py:352),
+    `train_loss` / `test_loss` are NumPy float64 scalars (np.concatenate(...).mean(), :160-161), one EMA state dict per
+    beta, here saved from a DDP-wrapped model ('module.' prefix).  numpy1_names rewrites the pickle to the module path
+    NumPy 1.x (the reference's pin) stores for a scalar."""
+    import zipfile
     from diffusesg_amd import weights as W
-    from diffusesg_amd.model import build_network
-    cfg = spec.tiny_config()
     sd = {k: torch.from_numpy(v) for k, v in W.synth_state_dict(cfg, 0, prefix="model.").items()}
     ema = {"module." + k: v * 0.5 if v.dtype == torch.float32 else v for k, v in sd.items()}
-    path = str(tmp_path / "tiny_00010.pth")
-    torch.save({"model": sd, "config": {"seed": 1234}, "epoch": 10, "train_loss": 0.1, "test_loss": 0.2,
+    conf = {"seed": 1234, "dev": torch.device("cpu"), "dataset": {"name": "visual_genome", "max_node_num": 64, "subset": None},
+            "mcmc": {"name": "edm", "num_steps": 256, "sample_clip": {"min": -1.0, "max": 1.0, "scope": "x_0"}},
+            "model": {"feature_dims": [96], "depths": [1, 1, 3, 1]}, "train": {"lr_init": 2e-4, "self_cond": True, "ema_coef": [0.9, 0.999]}}
+    losses = np.array([0.25, 0.75, 0.5])
+    torch.save({"model": sd, "config": conf, "epoch": 10, "train_loss": losses.mean(), "test_loss": np.float64(0.2),
                 "model_ema_beta_0.9990": ema}, path)
+    assert isinstance(losses.mean(), np.float64)
+    if numpy1_names:
+        src = zipfile.ZipFile(path)
+        blobs = {n: src.read(n) for n in src.namelist()}
+        src.close()
+        with zipfile.ZipFile(path, "w", zipfile.ZIP_STORED) as out:
+            for n, b in blobs.items():
+                if n.endswith("data.pkl"):
+                    assert b.count(b"numpy._core.multiarray") >= 1
+                    b = b.replace(b"numpy._core.multiarray", b"numpy.core.multiarray")
+                out.writestr(n, b)
+    return sd
+
+
+@pytest.mark.parametrize("numpy1_names", [False, True])
+def test_checkpoint_roundtrip(tmp_path, numpy1_names):
+    """the reference's checkpoint layout loads through the no-code loader: NumPy-scalar losses, nested config, DDP
+    'module.' keys, EMA copies; a plain weights_only load refuses the same file (that is what round 1 did)"""
+    from diffusesg_amd import io as dio
+    from diffusesg_amd.model import build_network
+    cfg = spec.tiny_config()
+    path = str(tmp_path / "tiny_00010.pth")
+    sd = reference_style_checkpoint(cfg, path, numpy1_names)
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu", weights_only=True)
     ck = dio.load_checkpoint(path)
+    assert float(ck["train_loss"]) == 0.5 and float(ck["test_loss"]) == 0.2 and ck["epoch"] == 10
+    assert ck["config"]["mcmc"]["sample_clip"]["scope"] == "x_0" and ck["config"]["dataset"]["subset"] is None
     assert dio.ema_weight_keywords(ck) == ["model"]
     assert dio.ema_weight_keywords(ck, "all") == ["model", "model_ema_beta_0.9990"]
     assert dio.ema_weight_keywords(ck, [1.0, 0.999]) == ["model", "model_ema_beta_0.9990"]
@@ -118,6 +150,16 @@ def test_checkpoint_roundtrip(tmp_path):
     bad.pop("model.norm.bias")
     with pytest.raises(RuntimeError):
         dio.load_model({"model": bad}, net, "model")        # strict=True like the reference
+
+
+def test_checkpoint_loader_still_refuses_code(tmp_path):
+    """the allow-list covers NumPy scalar reconstruction only: a pickle that names anything else is refused"""
+    from diffusesg_amd import io as dio
+    import argparse
+    path = str(tmp_path / "evil.pth")
+    torch.save({"model": {}, "oops": argparse.Namespace(a=1)}, path)
+    with pytest.raises(Exception):
+        dio.load_checkpoint(path)
 
 
 def test_npz_writer_keys(tmp_path):
@@ -140,5 +182,9 @@ def test_pack_decoded_roundtrip():
     fl = torch.rand(B, n) > 0.3
     bb = torch.rand(B, n, 4)
     p = dio.pack_decoded(qa, qn, bb, fl)
+    assert p.dtype == torch.int16 and p.shape == (B, n * n + 2 * n + 8 * n)     # int16 ids + fp32 bbox bits, as documented
+    vg = dio.pack_decoded(torch.zeros(1, 64, 64, dtype=torch.int32), torch.zeros(1, 64, dtype=torch.int32), torch.zeros(1, 64, 4),
+                          torch.ones(1, 64, dtype=torch.bool))
+    assert vg.numel() * vg.element_size() == 2 * (4096 + 64 + 64) + 1024          # 9.3 KB per VG graph vs 101 KB raw
     a2, n2, f2, b2 = dio.unpack_decoded(p, n, True)
     assert torch.equal(a2, qa) and torch.equal(n2, qn) and torch.equal(f2, fl) and torch.equal(b2, bb)

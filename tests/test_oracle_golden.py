@@ -13,7 +13,7 @@ def make_oracle(cfg, seed=0):
     return Oracle(cfg, W.synth_state_dict(cfg, seed))
 
 
-@pytest.mark.parametrize("name", ["tiny", "small", "nosc", "vg", "coco"])
+@pytest.mark.parametrize("name", ["tiny", "small", "nosc", "vg", "coco", "onehot"])
 def test_forward_matches_reference(name):
     cfg, flags, adj, node, sc_adj, sc_node = Y.fwd_case(name)
     g = load(f"fwd_{name}.npz")
@@ -108,3 +108,16 @@ def test_sampler_known_answer():
     assert np.abs(oa - gt_adj).max() < 1e-6 and np.abs(on - gt_node).max() < 1e-6
     assert_close(oa, g["gt_adj"], 1e-6, "gt adj vs reference run")
     assert orc.nfe == 0
+
+
+@pytest.mark.parametrize("name", ["vg", "coco"])
+def test_decode_bits_matches_reference(name):
+    """post-decode of 'bits' samples (sampler_node_adj.py:222-285 around the reference's own bin2dec): BIT-EXACT, incl.
+    values outside [-1,1], exact zeros and codes above n_type-1 (clamped)"""
+    g = load("decode.npz")
+    cfg, flags, adj, node = Y.decode_case(name)
+    _, n_adj, n_node, _ = Y.DECODE_CASES[name]
+    qa, qn, bb = make_oracle(cfg).decode_bits(adj, node, flags, n_adj, n_node)
+    assert np.array_equal(qa, g[f"{name}_q_adj"].astype(np.int32)) and np.array_equal(qn, g[f"{name}_q_node"].astype(np.int32))
+    assert np.array_equal(bb, g[f"{name}_bbox"])
+    assert (qa == n_adj - 1).sum() > 0 and (qn == n_node - 1).sum() > 0   # the clamp is exercised

@@ -255,6 +255,69 @@ def gen_sampler(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, out):
     np.savez_compressed(os.path.join(out, "sampler.npz"), **res)
 
 
+def gen_decode(out):
+    """G6: the post-decode of 'bits' samples.  `_decode_node` / `_decode_adj` are closures inside sg_go_sampling
+    (R/runner/sampler/sampler_node_adj.py:222-285; that module itself needs torchvision/pyemd and cannot be imported), so
+    their 'bits' branch is restated here statement by statement around the reference's OWN `bin2dec`
+    (R/utils/attribute_code.py:319-328) and `mask_nodes` / `mask_adjs` (R/utils/graph_utils.py), which are imported.
+    bbox: R/runner/sampler/sampler_node_adj.py:194-209 (last four node channels * 0.5 + 0.5, masked)."""
+    from utils.attribute_code import bin2dec
+    from utils.graph_utils import mask_adjs, mask_nodes
+    from utils.sg_utils import get_node_adj_num_type
+    res = {}
+    for name, (dataset, raw_adj, raw_node, _valid) in Y.DECODE_CASES.items():
+        cfg, flags, adj, node = Y.decode_case(name)
+        info = get_node_adj_num_type(dataset, flag_sg=True, encoding="bits", flag_node_only=False, flag_node_bbox=True)
+        raw_num_node_type, raw_num_adj_type = info["raw_num_node_type"], info["raw_num_adj_type"]
+        assert (raw_num_adj_type, raw_num_node_type) == (raw_adj, raw_node)
+        node_flags = t(flags)
+        final_samples_adjs, final_samples_nodes = t(adj.copy()), t(node.copy())
+        # :201-209 (flag_bbox, not node-only)
+        final_samples_nodes, final_samples_nodes_bbox = final_samples_nodes[..., :-4], final_samples_nodes[..., -4:]
+        final_samples_nodes_bbox = final_samples_nodes_bbox * 0.5 + 0.5
+        final_samples_nodes_bbox = mask_nodes(final_samples_nodes_bbox.cpu(), node_flags.cpu())
+        # _decode_node, 'bits' (:222-233)
+        node_samples = final_samples_nodes.clamp(-1.0, 1.0)
+        node_samples = torch.where(node_samples > 0.0, torch.ones_like(node_samples), -torch.ones_like(node_samples))
+        node_samples = mask_nodes(node_samples, node_flags)
+        _q_binary_node = node_samples.gt(0.0).cpu().float()
+        _q_binary_node = mask_nodes(_q_binary_node, node_flags.cpu())
+        _q_node = bin2dec(_q_binary_node, num_bits=np.ceil(np.log2(raw_num_node_type)).astype(int))
+        _q_node = mask_nodes(_q_node, node_flags.cpu()).clamp(min=0, max=raw_num_node_type - 1)
+        # _decode_adj, 'bits' (:242-247, :265-275, :279-283)
+        adj_samples = final_samples_adjs.clamp(-1.0, 1.0)
+        adj_samples = torch.where(adj_samples > 0.0, torch.ones_like(adj_samples), -torch.ones_like(adj_samples))
+        adj_samples = mask_adjs(adj_samples, node_flags)
+        _q_binary_adj = adj_samples.gt(0.0).cpu().float()
+        _q_binary_adj = mask_adjs(_q_binary_adj, node_flags.cpu())
+        _q_binary_adj = _q_binary_adj.permute(0, 2, 3, 1)
+        _q_adj = bin2dec(_q_binary_adj, num_bits=np.ceil(np.log2(raw_num_adj_type)).astype(int))
+        _q_adj = mask_adjs(_q_adj, node_flags.cpu()).clamp(min=0, max=raw_num_adj_type - 1)
+        b, n = node_flags.shape[:2]
+        _q_adj[:, torch.eye(n, device=_q_adj.device).bool()] = 0.0
+        qa, qn = _q_adj.contiguous().numpy(), _q_node.numpy()
+        assert np.array_equal(qa, np.round(qa)) and np.array_equal(qn, np.round(qn))
+        res[f"{name}_q_adj"], res[f"{name}_q_node"] = qa.astype(np.int16), qn.astype(np.int16)
+        res[f"{name}_bbox"] = final_samples_nodes_bbox.numpy().astype(np.float32)
+        print(f"decode {name}: q_adj max {qa.max():.0f} (clamped at {raw_num_adj_type - 1}: {(qa == raw_num_adj_type - 1).sum()}), "
+              f"q_node max {qn.max():.0f} (clamped at {raw_num_node_type - 1}: {(qn == raw_num_node_type - 1).sum()})")
+    np.savez_compressed(os.path.join(out, "decode.npz"), **res)
+
+
+def check_channel_table():
+    """diffusesg_amd.spec.sg_channels (data restated from sg_utils.py:348-409) against the imported reference function."""
+    from utils.sg_utils import get_node_adj_num_type
+    for dataset in ("visual_genome", "coco_stuff"):
+        for enc in ("bits", "ddpm", "one_hot"):
+            info = get_node_adj_num_type(dataset, flag_sg=True, encoding=enc, flag_node_only=False, flag_node_bbox=True)
+            mine = S.sg_channels(dataset, enc)
+            assert mine["c_adj"] == int(info["num_adj_type"]) == int(info["out_chans_adj"]) == int(info["in_chans_adj"]), (dataset, enc)
+            assert mine["c_node"] == int(info["num_node_type"]) == int(info["out_chans_node"]), (dataset, enc)
+            assert mine["in_chans"] == int(info["in_chans_node"]) + int(info["in_chans_adj"]), (dataset, enc)
+            assert (mine["raw_num_node_type"], mine["raw_num_adj_type"]) == (info["raw_num_node_type"], info["raw_num_adj_type"])
+    print("channel table: spec.sg_channels == get_node_adj_num_type for {visual_genome, coco_stuff} x {bits, ddpm, one_hot}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(REPO, "tests", "golden"))
@@ -264,6 +327,9 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler = _import_reference()
+    check_channel_table()
+    if args.only in ("", "decode"):
+        gen_decode(args.out)
     if args.only in ("", "fwd"):
         gen_forward(DiffuseSG, args.out)
     if args.only in ("", "precond"):
