@@ -7,66 +7,38 @@ stochastic Heun, S_churn=40, num_steps T=1000, fp32), from on-device initial noi
 (adj, node) resident in HBM, followed (N>1) by the single all-gather of the packed results.  Nothing is skipped:
 every preconditioned call, every coin-triggered extra self-conditioning forward, churn noise and masking run.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task prompt) with `roofline` and `cpu_baseline` objects.
+N > 1 without a torchrun environment: this process becomes a LAUNCHER -- before any GPU call it starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+as a child process (one rank per GPU over RCCL), relays rank 0's JSON line and exits with the child's status.  Launched
+by torchrun (RANK/LOCAL_RANK/WORLD_SIZE set) it is a rank.  The W warm-up samples run on a short schedule
+(`--warmup-num-steps`, default 20: graph capture, workspace allocation and clocks settle within the first forwards);
+the K timed steps are full T-step samples.  Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline` objects.
 """
 import argparse
-import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-from diffusesg_amd import dist as dsg_dist  # noqa: E402
-from diffusesg_amd import spec, synth, weights  # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2516.6  # same guide: ~2.5 PF dense = 16 x the fp32 matrix rate
 
 
-def cpu_baseline(cfg, sd, T, valid, budget_s=20.0):
-    """The ORACLE (oracle/dsg_ref.c, kind 'port') timed on this box's host cores on a bounded sample of the same
-    workload: B=2 graphs, the first `max_steps` sampler steps with the same coin stream; extrapolated by network
-    forwards (per-forward cost is constant)."""
-    from oracle.oracle import Oracle
-    orc = Oracle(cfg, sd)
-    cores = os.cpu_count() if not hasattr(os, "sched_getaffinity") else len(os.sched_getaffinity(0))
-    B = max(2, min(64, cores))   # one sample per thread (the oracle parallelises over the batch)
-    flags, ia, inn, _, _, cv = synth.sampler_case(cfg, 4, B, valid, 77, "bench/cpu")
-    coins_all = (weights.coins(77, "bench/cpu/all", 2 * T - 1) < 0.5).astype(np.uint8)
-    nfe_total = (2 * T - 1) + int(coins_all.sum())
-    steps, elapsed, nfe = 1, 0.0, 0
-    while True:
-        n0 = orc.nfe
-        t0 = time.perf_counter()
-        orc.sample(flags, ia, inn, None, None, coins_all, num_steps=T, max_steps=steps)
-        elapsed = time.perf_counter() - t0
-        nfe = orc.nfe - n0
-        if elapsed >= budget_s / 2 or steps >= 64:
-            break
-        steps = min(64, max(steps + 1, int(steps * (budget_s * 0.75) / max(elapsed, 1e-3))))
-    per_fwd = elapsed / nfe
-    graphs_per_s = B / (per_fwd * nfe_total)
-    return {"value": graphs_per_s, "unit": "scene-graphs/s", "cores": int(min(cores, B)), "kind": "port",
-            "sample": f"oracle/dsg_ref.c (OpenMP, one graph per thread), VG config B={B}, first {steps} of T={T} Heun steps = {nfe} network "
-                      f"forwards in {elapsed:.1f} s, scaled to {nfe_total} forwards/graph-batch"}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=64, help="graphs per GPU per step (configs[1]: 64)")
+    ap.add_argument("--batch", type=int, default=64, help="graphs per GPU per step (configs[1]: 64; configs[3]: 256)")
     ap.add_argument("--num-steps", type=int, default=1000, help="sampler steps T (BASELINE metric: 1000)")
+    ap.add_argument("--warmup-num-steps", type=int, default=20, help="sampler steps of the untimed warm-up samples")
     ap.add_argument("--config", default="vg", choices=["vg", "coco", "tiny"])
     ap.add_argument("--valid", type=int, default=None, help="valid nodes per graph (VG: 30)")
     ap.add_argument("--no-graph", action="store_true")
@@ -76,58 +48,147 @@ def main():
     ap.add_argument("--solver", default="heun", choices=["heun", "euler"], help="configs[2] variant 3b: --solver euler --s-churn 0")
     ap.add_argument("--s-churn", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget-s", type=float, default=15.0, help="wall-clock bound of the cpu_baseline leg")
     ap.add_argument("--seed", type=int, default=1234)
-    args = ap.parse_args()
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU rehearsal of the multi-rank plumbing (launcher, rank env, gloo process group, barrier, max-over-ranks "
+                         "timing, packed all-gather) with a stand-in step; no GPU, no product kernels, the value is meaningless")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(n_ranks: int, argv) -> int:
+    """Parent of a `--gpus N` (N > 1) run started without torchrun.  Touches no GPU API and never re-execs: the ranks are
+    child processes of `python -m torch.distributed.run`; their stdout (rank 0's JSON line) is relayed line by line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL / cross-process tensors)
+    env.setdefault("OMP_NUM_THREADS", "1")              # the ranks are launch-bound host threads, not OpenMP workers
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    try:
+        for line in proc.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    finally:
+        rc = proc.wait()
+    return rc
+
+
+def cpu_baseline(cfg, sd, T, valid, budget_s):
+    """The ORACLE (oracle/dsg_ref.c, kind 'port') timed on this box's host cores on a bounded sample of the same workload:
+    B = cores graphs (the oracle runs one graph per OpenMP thread), the first sampler steps of the same T-step schedule with
+    the same coin stream, as many as fit the budget; extrapolated by network forwards (per-forward cost is constant)."""
+    import numpy as np
+    from diffusesg_amd import synth, weights
+    from oracle.oracle import Oracle
+    orc = Oracle(cfg, sd)
+    cores = os.cpu_count() if not hasattr(os, "sched_getaffinity") else len(os.sched_getaffinity(0))
+    B = max(2, min(64, cores))
+    flags, ia, inn, _, _, cv = synth.sampler_case(cfg, 4, B, valid, 77, "bench/cpu")
+    coins_all = (weights.coins(77, "bench/cpu/all", 2 * T - 1) < 0.5).astype(np.uint8)
+    nfe_total = (2 * T - 1) + int(coins_all.sum())
+    t_begin = time.perf_counter()
+    # calibrate on one step, then one run sized to the remaining budget
+    n0 = orc.nfe
+    t0 = time.perf_counter()
+    orc.sample(flags, ia, inn, None, None, coins_all, num_steps=T, max_steps=1)
+    elapsed, nfe, steps = time.perf_counter() - t0, orc.nfe - n0, 1
+    remaining = budget_s - (time.perf_counter() - t_begin)
+    more = int(remaining / (elapsed / nfe) / 3.0)   # ~3 forwards per Heun step (2 precond calls + coins)
+    if more >= 2:
+        steps = min(64, more)
+        n0 = orc.nfe
+        t0 = time.perf_counter()
+        orc.sample(flags, ia, inn, None, None, coins_all, num_steps=T, max_steps=steps)
+        elapsed, nfe = time.perf_counter() - t0, orc.nfe - n0
+    per_fwd = elapsed / nfe
+    return {"value": B / (per_fwd * nfe_total), "unit": "scene-graphs/s", "cores": int(min(cores, B)), "kind": "port",
+            "sample": f"oracle/dsg_ref.c (OpenMP, one graph per thread), same config, B={B}, first {steps} of T={T} Heun steps = "
+                      f"{nfe} network forwards of {B} graphs in {elapsed:.1f} s, scaled to {nfe_total} forwards per graph"}
+
+
+def worker(args):
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from diffusesg_amd import dist as dsg_dist
+    from diffusesg_amd import spec, synth, weights
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
-
-    from diffusesg_amd.model import build_network
-    from diffusesg_amd.sampler import NodeAdjEDMSamplerHip
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    selftest = args.selftest_launcher
+    if selftest:
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+    world_seen = dist.get_world_size() if world > 1 else 1
 
     cfg = synth.CONFIGS[args.config]()
     n = cfg.max_node_num
     valid = args.valid if args.valid is not None else {"vg": 30, "coco": 20, "tiny": 8}[args.config]
-    sd = weights.synth_state_dict(cfg, 0)
-    net = build_network(cfg, sd, device=dev)
-    if args.precision == "bf16":
-        net.model._ensure_handle().set_option("gemm_bf16", 1)
-    if args.precision == "f32-split":
-        net.model._ensure_handle().set_option("gemm_split", 1)
     T, B = args.num_steps, args.batch
-    smp = NodeAdjEDMSamplerHip(num_steps=T, solver=args.solver, S_churn=args.s_churn, S_min=0.05, S_max=50, S_noise=1.003,
-                               clip_samples=True, clip_samples_min=-1.0, clip_samples_max=1.0, clip_samples_scope="x_0",
-                               self_condition=cfg.self_condition, dev=dev, use_graph=not args.no_graph)
-    flags = torch.from_numpy(weights.synth_flags(B, n, valid)).to(dev)
-    seed = dsg_dist.rank_seed(args.seed, rank)
-    np.random.seed(seed)   # the coin stream (np.random.rand, precond.py:90) is part of the workload
+    seed = dsg_dist.rank_seed(args.seed, rank)     # arg_parser.py:293-294: seed += rank
+    np.random.seed(seed)                           # the coin stream (np.random.rand, precond.py:90) is part of the workload
 
-    def one_step(k):
-        oa, on = smp.sample(net, flags, num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj, seed=seed + 1000 * k,
-                            return_device=True)
-        packed = dsg_dist.pack_results(oa.reshape(B, cfg.c_adj, n, n), on.reshape(B, n, cfg.c_node))
-        return dsg_dist.gather_results(packed), dict(smp.last_stats)
+    if selftest:
+        net = sd = smp = smp_warm = None
+        flags = torch.from_numpy(weights.synth_flags(B, n, valid))
+
+        def one_step(k, sampler):
+            g = torch.Generator().manual_seed(seed + 1000 * (k + 7))
+            oa, on = torch.randn(B, cfg.c_adj, n, n, generator=g), torch.randn(B, n, cfg.c_node, generator=g)
+            return dsg_dist.gather_results(dsg_dist.pack_results(oa, on)), {"net_forwards": 0}
+    else:
+        from diffusesg_amd.model import build_network
+        from diffusesg_amd.sampler import NodeAdjEDMSamplerHip
+        sd = weights.synth_state_dict(cfg, 0)
+        net = build_network(cfg, sd, device=dev)
+        h = net.model._ensure_handle()
+        if args.precision == "bf16":
+            h.set_option("gemm_bf16", 1)
+        if args.precision == "f32-split":
+            h.set_option("gemm_split", 1)
+        skw = dict(solver=args.solver, S_churn=args.s_churn, S_min=0.05, S_max=50, S_noise=1.003, clip_samples=True,
+                   clip_samples_min=-1.0, clip_samples_max=1.0, clip_samples_scope="x_0", self_condition=cfg.self_condition,
+                   dev=dev, use_graph=not args.no_graph)
+        smp = NodeAdjEDMSamplerHip(num_steps=T, **skw)
+        smp_warm = NodeAdjEDMSamplerHip(num_steps=max(1, min(T, args.warmup_num_steps)), **skw)
+        flags = torch.from_numpy(weights.synth_flags(B, n, valid)).to(dev)
+
+        def one_step(k, sampler):
+            oa, on = sampler.sample(net, flags, num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj, seed=seed + 1000 * k,
+                                    return_device=True)
+            packed = dsg_dist.pack_results(oa.reshape(B, cfg.c_adj, n, n), on.reshape(B, n, cfg.c_node))
+            return dsg_dist.gather_results(packed), dict(sampler.last_stats)
 
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not selftest:
+            torch.cuda.synchronize(dev)
 
     for k in range(args.warmup):
-        one_step(-1 - k)
+        one_step(-1 - k, smp_warm)
     fence()
     t0 = time.perf_counter()
     nfe = 0
     out = None
     for k in range(args.steps):
-        out, st = one_step(k)
+        out, st = one_step(k, smp)
         nfe += st["net_forwards"]
     fence()
     elapsed = time.perf_counter() - t0
@@ -135,29 +196,42 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert out.shape[0] == world * B and bool(torch.isfinite(out).all())
+    assert out.shape[0] == world_seen * B and bool(torch.isfinite(out).all())
+    if world > 1:
+        # rank order of the gather: every rank drew from its own seed, so the blocks must differ and block r must be rank r's
+        mine = out[rank * B:(rank + 1) * B]
+        other = out[((rank + 1) % world) * B:((rank + 1) % world + 1) * B]
+        assert not torch.equal(mine, other), "two ranks produced identical graphs: seeds are not offset by rank"
 
-    # The tail the reference pays after sampling (sampler_node_adj.py:194-345): decode the 'bits' samples, gather the
-    # decoded graphs and bring them to the host.  Reported beside `value`, never inside it.
-    from diffusesg_amd import io as dsg_io
-    n_adj_type, n_node_type = (51, 150) if args.config == "vg" else (7, 171) if args.config == "coco" else (2 ** cfg.c_adj, 2 ** (cfg.c_node - 4))
-    raw_a, raw_x = dsg_dist.unpack_results(out[rank * B:(rank + 1) * B], cfg.c_adj, n, cfg.c_node)
-    fence()
-    t1 = time.perf_counter()
-    qa, qn, bb = dsg_io.decode_bits(net, raw_a, raw_x, flags, n_adj_type, n_node_type, bbox=True)
-    dec = dsg_dist.gather_results(dsg_io.pack_decoded(qa, qn, bb, flags))
-    dec_host = dec.cpu()
-    fence()
-    tail = time.perf_counter() - t1
-    assert dec_host.shape[0] == world * B
+    line = None
+    if selftest:
+        if rank == 0:
+            line = {"metric": "launcher self-test (no GPU work)", "value": world * B * args.steps / max(elapsed, 1e-9),
+                    "unit": "stand-in steps/s", "n_gpus": world, "world_size": world_seen, "steps": args.steps,
+                    "warmup": args.warmup, "selftest": True, "backend": "gloo" if world > 1 else None,
+                    "gathered_rows": int(out.shape[0])}
+    else:
+        # The tail the reference pays after sampling (sampler_node_adj.py:194-345): decode the 'bits' samples, gather the
+        # decoded graphs and bring them to the host.  Reported beside `value`, never inside it.
+        from diffusesg_amd import io as dsg_io
+        n_adj_type, n_node_type = (51, 150) if args.config == "vg" else (7, 171) if args.config == "coco" else (2 ** cfg.c_adj, 2 ** (cfg.c_node - 4))
+        raw_a, raw_x = dsg_dist.unpack_results(out[rank * B:(rank + 1) * B], cfg.c_adj, n, cfg.c_node)
+        fence()
+        t1 = time.perf_counter()
+        qa, qn, bb = dsg_io.decode_bits(net, raw_a, raw_x, flags, n_adj_type, n_node_type, bbox=True)
+        dec = dsg_dist.gather_results(dsg_io.pack_decoded(qa, qn, bb, flags))
+        dec_host = dec.cpu()
+        fence()
+        tail = time.perf_counter() - t1
+        assert dec_host.shape[0] == world_seen * B
 
-    if rank == 0:
+    if rank == 0 and not selftest:
         graphs = world * B * args.steps
         value = graphs / elapsed
         f_fwd = spec.flops_per_forward(cfg)
-        # roofline of the dominant kernel (gemm_f32_kernel): HIP events around every launch of eager forwards on the
-        # state the timed run left in the workspace (random-data clocks, not zeros)
-        h = net.model._ensure_handle()
+        mode = h.precision_mode()     # what the handle actually ran (options or DSG_* environment defaults), not the CLI flag
+        # roofline of the dominant kernel (the GEMM): HIP events around every launch of eager forwards on the state the timed
+        # run left in the workspace (random-data clocks, not zeros)
         ms, cnt, fl = (C.c_double * 5)(), (C.c_int64 * 5)(), (C.c_double * 5)()
         gemm_ms = C.c_double(0.0)
         iters = 3
@@ -169,16 +243,16 @@ def main():
         gemm_avg_ms = ms[0] / cnt[0]
         gemm_avg_ms_inkernel = gemm_ms.value / cnt[0]
         achieved = (fl[0] / cnt[0]) / (gemm_avg_ms * 1e-3) / 1e12
-        kinds = ["gemm_f32", "window_attn", "row", "elementwise", "fused_blocks"]
-        # per-class times are event brackets (each includes dispatch latency); class 0 also has the in-kernel figure
+        kinds = ["gemm", "window_attn", "row", "elementwise", "fused_blocks"]
         breakdown = {kinds[i]: {"ms_per_forward": ms[i] / iters, "launches_per_forward": cnt[i] // iters,
-                                "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] > 0 else None} for i in range(5)}
+                                "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] > 0 and ms[i] > 0 else None} for i in range(5)}
         # HBM traffic of that kernel: PMC counters cannot be read from inside this process; the per-launch figure comes from
         # the committed rocprofv3 --pmc passes over this same command (tools/pmc_traffic.sh -> profiles/*/pmc_traffic.json)
         traffic, traffic_src = None, None
-        for rnd in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True) if os.path.isdir(os.path.join(ROOT, "profiles")) else []:
-            pj = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
-            if os.path.exists(pj) and args.config == "vg" and B == 64:
+        prof_root = os.path.join(ROOT, "profiles")
+        for rnd in sorted(os.listdir(prof_root), reverse=True) if os.path.isdir(prof_root) else []:
+            pj = os.path.join(prof_root, rnd, "pmc_traffic.json")
+            if os.path.exists(pj) and args.config == "vg" and B == 64 and mode == "f32":
                 tj = json.load(open(pj))
                 traffic = tj["kernels"]["gemm4_f32_kernel"]["hbm_bytes_per_launch"]
                 traffic_src = f"profiles/{rnd}/pmc_traffic.json"
@@ -186,9 +260,9 @@ def main():
         # peak of the pipe the dominant kernel runs on, in ALGORITHMIC (2*M*N*K) FLOP/s: the split kernel issues six bf16
         # MFMA products per algorithmic product, so its ceiling is the bf16 dense peak / 6
         kern, peak = {"f32": ("gemm4_f32_kernel", PEAK_F32_MFMA_TFLOPS), "bf16": ("gemm_bf16_kernel", PEAK_BF16_MFMA_TFLOPS),
-                      "f32-split": ("gemm_split2_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0)}[args.precision]
-        if args.precision != "f32":
-            traffic, traffic_src, gemm_avg_ms_inkernel = None, None, None
+                      "f32-split": ("gemm_split2_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0)}[mode]
+        if mode != "f32":
+            gemm_avg_ms_inkernel = None
         roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak,
                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": gemm_avg_ms, "avg_launch_ms_inkernel": gemm_avg_ms_inkernel,
@@ -199,7 +273,7 @@ def main():
         roofline["whole_path_frac"] = roofline["whole_path_tflops"] / PEAK_F32_MFMA_TFLOPS
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(cfg, sd, T, valid)
+            cpu = cpu_baseline(cfg, sd, T, valid, args.cpu_budget_s)
         # BASELINE.json's metric string for the configuration it is quoted on (VG shape: 30 valid nodes, T=1000); any other
         # workload is labelled plainly and described in config.workload
         metric_name = "scene-graphs/sec"
@@ -209,24 +283,36 @@ def main():
             except Exception:
                 metric_name = "scene-graphs/sec at N=30 nodes, T=1000 DDPM steps, 1/2/4/8 MI355X"
         line = {
-            "metric": metric_name, "value": value, "unit": "scene-graphs/s", "n_gpus": world,
+            "metric": metric_name, "value": value, "unit": "scene-graphs/s", "n_gpus": world, "world_size": world_seen,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": "bf16 GEMM operands, f32 accumulate/activations",
-                      "f32-split": "f32 (GEMM products as 3-way bf16 operand splits, six partial products, f32 accumulate)"}[args.precision], "data": "synthetic",
+                      "f32-split": "f32 (GEMM products as 3-way bf16 operand splits, six partial products, f32 accumulate)"}[mode],
+            "data": "synthetic",
             "config": {"workload": f"{args.config}-bits N={n} valid={valid} C_adj={cfg.c_adj} C_node={cfg.c_node} "
                                    f"T={T} {args.solver} S_churn={args.s_churn:g} self_cond={int(cfg.self_condition)}",
                        "batch_per_gpu": B, "global_batch": world * B, "num_steps": T,
+                       "warmup_num_steps": max(1, min(T, args.warmup_num_steps)),
                        "net_forwards_per_step": nfe / args.steps, "gflop_per_forward_per_graph": f_fwd / 1e9,
-                       "hip_graph": not args.no_graph, "parallelism": f"batch-sharded x{world}, one all-gather"},
+                       "hip_graph": not args.no_graph, "precision_mode": mode,
+                       "parallelism": f"batch-sharded x{world}, one all-gather"},
             "roofline": roofline, "cpu_baseline": cpu,
-            "tail": {"what": "on-GPU decode of the bits samples + packed all-gather + D2H of the decoded graphs (once per step)",
+            "tail": {"what": "on-GPU decode of the bits samples + packed int16 all-gather + D2H of the decoded graphs (once per step)",
                      "ms": 1e3 * tail, "value_with_tail": graphs / (elapsed + args.steps * tail)},
         }
-        print(json.dumps(line))
+    if line is not None:
+        sys.stdout.write(json.dumps(line) + "\n")
+        sys.stdout.flush()           # the line is out before any teardown
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    worker(args)
 
 
 if __name__ == "__main__":

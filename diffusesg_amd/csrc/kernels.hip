@@ -668,6 +668,7 @@ __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__
         int r_last = __shfl(rowid, 31, 64);
         if (r_last < 0) r_last = (M - 1) / N;  // partially filled last tile
         const float wgt = valid ? 1.0f / (float)N : 0.f;
+        if (r_first < 0) r_last = -2;          // a tile entirely beyond M (padding wave of the last block) owns no row
         for (int r = r_first; r <= r_last; r++) {
             const float sel = (rowid == r) ? wgt : 0.f;
             float *dst = pool_part + ((size_t)r * nseg + (tile - (r * N) / 32)) * C;

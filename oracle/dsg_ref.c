@@ -134,6 +134,48 @@ static void tap(dsgref *h, const char *name, const float *src, int64_t numel) {
 static inline float silu_f(float x) { return x / (1.0f + expf(-x)); }
 static inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); } /* exact erf GELU, nn.GELU default */
 
+/* y[M,N] = x[M,K] @ Wt[K,N] + b with Wt stored [in,out].  Every output element is the k-ordered chain
+ * y = b; y += x[m][k] * Wt[k][n] (k = 0..K-1), exactly as a row-by-row axpy would form it; the 4-row x 24-column register
+ * tile only changes how often the weights are streamed (this is also the CPU baseline bench.py times). */
+#define LIN_RB 4
+#define LIN_NB 24
+static void linear_kn(const float *wt, const float *bias, const float *x, float *y, int M, int K, int N) {
+    const int mblocks = (M + LIN_RB - 1) / LIN_RB;
+#pragma omp parallel for schedule(static)
+    for (int mb = 0; mb < mblocks; mb++) {
+        const int m0 = mb * LIN_RB, rows = (M - m0 < LIN_RB) ? M - m0 : LIN_RB;
+        for (int n0 = 0; n0 < N; n0 += LIN_NB) {
+            const int nb = (N - n0 < LIN_NB) ? N - n0 : LIN_NB;
+            if (rows == LIN_RB && nb == LIN_NB) {
+                float acc[LIN_RB][LIN_NB];
+                for (int r = 0; r < LIN_RB; r++)
+                    for (int n = 0; n < LIN_NB; n++) acc[r][n] = bias ? bias[n0 + n] : 0.f;
+                const float *x0 = x + (size_t)m0 * K, *x1 = x0 + K, *x2 = x1 + K, *x3 = x2 + K;
+                for (int k = 0; k < K; k++) {
+                    const float *wr = wt + (size_t)k * N + n0;
+                    const float a0 = x0[k], a1 = x1[k], a2 = x2[k], a3 = x3[k];
+                    for (int n = 0; n < LIN_NB; n++) {
+                        const float wv = wr[n];
+                        acc[0][n] += a0 * wv; acc[1][n] += a1 * wv; acc[2][n] += a2 * wv; acc[3][n] += a3 * wv;
+                    }
+                }
+                for (int r = 0; r < LIN_RB; r++) memcpy(y + (size_t)(m0 + r) * N + n0, acc[r], sizeof(float) * LIN_NB);
+            } else {
+                for (int r = 0; r < rows; r++) {
+                    float *yr = y + (size_t)(m0 + r) * N + n0;
+                    const float *xr = x + (size_t)(m0 + r) * K;
+                    for (int n = 0; n < nb; n++) yr[n] = bias ? bias[n0 + n] : 0.f;
+                    for (int k = 0; k < K; k++) {
+                        const float a = xr[k];
+                        const float *wr = wt + (size_t)k * N + n0;
+                        for (int n = 0; n < nb; n++) yr[n] += a * wr[n];
+                    }
+                }
+            }
+        }
+    }
+}
+
 /* y[M,N] = x[M,K] @ W[N,K]^T + b   (torch.nn.functional.linear; diffusesg.py:14-16 etc.) */
 static void linear(wentry *w, const float *bias, const float *x, float *y, int M, int K, int N) {
     if (!w->tr) {
@@ -145,35 +187,12 @@ static void linear(wentry *w, const float *bias, const float *x, float *y, int M
             w->tr = t;
         }
     }
-    const float *wt = w->tr;
-#pragma omp parallel for schedule(static)
-    for (int m = 0; m < M; m++) {
-        float *yr = y + (size_t)m * N;
-        const float *xr = x + (size_t)m * K;
-        if (bias) memcpy(yr, bias, sizeof(float) * N);
-        else memset(yr, 0, sizeof(float) * N);
-        for (int k = 0; k < K; k++) {
-            const float a = xr[k];
-            const float *wr = wt + (size_t)k * N;
-            for (int n = 0; n < N; n++) yr[n] += a * wr[n];
-        }
-    }
+    linear_kn(w->tr, bias, x, y, M, K, N);
 }
 
 /* y = x @ W (weight already stored [in,out]); used for ConvTranspose2d k=1 (diffusesg.py:706) */
 static void linear_in_out(const float *w_in_out, const float *bias, const float *x, float *y, int M, int K, int N) {
-#pragma omp parallel for schedule(static)
-    for (int m = 0; m < M; m++) {
-        float *yr = y + (size_t)m * N;
-        const float *xr = x + (size_t)m * K;
-        if (bias) memcpy(yr, bias, sizeof(float) * N);
-        else memset(yr, 0, sizeof(float) * N);
-        for (int k = 0; k < K; k++) {
-            const float a = xr[k];
-            const float *wr = w_in_out + (size_t)k * N;
-            for (int n = 0; n < N; n++) yr[n] += a * wr[n];
-        }
-    }
+    linear_kn(w_in_out, bias, x, y, M, K, N);
 }
 
 /* nn.LayerNorm over the last dim, eps=1e-5, biased variance */

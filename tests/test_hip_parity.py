@@ -690,3 +690,103 @@ def test_onehot_channel_widths_vs_oracle():
                                      num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
     assert_close(ga.numpy(), ea, 1e-4, "onehot trajectory adj")
     assert_close(gn.numpy(), en, 1e-4, "onehot trajectory node")
+
+
+# ---- BASELINE.json configs[2..4] at their own shapes (round-1 verdict: untested under -m gpu) ----
+def test_vg_euler_no_churn_short_trajectory_vs_oracle():
+    """configs[2] variant 3b ("DDIM-equivalent": solver='euler', S_churn=0) at the VG shape: 6 steps vs the oracle"""
+    from oracle.oracle import Oracle
+    cfg = Y.CONFIGS["vg"]()
+    T_ = 6
+    flags, ia, inn, na, nn, cv = Y.sampler_case(cfg, T_, 2, [30, 11], 41, "vg/euler6", "euler")
+    coins = (cv < 0.5).astype(np.uint8)
+    orc = Oracle(cfg, W.synth_state_dict(cfg, 0))
+    ra, rn = orc.sample(flags, ia, inn, None, None, coins, num_steps=T_, solver="euler", S_churn=0.0)
+    smp = make_sampler(T_, solver="euler", S_churn=0.0)
+    oa, on = smp.sample(net_for("vg"), T(flags), init_adjs=T(ia), init_nodes=T(inn), coins=coins,
+                        num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    assert_close(oa.numpy(), ra, 1e-4, "vg euler 6-step adj")
+    assert_close(on.numpy(), rn, 1e-4, "vg euler 6-step node")
+    assert smp.last_stats["precond_calls"] == T_ and smp.last_stats["net_forwards"] == T_ + int(coins[:T_].sum())
+
+
+def test_vg_batch256_properties_with_graph():
+    """configs[2]/[3] per-GPU batch (B = 256) with the hipGraph-replayed forward: samples are independent of their batch
+    neighbours (B=256 rows vs the same rows run at B=3), padded rows/columns exactly zero, and the known-answer run lands on GT"""
+    cfg = Y.CONFIGS["vg"]()
+    n, B = cfg.max_node_num, 256
+    valid = [30, 64, 1, 17, 45]
+    flags, ia, inn, na, nn, cv = Y.sampler_case(cfg, 4, B, valid, 43, "vg/b256", "euler")
+    coins = np.array([1, 0, 1, 0], np.uint8)
+    smp = make_sampler(4, solver="euler", S_churn=0.0, use_graph=True)
+    oa, on = smp.sample(net_for("vg"), T(flags), init_adjs=T(ia), init_nodes=T(inn), coins=coins,
+                        num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    assert smp.last_stats["graph_replays"] == smp.last_stats["net_forwards"] == 4 + 2
+    assert torch.isfinite(oa).all() and torch.isfinite(on).all()
+    f = torch.from_numpy(flags)
+    assert torch.all(on[~f] == 0) and torch.all(oa.permute(0, 2, 3, 1)[~f] == 0) and torch.all(oa.permute(0, 3, 2, 1)[~f] == 0)
+    sel = [0, 101, 255]
+    oa2, on2 = smp.sample(net_for("vg"), T(flags[sel]), init_adjs=T(ia[sel]), init_nodes=T(inn[sel]), coins=coins,
+                          num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    assert_close(oa2.numpy(), oa[sel].numpy(), 2e-5, "B=256 vs B=3 adj")
+    assert_close(on2.numpy(), on[sel].numpy(), 2e-5, "B=256 vs B=3 node")
+    gt_adj = W.mask_adj(np.sign(W.normal(47, "vg/b256/gt_a", (B, cfg.c_adj, n, n))).astype(np.float32), flags)
+    gt_node = W.mask_node(np.sign(W.normal(47, "vg/b256/gt_n", (B, n, cfg.c_node))).astype(np.float32), flags)
+    ga, gn = make_sampler(12).sample(net_for("vg"), T(flags), sanity_check_gt_adjs=T(gt_adj), sanity_check_gt_nodes=T(gt_node),
+                                     num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj, seed=9)
+    assert np.abs(ga.numpy() - gt_adj).max() < 1e-5 and np.abs(gn.numpy() - gt_node).max() < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_coco_short_trajectory_vs_oracle(mode):
+    """configs[4]'s network (COCO-bits: N=40, 100-token windows, depths [1,2,6]): 6 Heun+churn steps with replayed noise and
+    coins against the fp32 oracle -- at the fp32 bar (1e-4) in the default mode, at the stated bf16 bar in the opt-in mode"""
+    from oracle.oracle import Oracle
+    from diffusesg_amd.model import build_network
+    cfg = Y.CONFIGS["coco"]()
+    T_ = 6
+    flags, ia, inn, na, nn, cv = Y.sampler_case(cfg, T_, 2, [20, 40], 53, "coco/smp6")
+    coins = (cv < 0.5).astype(np.uint8)
+    orc = Oracle(cfg, W.synth_state_dict(cfg, 0))
+    ra, rn = orc.sample(flags, ia, inn, na, nn, coins, num_steps=T_)
+    net = net_for("coco") if mode == "f32" else build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")
+    if mode == "bf16":
+        net.model._ensure_handle().set_option("gemm_bf16", 1)
+        assert net.model._ensure_handle().precision_mode() == "bf16"
+    oa, on = make_sampler(T_).sample(net, T(flags), init_adjs=T(ia), init_nodes=T(inn), churn_noise=(T(na), T(nn)), coins=coins,
+                                     num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    if mode == "f32":
+        assert_close(oa.numpy(), ra, 1e-4, "coco 6-step adj")
+        assert_close(on.numpy(), rn, 1e-4, "coco 6-step node")
+    else:
+        ea, en = rel_err(oa.numpy(), ra), rel_err(on.numpy(), rn)
+        print(f"coco bf16 6-step: max {ea:.2e}/{en:.2e} rms {rms_rel(oa.numpy(), ra):.2e}/{rms_rel(on.numpy(), rn):.2e}")
+        assert ea <= BF16_MAX_RTOL and en <= BF16_MAX_RTOL
+        assert rms_rel(oa.numpy(), ra) <= BF16_RMS_RTOL and rms_rel(on.numpy(), rn) <= BF16_RMS_RTOL
+
+
+def test_coco_batch512_properties():
+    """configs[4] per-GPU batch (COCO-bits, B = 512), fp32 and bf16 mode: finite, exact-zero masks, batch independence,
+    and the bf16 mode stays within its stated bar of the fp32 result on every one of the 512 graphs"""
+    from diffusesg_amd.model import build_network
+    cfg = Y.CONFIGS["coco"]()
+    n, B = cfg.max_node_num, 512
+    flags, adj, node, sc_adj, sc_node = Y.case_inputs(cfg, B, [20, 40, 1, 33], 59, "coco/b512")
+    c_noise = np.linspace(-1.4, 1.1, B).astype(np.float32)
+    net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda").model
+    args = (T(adj), T(node), T(flags), T(c_noise), T(sc_adj), T(sc_node))
+    oa, on = [t.clone() for t in net(*args)]
+    assert torch.isfinite(oa).all() and torch.isfinite(on).all()
+    f = torch.from_numpy(flags).cuda()
+    assert torch.all(on[~f] == 0) and torch.all(oa.permute(0, 2, 3, 1)[~f] == 0) and torch.all(oa.permute(0, 3, 2, 1)[~f] == 0)
+    sel = [3, 200, 511]
+    oa2, on2 = net(T(adj[sel]), T(node[sel]), T(flags[sel]), T(c_noise[sel]), T(sc_adj[sel]), T(sc_node[sel]))
+    assert_close(oa2.cpu().numpy(), oa[sel].cpu().numpy(), 2e-6, "coco B=512 batch independence adj")
+    assert_close(on2.cpu().numpy(), on[sel].cpu().numpy(), 2e-6, "coco B=512 batch independence node")
+    net._ensure_handle().set_option("gemm_bf16", 1)
+    ba, bn = net(*args)
+    sa_, sn_ = float(oa.abs().max()), float(on.abs().max())
+    per_graph = torch.maximum((ba - oa).abs().reshape(B, -1).max(1).values / sa_, (bn - on).abs().reshape(B, -1).max(1).values / sn_)
+    assert float(per_graph.max()) <= BF16_MAX_RTOL, f"worst graph {int(per_graph.argmax())}: {float(per_graph.max()):.2e}"
+    assert float(per_graph.max()) > 1e-5, "bf16 mode did not engage"
+    assert torch.all(bn[~f] == 0)

@@ -188,3 +188,43 @@ def test_pack_decoded_roundtrip():
     assert vg.numel() * vg.element_size() == 2 * (4096 + 64 + 64) + 1024          # 9.3 KB per VG graph vs 101 KB raw
     a2, n2, f2, b2 = dio.unpack_decoded(p, n, True)
     assert torch.equal(a2, qa) and torch.equal(n2, qn) and torch.equal(f2, fl) and torch.equal(b2, bb)
+
+
+def _run_bench(args, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_bench_self_launches_two_ranks_gloo():
+    """`python bench.py --gpus 2` with no torchrun environment: the parent spawns torch.distributed.run (2 ranks, 127.0.0.1),
+    the ranks run the bench's own barrier / max-over-ranks timing / packed all-gather sequence over gloo with a stand-in
+    step, rank 0's single JSON line is relayed and the exit status is the children's"""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "tiny", "--batch", "3", "--selftest-launcher"])
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    ln = lines[0]
+    assert ln["selftest"] and ln["n_gpus"] == 2 and ln["world_size"] == 2 and ln["backend"] == "gloo"
+    assert ln["gathered_rows"] == 6 and ln["steps"] == 2 and ln["warmup"] == 1
+
+
+def test_bench_launcher_propagates_failure():
+    """a rank that dies makes the launcher exit non-zero (here: WORLD_SIZE check fails because torchrun gives 2 ranks to --gpus 3...)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--selftest-launcher"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
+
+
+def test_bench_single_rank_selftest_needs_no_process_group():
+    rc, lines, err = _run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0", "--config", "tiny", "--batch", "2", "--selftest-launcher"])
+    assert rc == 0, err[-2000:]
+    assert lines[0]["world_size"] == 1 and lines[0]["gathered_rows"] == 2
