@@ -103,6 +103,8 @@ struct dsg_handle_s {
     std::map<int, std::unique_ptr<Workspace>> ws;
     // kernel-selection options (dsg_set_option); defaults may be overridden once by DSG_* environment variables
     bool opt_fused_attn = true, opt_fused_mlp = true, opt_fused_readout = true, opt_fused_pe = true;
+    bool opt_fused_qkv_attn = true;   // QKV projection + 64-token window attention in one kernel (q, k, v never reach HBM)
+    bool opt_fused_rowstats = true;   // modulate+SiLU and LayerNorm statistics in the producing GEMM's epilogue (fp32 kernel)
     bool opt_gemm_bf16 = false;                                   // bf16-MFMA GEMMs (fp32 accumulate), opt-in precision mode
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
@@ -492,6 +494,8 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     h->opt_fused_mlp = env_on("DSG_FUSED_MLP", true);
     h->opt_fused_readout = env_on("DSG_FUSED_READOUT", true);
     h->opt_fused_pe = env_on("DSG_FUSED_PE", true);
+    h->opt_fused_rowstats = env_on("DSG_FUSED_ROWSTATS", true);
+    h->opt_fused_qkv_attn = env_on("DSG_FUSED_QKV_ATTN", true);
     if (getenv("DSG_FUSED_MLP_MAXC")) h->opt_fused_mlp_maxc = atoi(getenv("DSG_FUSED_MLP_MAXC"));
     h->opt_gemm_bf16 = env_on("DSG_GEMM_BF16", false);
     h->opt_gemm_split = env_on("DSG_GEMM_SPLIT", false);
@@ -800,14 +804,31 @@ void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStre
 #define P_GEMM_LP(g) do { (g).Ws3 = split_of(h, (g).W); (g).Wb = (g).Ws3 ? nullptr : bf16_of(h, (g).W); P_GEMM_(g); } while (0)
 #define P_GEMM(g) do { (g).Ws3 = split_of(h, (g).W); (g).Wb = nullptr; P_GEMM_(g); } while (0)
 #define P_GEMM_(g) do { char tg_[96]; if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) (g).prof = h->prof_gemm + 2 * (h->prof_gemm_used++); else (g).prof = nullptr; \
-    if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm M=%d N=%d K=%d ln=%d act=%d res=%d", (g).M, (g).N, (g).K, (g).ln_stats != nullptr, (g).act, (g).res != nullptr); \
+    if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm M=%d N=%d K=%d ln=%d act=%d res=%d", (g).M, (g).N, (g).K, ((g).ln_stats != nullptr) + 2 * ((g).ln_part != nullptr) + 4 * ((g).stats_out != nullptr) + 8 * ((g).mod_aff != nullptr), (g).act, (g).res != nullptr); \
     ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)(g).M * (double)(g).N * (double)(g).K, tg_); launch_gemm((g), s); } while (0)
 #define P_KERN(kind, flops, call) do { ProfScope ps_(h, s, (kind), (flops), #call); call; } while (0)
 
-// One Swin block (diffusesg.py:232-277) on x [B*T, C] in place.
-void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
+// Row-kernel fusion (fp32 GEMM kernel only; off while debug taps want the un-modulated block outputs): the GEMM that produces
+// a block's input also applies that block's modulate+SiLU and leaves per-column-tile (sum, sumsq) partials of the stored rows
+// in w->stats, from which the consuming GEMM forms the LayerNorm statistics -- mod_stats / ln_stats launches disappear.
+bool rowstats_on(dsg_handle h) { return h->opt_fused_rowstats && !h->opt_gemm_bf16 && !h->opt_gemm_split && h->taps.empty(); }
+// does block `nb` take its input pre-modulated with LN1 partials?  (the C = 96 fused attention kernel modulates itself)
+bool wants_premod(dsg_handle h, const BlockPlan *nb) { return nb && rowstats_on(h) && !(h->opt_fused_attn && nb->wqp); }
+// attach "modulate for block nb + row statistics" to the GEMM that writes nb's input (M rows = B * T tokens of nb's level)
+void attach_premod(dsg_handle h, Workspace *w, GemmArgs &g, const BlockPlan *nb) {
+    if (!wants_premod(h, nb)) return;
+    g.stats_out = w->stats;
+    g.mod_aff = w->aff; g.mod_ld = w->aff_ld; g.mod_off = nb->aff_off; g.mod_T = nb->res * nb->res;
+}
+
+// One Swin block (diffusesg.py:232-277) on x [B*T, C] in place.  premod: x is already modulated and w->stats holds the LN1
+// partials (attach_premod on the producer).  next: the block that consumes this block's output directly (same width), or null.
+// Returns true if `next`'s input was left pre-modulated.
+bool run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, const BlockPlan *next, hipStream_t s) {
     const int B = w->B, T = b.res * b.res, C = b.C, M = B * T, Hd = h->cfg.mlp_ratio * C;
     const std::string &p = b.prefix;
+    const bool fuse = rowstats_on(h);
+    const bool mlp_fused = h->opt_fused_mlp && b.w1p && C <= h->opt_fused_mlp_maxc;
     GemmArgs g;
     if (h->opt_fused_attn && b.wqp) {
         // modulate+SiLU, LN1, QKV, window attention, proj and the residual in one register-resident kernel
@@ -817,31 +838,48 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
                                    b.bqkv_s, b.biasT, b.wpp, WT(h, p + ".attn.proj.bias"), B, wg, s));
     } else {
         // x <- silu(shift + x*(1+scale)) (also the shortcut), LayerNorm-1 statistics
-        P_KERN(PK_ROW, 0.0, launch_mod_stats(w->x, w->aff, w->aff_ld, b.aff_off, w->stats, B, T, C, s));
+        if (!premod) P_KERN(PK_ROW, 0.0, launch_mod_stats(w->x, w->aff, w->aff_ld, b.aff_off, w->stats, B, T, C, s));
         g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M;
-        g.ln_stats = w->stats;   // gamma/beta of norm1 are folded into qkv_wf / qkv_bf
+        if (premod) { g.ln_part = w->stats; g.ln_nparts = (C + 95) / 96; }
+        else g.ln_stats = w->stats;   // gamma/beta of norm1 are folded into qkv_wf / qkv_bf
         g.W = b.qkv_wf; g.bias = b.qkv_bf; g.N = 3 * C;
-        g.C = w->qkv; g.ldc = 3 * C;
-        P_GEMM_LP(g);
         WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
-        P_KERN(PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s));
+        bool attn_done = false;
+        if (h->opt_fused_qkv_attn && b.ws == 8 && !h->opt_gemm_bf16 && !h->opt_gemm_split) {
+            // LN1 -> QKV -> softmax(q k^T + bias) v in one kernel: q, k, v of (two windows, one head) stay in LDS
+            g.attn_bias = b.biasT; g.wg = wg; g.attn_batch = B; g.C = w->att; g.ldc = C;
+            char tg_[96];
+            if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) g.prof = h->prof_gemm + 2 * (h->prof_gemm_used++);
+            if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm+attn M=%d N=%d K=%d ln=%d heads=%d", g.M, g.N, g.K, g.ln_part ? 2 : 1, b.heads);
+            ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)M * 3.0 * C * C + 4.0 * (double)M * 64.0 * (double)C, tg_);
+            attn_done = launch_gemm_qkv_attn(g, s);
+        }
+        if (!attn_done) {
+            g.attn_bias = nullptr; g.prof = nullptr;
+            g.C = w->qkv; g.ldc = 3 * C;
+            P_GEMM_LP(g);
+            P_KERN(PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s));
+        }
         g = GemmArgs();
         g.A = w->att; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = C;
         g.W = WT(h, p + ".attn.proj.weight"); g.bias = WT(h, p + ".attn.proj.bias");
         g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
+        if (fuse && !mlp_fused) g.stats_out = w->stats;   // LN2 partials of x + proj(...)
         P_GEMM_LP(g);
     }
-    if (h->opt_fused_mlp && b.w1p && C <= h->opt_fused_mlp_maxc) {
+    if (mlp_fused) {
         // LN2 + fc1 + GELU + fc2 + residual in one kernel, hidden activations never leave the register file
         P_KERN(PK_FUSED, 4.0 * (double)M * (double)C * (double)Hd,
                launch_fused_mlp(w->x, WT(h, p + ".norm2.weight"), WT(h, p + ".norm2.bias"), b.w1p, WT(h, p + ".mlp.fc1.bias"), b.w2p,
                                 WT(h, p + ".mlp.fc2.bias"), M, C, s));
-        return;
+        return false;   // the fused MLP has no modulate epilogue: the next block runs its own mod_stats
     }
-    P_KERN(PK_ROW, 0.0, launch_ln_stats(w->x, w->stats, M, C, s));
+    const bool ln2_part = fuse && !(h->opt_fused_attn && b.wqp);   // the proj GEMM above left the partials
+    if (!ln2_part) P_KERN(PK_ROW, 0.0, launch_ln_stats(w->x, w->stats, M, C, s));
     g = GemmArgs();
     g.A = w->x; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = Hd;
-    g.ln_stats = w->stats;   // gamma/beta of norm2 are folded into fc1_wf / fc1_bf
+    if (ln2_part) { g.ln_part = w->stats; g.ln_nparts = (C + 95) / 96; }
+    else g.ln_stats = w->stats;   // gamma/beta of norm2 are folded into fc1_wf / fc1_bf
     g.W = b.fc1_wf; g.bias = b.fc1_bf; g.act = ACT_GELU;
     g.C = w->hid; g.ldc = Hd;
     P_GEMM_LP(g);
@@ -849,7 +887,9 @@ void run_block(dsg_handle h, Workspace *w, const BlockPlan &b, hipStream_t s) {
     g.A = w->hid; g.lda = Hd; g.K1 = Hd; g.K = Hd; g.M = M; g.N = C;
     g.W = WT(h, p + ".mlp.fc2.weight"); g.bias = WT(h, p + ".mlp.fc2.bias");
     g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
+    attach_premod(h, w, g, next);
     P_GEMM_LP(g);
+    return g.stats_out != nullptr;
 }
 
 // PositionalEmbedding + map_layer0/1 + all affine linears for `rows` noise labels (diffusesg.py:768-771, :238, :574)
@@ -901,10 +941,14 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     }
     tap(h, "patch_embed", w->x, (size_t)B * T0 * E, s);
     // encoder (diffusesg.py:745-748)
+    bool premod = false;   // is w->x already modulated for the next block, with its LN1 partials in w->stats?
     for (int l = 0; l < L; l++) {
         const int C = E << l, res = N >> l, T = res * res;
         for (size_t j = 0; j < h->down[l].size(); j++) {
-            run_block(h, w, h->down[l][j], s);
+            // the consumer of this block's output: the next block of the level; after the deepest level the first decoder
+            // block (no upsample there); otherwise PatchMerging, which takes the un-modulated tensor
+            const BlockPlan *next = j + 1 < h->down[l].size() ? &h->down[l][j + 1] : (l == L - 1 && !h->up[0].empty() ? &h->up[0][0] : nullptr);
+            premod = run_block(h, w, h->down[l][j], premod, next, s);
             snprintf(name, sizeof(name), "down%d.block%d", l, (int)j);
             tap(h, name, w->x, (size_t)B * T * C, s);
         }
@@ -914,7 +958,9 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
             g = GemmArgs();
             g.A = w->y; g.lda = 4 * C; g.K1 = 4 * C; g.K = 4 * C; g.M = B * T / 4; g.N = 2 * C;
             g.W = WT(h, p + ".reduction.weight"); g.C = w->x; g.ldc = 2 * C; g.C2 = w->skips[l]; g.ldc2 = 2 * C;
+            attach_premod(h, w, g, h->down[l + 1].empty() ? nullptr : &h->down[l + 1][0]);   // the skip copy (C2) stays un-modulated
             P_GEMM_LP(g);
+            premod = g.stats_out != nullptr;
         }
         snprintf(name, sizeof(name), "down%d", l);
         tap(h, name, w->x, l < L - 1 ? (size_t)B * (T / 4) * 2 * C : (size_t)B * T * C, s);
@@ -935,12 +981,15 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
             g = GemmArgs();
             g.A = w->y; g.lda = C; g.K1 = C; g.K = C; g.M = B * T; g.N = C;
             g.W = WT(h, p + ".post_linear.weight"); g.C = w->x; g.ldc = C;
+            attach_premod(h, w, g, h->up[i].empty() ? nullptr : &h->up[i][0]);
             P_GEMM_LP(g);
+            premod = g.stats_out != nullptr;
             snprintf(name, sizeof(name), "up%d.upsample", i);
             tap(h, name, w->x, (size_t)B * T * C, s);
         }
         for (size_t j = 0; j < h->up[i].size(); j++) {
-            run_block(h, w, h->up[i][j], s);
+            const BlockPlan *next = j + 1 < h->up[i].size() ? &h->up[i][j + 1] : nullptr;   // then PatchBreakup / the read-out
+            premod = run_block(h, w, h->up[i][j], premod, next, s);
             snprintf(name, sizeof(name), "up%d.block%d", i, (int)j);
             tap(h, name, w->x, (size_t)B * T * C, s);
         }
@@ -1075,6 +1124,8 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "fused_mlp_maxc") h->opt_fused_mlp_maxc = value;
     else if (n == "fused_readout") h->opt_fused_readout = value != 0;
     else if (n == "fused_patch_embed") h->opt_fused_pe = value != 0;
+    else if (n == "fused_rowstats") h->opt_fused_rowstats = value != 0;
+    else if (n == "fused_qkv_attn") h->opt_fused_qkv_attn = value != 0;
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
         if (h->opt_gemm_bf16 && h->finalized) if (int rc = ensure_bf16_weights(h)) return rc;
@@ -1100,6 +1151,8 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "fused_mlp_maxc") *value = h->opt_fused_mlp_maxc;
     else if (n == "fused_readout") *value = h->opt_fused_readout;
     else if (n == "fused_patch_embed") *value = h->opt_fused_pe;
+    else if (n == "fused_rowstats") *value = h->opt_fused_rowstats;
+    else if (n == "fused_qkv_attn") *value = h->opt_fused_qkv_attn;
     else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
     else if (n == "gemm_split") *value = h->opt_gemm_split;
     else return fail(h, DSG_ERR_INVALID, "unknown option '%s'", name);

@@ -7,6 +7,15 @@ namespace dsg {
 
 enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
 
+// geometry of one Swin block's windows
+struct WinGeom {
+    int res;      // tokens per side
+    int ws;       // window side
+    int shift;    // cyclic shift (0 or ws/2)
+    int heads;
+    int C;
+};
+
 // C[M,N] = act( pro(A)[M,K] * W[N,K]^T + bias ) (+ res), optionally stored twice.
 struct GemmArgs {
     const float *A = nullptr;  int lda = 0;      // rows of K1 floats (k <  K1)
@@ -23,10 +32,27 @@ struct GemmArgs {
     float *C2 = nullptr; int ldc2 = 0;           // optional second destination
     int M = 0, N = 0, K = 0;                     // K % 32 == 0
     int act = ACT_NONE;
+    // LayerNorm statistics from per-column-tile partial sums written by the PRODUCING GEMM's epilogue (stats_out below):
+    // ln_part [M][ln_nparts][2] = (sum, sum of squares) over 96 columns each; mean/rstd are formed in the prologue
+    const float *ln_part = nullptr; int ln_nparts = 0;
+    // epilogue extensions of the fp32 kernel (act == ACT_NONE only): the next Swin block's modulate+SiLU
+    // x <- silu(shift + x*(1+scale)) applied to the value stored to C (C2 keeps the un-modulated value), with
+    // (scale,shift) = mod_aff[b*mod_ld + mod_off + {n, N+n}], b = row / mod_T (mod_ld == 0: one row for the whole batch);
+    // and the row statistics of what was stored to C: stats_out [M][ceil(N/96)][2] partial (sum, sumsq) per column tile
+    const float *mod_aff = nullptr; int mod_ld = 0, mod_off = 0, mod_T = 1;
+    float *stats_out = nullptr;
+    // fused QKV projection + window attention (8x8 windows; launch_gemm_qkv_attn): W = qkv weight [3C,K] (q rows pre-scaled),
+    // bias = qkv bias [3C]; a block computes q|k|v of ONE head for TWO windows (rows gathered through the window partition /
+    // cyclic shift), runs softmax(q k^T + attn_bias) v from LDS and stores the head's 32 output columns to C [M, wg.C]
+    const float *attn_bias = nullptr;            // [nWt][heads][64][64] key-major, log2(e)-scaled (build_bias_table)
+    WinGeom wg{0, 0, 0, 0, 0};
+    int attn_batch = 0;
     const float *gelu_tab = nullptr;             // filled in by launch_gemm (table-driven GELU of the split kernel)
     unsigned long long *prof = nullptr;          // measurement mode: {min block start, max block end} in 100 MHz ticks
 };
 void launch_gemm(const GemmArgs &g, hipStream_t s);
+// fused LN1 -> QKV -> window attention for 64-token windows (fp32 kernel); returns false if the geometry is not supported
+bool launch_gemm_qkv_attn(const GemmArgs &g, hipStream_t s);
 void launch_f32_to_bf16(const float *src, void *dst, size_t n, hipStream_t s);
 void launch_f32_split3(const float *src, void *dst, size_t n, hipStream_t s);
 // device table of the fused MLP's table-driven GELU; must be called once (outside any stream capture) before the first launch
@@ -36,14 +62,6 @@ const float *gelu_table();
 void launch_fused_mlp(float *x, const float *gam, const float *bet, const float *W1p, const float *b1, const float *W2p,
                       const float *b2, int M, int C, hipStream_t s);
 
-// geometry of one Swin block's windows
-struct WinGeom {
-    int res;      // tokens per side
-    int ws;       // window side
-    int shift;    // cyclic shift (0 or ws/2)
-    int heads;
-    int C;
-};
 // input assembly + 1x1 conv + LayerNorm + modulate+SiLU in one kernel (E = 96, in_chans <= 64); false if unsupported
 bool launch_fused_patch_embed96(const float *adj, const float *node, const float *sc_adj, const float *sc_node, const int *has_sc,
                                 const uint8_t *flags, const float *Wp, const float *bias, const float *gam, const float *bet,

@@ -46,7 +46,11 @@ __device__ unsigned long long *g_diag_buf = nullptr;
 //     beta into the bias when the weights are packed (dsg_finalize_weights);
 //   * the epilogue uses buffer stores / loads with scalar row offsets.
 // -------------------------------------------------------------------------------------------------
-template <bool LN, int ACT, bool RES>
+// EPI (epilogue extension, see GemmArgs): 0 none; 1 row-statistics partials; 2 batch-uniform modulate+SiLU + partials;
+// 3 per-sample modulate+SiLU + partials; 4 fused window attention: the tile is (two 64-token windows) x (q|k|v of one head),
+// tile rows are gathered through the window partition / cyclic shift (diffusesg.py:28-57, :246-256), q, k, v go to LDS
+// instead of HBM and softmax(q k^T + bias) v runs from there (same operand scheme as window_attn_kernel below).
+template <bool LN, int ACT, bool RES, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (GBM + GBN) * GLD];
     constexpr int BUF = (GBM + GBN) * GLD;
@@ -63,26 +67,72 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     unsigned long long prof_t0 = 0;
     if (g.prof && tid == 0) prof_t0 = __builtin_amdgcn_s_memrealtime();
 
+    // EPI == 4: tile row r -> token row of the activation: window 2*tm + r/64, position r%64 inside the (shifted) window
+    const int a_res = g.wg.res, a_nwr = (EPI == 4) ? a_res / 8 : 1, a_nW = a_nwr * a_nwr, a_T = a_res * a_res;
+    const int a_nwin = g.attn_batch * a_nW;
+    auto win_row = [&](int r) -> int {   // global row of tile row r, or -1 if its window does not exist
+        const int gw = 2 * tm + (r >> 6), pos = r & 63;
+        if (gw >= a_nwin) return -1;
+        const int b = gw / a_nW, w = gw - b * a_nW, wi = w / a_nwr, wj = w - wi * a_nwr;
+        int ti = wi * 8 + (pos >> 3) + g.wg.shift, tj = wj * 8 + (pos & 7) + g.wg.shift;
+        if (ti >= a_res) ti -= a_res;
+        if (tj >= a_res) tj -= a_res;
+        return b * a_T + ti * a_res + tj;
+    };
     // block-uniform descriptors: base = first row of the tile, range = the valid rows (out-of-range reads give 0)
-    const rsrc_t rsA1 = make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
+    const rsrc_t rsA1 = (EPI == 4) ? make_rsrc(g.A, (unsigned)g.M * g.lda * 4u) : make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
     const rsrc_t rsA2 = make_rsrc(g.A2 ? g.A2 + (size_t)m0 * g.lda2 : g.A, g.A2 ? (unsigned)rows_m * g.lda2 * 4u : 0u);
-    const rsrc_t rsW = make_rsrc(g.W + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 4u);
+    const rsrc_t rsW = (EPI == 4) ? make_rsrc(g.W, (unsigned)(3 * g.wg.C) * g.K * 4u) : make_rsrc(g.W + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 4u);
     unsigned voffA1[4], voffA2[4], voffW[3];
     float a_rstd[4], a_nmr[4];
+    int my_tok = -1;   // EPI == 4: token row of tile row `tid` (threads 0..127), for the output scatter
+    if (EPI == 4 && tid < GBM) my_tok = win_row(tid);
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         const int r = r0 + 32 * p;
         voffA1[p] = ((unsigned)r * g.lda + 4u * c4) * 4u;
         voffA2[p] = ((unsigned)r * g.lda2 + 4u * c4) * 4u;
+        int grow = 0;
+        if (EPI == 4) {
+            grow = win_row(r);
+            voffA1[p] = grow >= 0 ? ((unsigned)grow * g.lda + 4u * c4) * 4u : 0x7fffffffu;
+        }
         if (LN) {
-            const int m = min(m0 + r, g.M - 1);
-            const float mean = g.ln_stats[2 * m], rstd = g.ln_stats[2 * m + 1];
+            const int m = (EPI == 4) ? max(grow, 0) : min(m0 + r, g.M - 1);
+            float mean, rstd;
+            if (g.ln_part) {   // partial (sum, sumsq) per 96-column tile of the producer: [M][nparts][2], added in tile order
+                const float *pp = g.ln_part + (size_t)m * g.ln_nparts * 2;
+                float sm, sq;
+                if (g.ln_nparts == 2) {          // all loads of a row independent: one memory latency in the prologue
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(pp);
+                    sm = a[0] + a[2]; sq = a[1] + a[3];
+                } else if (g.ln_nparts == 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(pp), b = *reinterpret_cast<const f32x4 *>(pp + 4);
+                    sm = (a[0] + a[2]) + (b[0] + b[2]); sq = (a[1] + a[3]) + (b[1] + b[3]);
+                } else if (g.ln_nparts == 8) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(pp), b = *reinterpret_cast<const f32x4 *>(pp + 4),
+                                c = *reinterpret_cast<const f32x4 *>(pp + 8), d = *reinterpret_cast<const f32x4 *>(pp + 12);
+                    sm = ((a[0] + a[2]) + (b[0] + b[2])) + ((c[0] + c[2]) + (d[0] + d[2]));
+                    sq = ((a[1] + a[3]) + (b[1] + b[3])) + ((c[1] + c[3]) + (d[1] + d[3]));
+                } else {
+                    sm = 0.f; sq = 0.f;
+                    for (int t = 0; t < g.ln_nparts; t++) { sm += pp[2 * t]; sq += pp[2 * t + 1]; }
+                }
+                const float invk = 1.0f / (float)g.K;
+                mean = sm * invk;
+                rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);
+            } else {
+                mean = g.ln_stats[2 * m]; rstd = g.ln_stats[2 * m + 1];
+            }
             a_rstd[p] = rstd;
             a_nmr[p] = -mean * rstd;
         }
     }
 #pragma unroll
-    for (int p = 0; p < 3; p++) voffW[p] = ((unsigned)(r0 + 32 * p) * g.K + 4u * c4) * 4u;
+    for (int p = 0; p < 3; p++) {
+        voffW[p] = ((unsigned)(r0 + 32 * p) * g.K + 4u * c4) * 4u;
+        if (EPI == 4) voffW[p] = ((unsigned)(p * g.wg.C + tn * 32 + r0) * g.K + 4u * c4) * 4u;   // rows [q_h | k_h | v_h] of head tn
+    }
     const int nk = g.K / GBK;
     const int nk1 = g.A2 ? g.K1 / GBK : nk;  // chunks served by the first source
 
@@ -192,6 +242,86 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     }
 #endif
 
+    if (EPI == 4) {
+        // ---- fused window attention: q, k, v of (two windows, one head) -> LDS -> S^T = K Q^T + bias -> softmax -> P V ----
+        constexpr int QKV = GBM * GLD;   // one [128][36] slab each for q, k, v; the token table sits behind them
+        float *Qs = lds, *Ks = lds + QKV, *Vs = lds + 2 * QKV;
+        int *toks = reinterpret_cast<int *>(lds + 3 * QKV);
+        __syncthreads();                 // every wave is done with the K loop's tiles
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float bias = g.bias ? g.bias[j * g.wg.C + tn * 32 + lrow] : 0.f;
+            float *dst = lds + j * QKV + (wave * 32 + 4 * lhalf) * GLD + lrow;
+#pragma unroll
+            for (int r = 0; r < 16; r++) dst[((r & 3) + 8 * (r >> 2)) * GLD] = acc[j][r] + bias;
+        }
+        if (tid < GBM) toks[tid] = my_tok;
+        __syncthreads();
+        const int wl = wave >> 1, qh = wave & 1;
+        const int gw = 2 * tm + wl;
+        if (gw < a_nwin) {               // wave-uniform: the second window of the last tile may not exist
+            f32x4 kf[2][4], qf[4];
+            float vf[2][16];
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) {
+#pragma unroll
+                for (int sx = 0; sx < 4; sx++)
+                    kf[kt][sx] = *reinterpret_cast<const f32x4 *>(Ks + (64 * wl + 32 * kt + lrow) * GLD + 8 * sx + 4 * lhalf);
+#pragma unroll
+                for (int r = 0; r < 16; r++) vf[kt][r] = Vs[(64 * wl + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * GLD + lrow];
+            }
+#pragma unroll
+            for (int sx = 0; sx < 4; sx++) qf[sx] = *reinterpret_cast<const f32x4 *>(Qs + (32 * wave + lrow) * GLD + 8 * sx + 4 * lhalf);
+            const int wtype = g.wg.shift > 0 ? gw % a_nW : 0;
+            const rsrc_t rsB = make_rsrc(g.attn_bias + ((size_t)wtype * g.wg.heads + tn) * 4096, 4096u * 4u);
+            const unsigned boff = (unsigned)(4 * lhalf * 64 + 32 * qh + lrow) * 4u;
+            f32x16 sacc[2];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) sacc[kt][r] = buf_load1(rsB, boff, (unsigned)((32 * kt + (r & 3) + 8 * (r >> 2)) * 64) * 4u);
+#pragma unroll
+                for (int sx = 0; sx < 4; sx++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kt][sx][t], qf[sx][t], sacc[kt], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - mx);   // scores carry the log2(e) factor
+                    sacc[kt][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = fast_rcp(sum);
+            f32x16 oacc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[r] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r] * inv, vf[kt][r], oacc, 0, 0, 0);
+            // O tile: column d = lrow of head tn, row = query (r&3)+8(r>>2)+4*half of this wave's 32 tokens
+            const rsrc_t rsO = make_rsrc(g.C, (unsigned)g.M * g.ldc * 4u);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int tok = toks[32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lhalf];
+                buf_store1(oacc[r], rsO, tok >= 0 ? ((unsigned)tok * g.ldc + (unsigned)(tn * 32 + lrow)) * 4u : 0x7fffffffu, 0u);
+            }
+        }
+        if (g.prof && tid == 0) {
+            __builtin_amdgcn_s_waitcnt(0);
+            atomicMin(g.prof, prof_t0);
+            atomicMax(g.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        }
+        return;
+    }
     // epilogue: buffer stores; lane-dependent part of the address in voffset, (register, tile) part in a scalar offset.
     // rows >= M fall outside the descriptor and are dropped; columns >= N get an out-of-range voffset.
     const rsrc_t rsC = make_rsrc(g.C + (size_t)m0 * g.ldc, (unsigned)rows_m * g.ldc * 4u);
@@ -199,6 +329,20 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     const rsrc_t rsR = make_rsrc(RES ? g.res + (size_t)m0 * g.ldres : g.C, RES ? (unsigned)rows_m * g.ldres * 4u : 0u);
     const unsigned rowl = (unsigned)(wave * 32 + 4 * lhalf);
     const unsigned OOB = 0x7fffffffu;
+    float st_s[16], st_q[16];   // EPI: this lane's share of (sum, sumsq) of its 16 rows
+    int brow[16];               // EPI == 3: sample index of each of the lane's rows
+    if (EPI >= 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) { st_s[r] = 0.f; st_q[r] = 0.f; }
+    }
+    if (EPI == 3) {   // per-sample (scale,shift): row -> sample through a 128-entry LDS table (one division per thread)
+        __syncthreads();   // every wave is done with the K loop's tiles
+        int *bt = reinterpret_cast<int *>(lds) + 4 * 2304;   // behind the four per-wave reduction slabs used below
+        if (tid < GBM) bt[tid] = min(m0 + tid, g.M - 1) / g.mod_T;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) brow[r] = bt[rowl + (r & 3) + 8 * (r >> 2)];
+    }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int n = n0 + 32 * j + lrow;
@@ -207,6 +351,8 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
         const unsigned vC = nok ? (rowl * g.ldc + (unsigned)n) * 4u : OOB;
         const unsigned vC2 = nok ? (rowl * g.ldc2 + (unsigned)n) * 4u : OOB;
         const unsigned vR = nok ? (rowl * g.ldres + (unsigned)n) * 4u : OOB;
+        float msc = 0.f, msh = 0.f;
+        if (EPI == 2 && nok) { msc = g.mod_aff[g.mod_off + n] + 1.0f; msh = g.mod_aff[g.mod_off + g.N + n]; }
         float rres[16];
         if (RES) {
 #pragma unroll
@@ -219,9 +365,38 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
             if (ACT == ACT_GELU) v = gelu_f(v);
             else if (ACT == ACT_SILU) v = silu_exact(v);
             if (RES) v += rres[r];
-            buf_store1(v, rsC, vC, rr * g.ldc * 4u);
             if (g.C2) buf_store1(v, rsC2, vC2, rr * g.ldc2 * 4u);
+            if (EPI == 3 && nok) {
+                const float *ar = g.mod_aff + (size_t)brow[r] * g.mod_ld + g.mod_off + n;
+                msc = ar[0] + 1.0f; msh = ar[g.N];
+            }
+            if (EPI >= 2) v = silu_exact(fmaf(v, msc, msh));
+            if (EPI >= 1 && nok) { st_s[r] += v; st_q[r] = fmaf(v, v, st_q[r]); }
+            buf_store1(v, rsC, vC, rr * g.ldc * 4u);
         }
+    }
+    if (EPI >= 1) {
+        // Row statistics of the stored tile.  A row's 96 values sit in the 32 lanes of a half-wave: transpose through a
+        // per-wave LDS slab (the K loop's tiles are dead) so that lane (row, q) adds the 32 lane-partials of quantity q
+        // of one row in a fixed order, then store the (sum, sumsq) pair of this column tile.
+        if (EPI != 3) __syncthreads();
+        float *red = lds + wave * 2304;   // [2 quantities][32 rows][36]
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            red[row * GLD + lrow] = st_s[r];
+            red[(32 + row) * GLD + lrow] = st_q[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float *src = red + (lhalf * 32 + lrow) * GLD;
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4 *>(src + 4 * i);
+            tot += (q4[0] + q4[1]) + (q4[2] + q4[3]);
+        }
+        const rsrc_t rsP = make_rsrc(g.stats_out + (size_t)m0 * tiles_n * 2, (unsigned)(rows_m * tiles_n) * 8u);   // [M][tiles_n][2]
+        buf_store1(tot, rsP, (unsigned)(((wave * 32 + lrow) * tiles_n + tn) * 2 + lhalf) * 4u, 0u);
     }
 #ifdef DSG_PHASE_DIAG
     if (tid == 0 && g.prof) {   // g.prof doubles as a [4 x blocks] stamp buffer in this build
@@ -260,8 +435,16 @@ void launch_gemm(const GemmArgs &g, hipStream_t s) {
     if ((g.Ws3 || g.Wb) && launch_gemm_lp(g, s)) return;   // opt-in bf16-MFMA modes (kernels_lp.hip)
     const int tiles_m = (g.M + GBM - 1) / GBM, tiles_n = (g.N + GBN - 1) / GBN;
     const dim3 grid(((tiles_m + 7) / 8) * 8 * tiles_n), block(256);
-    const bool ln = g.ln_stats != nullptr, res = g.res != nullptr;
-#define GEMM_CASE(L, A, R) hipLaunchKernelGGL((gemm4_f32_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n)
+    const bool ln = g.ln_stats != nullptr || g.ln_part != nullptr, res = g.res != nullptr;
+#define GEMM_CASE(L, A, R) hipLaunchKernelGGL((gemm4_f32_kernel<L, A, R, 0>), grid, block, 0, s, g, tiles_m, tiles_n)
+#define GEMM_EPI(R, E) hipLaunchKernelGGL((gemm4_f32_kernel<false, ACT_NONE, R, E>), grid, block, 0, s, g, tiles_m, tiles_n)
+    if (g.stats_out) {   // epilogue extensions: only the shapes the forward uses (plain A path, no activation)
+        if (ln || g.act != ACT_NONE) { fprintf(stderr, "dsg: launch_gemm: stats_out with LN/activation is not built\n"); abort(); }
+        const int epi = !g.mod_aff ? 1 : (g.mod_ld == 0 ? 2 : 3);
+        if (res) { if (epi == 1) GEMM_EPI(true, 1); else if (epi == 2) GEMM_EPI(true, 2); else GEMM_EPI(true, 3); }
+        else { if (epi == 1) GEMM_EPI(false, 1); else if (epi == 2) GEMM_EPI(false, 2); else GEMM_EPI(false, 3); }
+        return;
+    }
     if (ln && g.act == ACT_NONE && !res) GEMM_CASE(true, ACT_NONE, false);
     else if (ln && g.act == ACT_GELU && !res) GEMM_CASE(true, ACT_GELU, false);
     else if (!ln && g.act == ACT_NONE && res) GEMM_CASE(false, ACT_NONE, true);
@@ -274,7 +457,20 @@ void launch_gemm(const GemmArgs &g, hipStream_t s) {
     else if (ln && g.act == ACT_SILU && res) GEMM_CASE(true, ACT_SILU, true);
     else if (!ln && g.act == ACT_GELU && res) GEMM_CASE(false, ACT_GELU, true);
     else GEMM_CASE(false, ACT_SILU, true);
+#undef GEMM_EPI
 #undef GEMM_CASE
+}
+
+bool launch_gemm_qkv_attn(const GemmArgs &g, hipStream_t s) {
+    const WinGeom &wg = g.wg;
+    if (wg.ws != 8 || wg.res % 8 != 0 || wg.C != 32 * wg.heads || g.N != 3 * wg.C || g.K % GBK != 0 || g.act != ACT_NONE || g.res ||
+        g.A2 || !g.attn_bias || !(g.ln_stats || g.ln_part) || g.Wb || g.Ws3)
+        return false;
+    const int n_windows = g.attn_batch * (wg.res / 8) * (wg.res / 8);
+    const int tiles_m = (n_windows + 1) / 2, tiles_n = wg.heads;
+    const dim3 grid(((tiles_m + 7) / 8) * 8 * tiles_n), block(256);
+    hipLaunchKernelGGL((gemm4_f32_kernel<true, ACT_NONE, false, 4>), grid, block, 0, s, g, tiles_m, tiles_n);
+    return true;
 }
 
 // =================================================================================================

@@ -139,7 +139,9 @@ int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t
 
 /* Kernel selection.  The narrow levels (C = 96 / 192) have register-resident fused kernels; each can be switched off to
  * fall back to the generic GEMM + attention + row-kernel path (all combinations are parity-tested):
- *   "fused_attn" (C=96 attention block), "fused_mlp", "fused_mlp_maxc" (96|192), "fused_readout", "fused_patch_embed".
+ *   "fused_attn" (C=96 attention block), "fused_mlp", "fused_mlp_maxc" (96|192), "fused_readout", "fused_patch_embed",
+ *   "fused_rowstats" (modulate+SiLU and LayerNorm statistics in the producing GEMM's epilogue instead of row kernels),
+ *   "fused_qkv_attn" (C >= 192, 8x8 windows: QKV projection + window attention in one kernel, q/k/v never reach HBM).
  * Precision modes (default: exact fp32 MFMA everywhere):
  *   "gemm_split" = 1: every GEMM as six bf16-MFMA partial products of hi/mid/lo (3 x bf16 = 24-bit) operand splits with
  *       fp32 accumulation -- fp32-level accuracy, the 1e-4 parity bar still holds; 1.3-1.6x faster GEMMs (power-bound).

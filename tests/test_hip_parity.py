@@ -105,6 +105,7 @@ def make_sampler(T_, solver="heun", S_churn=40.0, use_graph=True):
 @pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("tag,T_,solver,churn", Y.SAMPLER_RUNS)
 def test_sampler_trajectory_vs_reference(tag, T_, solver, churn, use_graph):
+    """(the sampler's batch-uniform noise level also exercises the uniform-(scale,shift) GEMM epilogue, EPI = 2)"""
     g = load("sampler.npz")
     cfg = Y.CONFIGS["tiny"]()
     flags, ia, inn, na, nn, coin_vals = Y.sampler_case(cfg, T_, 4, Y.SAMPLER_VALID, 3, f"smp/{tag}", solver)
@@ -364,13 +365,16 @@ def test_generic_path_matches_reference(name):
     g = load(f"fwd_{name}.npz")
     net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda").model
     h = net._ensure_handle()
-    for opt in ("fused_attn", "fused_mlp", "fused_readout", "fused_patch_embed"):
+    ALL = ("fused_attn", "fused_mlp", "fused_readout", "fused_patch_embed", "fused_rowstats", "fused_qkv_attn")
+    for opt in ALL:
         h.set_option(opt, 0)
+        assert h.get_option(opt) == 0
     oa, on = net(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
     assert_close(oa.cpu().numpy(), g["sc_adj_out"], FWD_RTOL, f"{name} adj (generic path)")
     assert_close(on.cpu().numpy(), g["sc_node_out"], FWD_RTOL, f"{name} node (generic path)")
-    # and each fused kernel alone on top of the generic path
-    for opt in ("fused_attn", "fused_mlp", "fused_readout", "fused_patch_embed"):
+    # and each fused kernel alone on top of the generic path ("fused_rowstats": modulate+SiLU and LayerNorm statistics in
+    # the producing GEMM's epilogue instead of the mod_stats / ln_stats row kernels -- here with per-sample noise labels)
+    for opt in ALL:
         h.set_option(opt, 1)
         oa, on = net(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
         assert_close(oa.cpu().numpy(), g["sc_adj_out"], FWD_RTOL, f"{name} adj (+{opt})")
@@ -566,20 +570,22 @@ def test_vg_full_batch_kernel_paths_agree_everywhere():
     h = net._ensure_handle()
     args = (T(adj), T(node), T(flags), T(c_noise), T(sc_adj), T(sc_node))
 
-    def run(fused, split):
+    def run(fused, split, rowstats=1):
         for opt in ("fused_attn", "fused_mlp", "fused_readout", "fused_patch_embed"):
             h.set_option(opt, fused)
+        h.set_option("fused_rowstats", rowstats)
+        h.set_option("fused_qkv_attn", rowstats)
         h.set_option("gemm_split", split)
         return [t.clone() for t in net(*args)]
 
     ref_a, ref_n = run(1, 0)
     scale_a, scale_n = float(ref_a.abs().max()), float(ref_n.abs().max())
     for it in range(5):
-        for fused, split in ((1, 0), (0, 0), (1, 1), (0, 1)):
-            oa, on = run(fused, split)
+        for fused, split, rowstats in ((1, 0, 1), (0, 0, 1), (1, 0, 0), (0, 0, 0), (1, 1, 1), (0, 1, 1)):
+            oa, on = run(fused, split, rowstats)
             ea = float((oa - ref_a).abs().max()) / scale_a
             en = float((on - ref_n).abs().max()) / scale_n
-            assert ea <= FWD_RTOL and en <= FWD_RTOL, f"iteration {it} fused={fused} split={split}: {ea:.2e}/{en:.2e}"
+            assert ea <= FWD_RTOL and en <= FWD_RTOL, f"iteration {it} fused={fused} split={split} rowstats={rowstats}: {ea:.2e}/{en:.2e}"
     run(1, 0)
 
 
