@@ -65,6 +65,11 @@ struct Workspace {
     float *in_adj, *in_node, *sc_adj, *sc_node, *c_noise, *f_adj, *f_node;
     uint8_t *flags;
     int *has_sc;
+    // self-conditioning input the next forward_fixed reads: the fixed buffers + device flag above (dsg_denoise, dsg_precond, the
+    // forward-only graph), or -- inside a step body of the reverse loop -- the denoised buffer itself / null, with no flag and
+    // no copy, so that a captured step body consists of kernel nodes only
+    const float *cur_sc_adj = nullptr, *cur_sc_node = nullptr;
+    const int *cur_has_sc = nullptr;
     float *pe, *emb0, *emb, *aff, *tok_in, *x, *y, *qkv, *att, *hid, *stats, *pool, *hn, *pool_ext, *pool_part;
     float *skips[DSG_MAX_LAYERS];
     // sampler state
@@ -76,6 +81,10 @@ struct Workspace {
     int aff_ld = 0;
     hipGraphExec_t graph = nullptr, graph_uniform = nullptr;
     hipStream_t cap_stream = nullptr;
+    // reverse loop: control block (device step counter, seed, recorded-noise pointers) and the captured step bodies, one
+    // per (self-cond slot, output slots, Euler/Heun update, coin of stage 1, coin of stage 2) combination that occurs
+    RunCtl *ctl = nullptr;
+    std::map<int, std::pair<hipGraphExec_t, int>> step_graphs;   // key -> (exec, network forwards inside)
 };
 
 struct Tap { std::string name; float *dst; int64_t cap; };
@@ -103,6 +112,7 @@ struct dsg_handle_s {
     std::map<int, std::unique_ptr<Workspace>> ws;
     // kernel-selection options (dsg_set_option); defaults may be overridden once by DSG_* environment variables
     bool opt_fused_attn = true, opt_fused_mlp = true, opt_fused_readout = true, opt_fused_pe = true;
+    bool opt_loop_graph = true;       // capture whole step bodies of the reverse loop (0: only the network forward is a graph)
     bool opt_fused_qkv_attn = true;   // QKV projection + 64-token window attention in one kernel (q, k, v never reach HBM)
     bool opt_fused_rowstats = true;   // modulate+SiLU and LayerNorm statistics in the producing GEMM's epilogue (fp32 kernel)
     bool opt_gemm_bf16 = false;                                   // bf16-MFMA GEMMs (fp32 accumulate), opt-in precision mode
@@ -114,6 +124,7 @@ struct dsg_handle_s {
     // per-step (scale,shift) table of the sampler (batch-uniform sigma): [cap][aff_n] and its staging buffers
     int tab_cap = 0;
     float *tab_sig = nullptr, *tab_cn = nullptr, *tab_pe = nullptr, *tab_e0 = nullptr, *tab_e1 = nullptr, *tab_aff = nullptr;
+    StepRow *tab_step = nullptr;   // per-step scalars of the loop, read by the table-driven sampler kernels
     std::vector<Tap> taps;
     dsg_sample_stats last_stats{};
     // per-kernel-class timing (dsg_profile_forward): HIP events bracketing every launch on the launch stream
@@ -169,6 +180,17 @@ struct ProfScope {
         h->prof_used += 2;
     }
 };
+
+// captured graphs bake weight pointers, kernel selection and table addresses: drop them whenever one of those changes
+void drop_graphs(dsg_handle h) {
+    for (auto &kv : h->ws) {
+        Workspace *w = kv.second.get();
+        if (w->graph) { (void)hipGraphExecDestroy(w->graph); w->graph = nullptr; }
+        if (w->graph_uniform) { (void)hipGraphExecDestroy(w->graph_uniform); w->graph_uniform = nullptr; }
+        for (auto &g : w->step_graphs) (void)hipGraphExecDestroy(g.second.first);
+        w->step_graphs.clear();
+    }
+}
 
 int level_window(const dsg_config &c, int lvl) {
     const int r = c.max_node_num >> lvl;
@@ -496,6 +518,7 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     h->opt_fused_pe = env_on("DSG_FUSED_PE", true);
     h->opt_fused_rowstats = env_on("DSG_FUSED_ROWSTATS", true);
     h->opt_fused_qkv_attn = env_on("DSG_FUSED_QKV_ATTN", true);
+    h->opt_loop_graph = env_on("DSG_LOOP_GRAPH", true);
     if (getenv("DSG_FUSED_MLP_MAXC")) h->opt_fused_mlp_maxc = atoi(getenv("DSG_FUSED_MLP_MAXC"));
     h->opt_gemm_bf16 = env_on("DSG_GEMM_BF16", false);
     h->opt_gemm_split = env_on("DSG_GEMM_SPLIT", false);
@@ -512,9 +535,9 @@ void dsg_destroy(dsg_handle h) {
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
     if (h->prof_gemm) (void)hipFree(h->prof_gemm);
     for (float *q : {h->tab_sig, h->tab_cn, h->tab_pe, h->tab_e0, h->tab_e1, h->tab_aff}) if (q) (void)hipFree(q);
+    drop_graphs(h);
+    if (h->tab_step) (void)hipFree(h->tab_step);
     for (auto &kv : h->ws) {
-        if (kv.second->graph) (void)hipGraphExecDestroy(kv.second->graph);
-        if (kv.second->graph_uniform) (void)hipGraphExecDestroy(kv.second->graph_uniform);
         if (kv.second->cap_stream) (void)hipStreamDestroy(kv.second->cap_stream);
         for (void *p : kv.second->allocs) (void)hipFree(p);
     }
@@ -697,11 +720,7 @@ int dsg_finalize_weights(dsg_handle h) {
         if (int rc = up(f2p, &h->ro_f2p)) return rc;
         if (int rc = up(gext, &h->ro_gext)) return rc;
     }
-    // captured graphs bake weight pointers: drop them
-    for (auto &kv : h->ws) {
-        if (kv.second->graph) { (void)hipGraphExecDestroy(kv.second->graph); kv.second->graph = nullptr; }
-        if (kv.second->graph_uniform) { (void)hipGraphExecDestroy(kv.second->graph_uniform); kv.second->graph_uniform = nullptr; }
-    }
+    drop_graphs(h);   // captured graphs bake weight pointers
     // bf16 copies (opt-in mode): drop stale ones, list every GEMM weight, rebuild if the mode is on
     for (auto &kv : h->w_bf16) (void)hipFree(kv.second);
     h->w_bf16.clear();
@@ -786,6 +805,8 @@ int get_workspace(dsg_handle h, int B, Workspace **out) {
     w->flags = (uint8_t *)q;
     if (int rc = dev_alloc(h, w->allocs, &q, 16)) return rc;
     w->has_sc = (int *)q;
+    if (int rc = dev_alloc(h, w->allocs, &q, sizeof(RunCtl))) return rc;
+    w->ctl = (RunCtl *)q;
     *out = w.get();
     h->ws[B] = std::move(w);
     return 0;
@@ -924,13 +945,13 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     bool pe_done = false;
     if (h->opt_fused_pe && h->pe_wp) {
         ProfScope ps_(h, s, PK_FUSED, 2.0 * (double)B * T0 * E * h->Cin, "launch_fused_patch_embed96");
-        pe_done = launch_fused_patch_embed96(w->in_adj, w->in_node, w->sc_adj, w->sc_node, w->has_sc, w->flags, h->pe_wp,
+        pe_done = launch_fused_patch_embed96(w->in_adj, w->in_node, w->cur_sc_adj, w->cur_sc_node, w->cur_has_sc, w->flags, h->pe_wp,
                                              WT(h, "patch_embed.proj.bias"), WT(h, "patch_embed.norm.weight"),
                                              WT(h, "patch_embed.norm.bias"), w->aff, w->aff_ld, h->pe_aff_off, w->x, B, N, h->Ca, h->Cn,
                                              c.self_condition, h->Kp, s);
     }
     if (!pe_done) {
-        P_KERN(PK_ELEM, 0.0, launch_assemble(w->in_adj, w->in_node, w->sc_adj, w->sc_node, w->has_sc, w->flags, w->tok_in, B, N, h->Ca, h->Cn,
+        P_KERN(PK_ELEM, 0.0, launch_assemble(w->in_adj, w->in_node, w->cur_sc_adj, w->cur_sc_node, w->cur_has_sc, w->flags, w->tok_in, B, N, h->Ca, h->Cn,
                         c.self_condition, h->Kp, s));
         g = GemmArgs();
         g.A = w->tok_in; g.lda = h->Kp; g.K1 = h->Kp; g.K = h->Kp; g.M = B * T0; g.N = E;
@@ -1081,6 +1102,7 @@ int stage_inputs(dsg_handle h, Workspace *w, const float *adj, const float *node
     }
     HIP_TRY(h, hipMemsetAsync(w->has_sc, 0, 16, s));
     if (has) HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)w->has_sc, 1, 1, s));
+    w->cur_sc_adj = w->sc_adj; w->cur_sc_node = w->sc_node; w->cur_has_sc = w->has_sc;
     return 0;
 }
 
@@ -1107,6 +1129,104 @@ int precond_core(dsg_handle h, Workspace *w, CStatePtrs x, const float *sc_adj, 
     return 0;
 }
 
+// ---- one step of the reverse loop (edm.py:350-427) as a static launch sequence ------------------------------------------
+// Everything that changes from step to step is read on the device from StepRow[ctl->step] / the step's (scale,shift) row, so
+// the sequence below depends only on the StepPlan and can be captured once per plan and replayed for every step it fits.
+struct StepPlan {
+    int sc_slot;          // d_* buffer holding the self-conditioning input of stage 1, -1 = None
+    int s1, s2;           // d_* buffers receiving the stage-1 / stage-2 denoised outputs
+    bool euler;           // Euler update (solver 'euler', or the last step: edm.py:394-396), else Heun
+    bool coin1, coin2;    // outcome of the self-conditioning coin of each preconditioned call (precond.py:90)
+    int key() const { return (sc_slot + 1) | (s1 << 2) | (s2 << 4) | ((int)euler << 6) | ((int)coin1 << 7) | ((int)coin2 << 8); }
+};
+
+// NodeAdjPrecond.forward at sigma[step] on workspace state x -> dst; forwards run inline on `s` (capturable)
+// fwd_graph: replay the captured network forward (round-1 scheme: only the forward is a graph, the loop is host-enqueued)
+int precond_tab(dsg_handle h, Workspace *w, CStatePtrs x, const float *sc_adj, const float *sc_node, bool coin, StatePtrs dst,
+                hipStream_t s, int *nfe, bool fwd_graph) {
+    const Dims d = dims_of(h, w->B);
+    w->uniform = true;
+    launch_precond_in_tab(x, h->tab_step, w->ctl, StatePtrs{w->in_adj, w->in_node}, d, s);
+    const bool has = sc_adj && sc_node && h->cfg.self_condition;
+    if (fwd_graph) {   // the forward-only graph reads the fixed self-cond buffers and the device flag
+        if (int rc = stage_inputs(h, w, nullptr, nullptr, nullptr, sc_adj, sc_node, s)) return rc;
+    } else {           // kernels only: the forward reads the denoised buffer in place (or nothing)
+        w->cur_sc_adj = has ? sc_adj : nullptr; w->cur_sc_node = has ? sc_node : nullptr; w->cur_has_sc = nullptr;
+    }
+    if (h->cfg.self_condition && coin) {  // precond.py:90-98: the D of the extra pass becomes the self-cond input
+        if (int rc = run_forward(h, w, fwd_graph, s)) return rc;
+        (*nfe)++;
+        launch_precond_out_tab(x, CStatePtrs{w->f_adj, w->f_node}, h->tab_step, w->ctl, w->flags, StatePtrs{w->sc_adj, w->sc_node}, d, s);
+        if (fwd_graph) HIP_TRY(h, hipMemsetD32Async((hipDeviceptr_t)w->has_sc, 1, 1, s));
+        else { w->cur_sc_adj = w->sc_adj; w->cur_sc_node = w->sc_node; }
+    }
+    if (int rc = run_forward(h, w, fwd_graph, s)) return rc;
+    (*nfe)++;
+    launch_precond_out_tab(x, CStatePtrs{w->f_adj, w->f_node}, h->tab_step, w->ctl, w->flags, dst, d, s);
+    return 0;
+}
+
+int enqueue_step(dsg_handle h, Workspace *w, const StepPlan &p, const float *gt_adj, const float *gt_node, hipStream_t s, int *nfe,
+                 bool fwd_graph = false) {
+    const Dims d = dims_of(h, w->B);
+    const CStatePtrs xh{w->xh_adj, w->xh_node};
+    launch_churn_tab(CStatePtrs{w->x_adj, w->x_node}, h->tab_step, w->ctl, w->flags, StatePtrs{w->xh_adj, w->xh_node}, d, s);   // edm.py:355-366
+    CStatePtrs D1{gt_adj, gt_node};   // sanity-check mode (edm.py:372-377): the denoiser is bypassed
+    if (!gt_adj) {
+        launch_step_row(h->tab_aff, h->aff_n, w->ctl, w->aff, s);   // this step's (scale,shift) row for every block
+        if (int rc = precond_tab(h, w, xh, p.sc_slot >= 0 ? w->d_adj[p.sc_slot] : nullptr, p.sc_slot >= 0 ? w->d_node[p.sc_slot] : nullptr,
+                                 p.coin1, StatePtrs{w->d_adj[p.s1], w->d_node[p.s1]}, s, nfe, fwd_graph)) return rc;
+        D1 = CStatePtrs{w->d_adj[p.s1], w->d_node[p.s1]};
+    }
+    if (p.euler) {
+        launch_euler_tab(xh, D1, h->tab_step, w->ctl, w->flags, StatePtrs{w->x_adj, w->x_node}, d, s);
+    } else {
+        CStatePtrs D2 = D1;
+        if (!gt_adj) {   // stage 2 re-evaluates at (x_hat, sigma(t_hat)) with self-cond = D1 (edm.py:400-405)
+            const bool sc = h->cfg.self_condition;
+            if (int rc = precond_tab(h, w, xh, sc ? w->d_adj[p.s1] : nullptr, sc ? w->d_node[p.s1] : nullptr, p.coin2,
+                                     StatePtrs{w->d_adj[p.s2], w->d_node[p.s2]}, s, nfe, fwd_graph)) return rc;
+            D2 = CStatePtrs{w->d_adj[p.s2], w->d_node[p.s2]};
+        }
+        launch_heun_tab(xh, D1, D2, h->tab_step, w->ctl, w->flags, StatePtrs{w->x_adj, w->x_node}, d, s);
+    }
+    launch_step_advance(w->ctl, s);
+    return 0;
+}
+
+// capture + instantiate the step body of plan p (no-op if it exists).  Called for every plan of a run BEFORE the run's first
+// launch: instantiating a new graph while earlier graph launches are still in flight on the caller's stream gave wrong
+// trajectories on ROCm 7.2 (tools/loop_graph_ab.py history in DESIGN.md), so nothing is captured mid-flight.
+int ensure_step_graph(dsg_handle h, Workspace *w, const StepPlan &p) {
+    if (w->step_graphs.count(p.key())) return 0;
+    if (!w->cap_stream) HIP_TRY(h, hipStreamCreateWithFlags(&w->cap_stream, hipStreamNonBlocking));
+    hipGraph_t graph;
+    int n = 0;
+    HIP_TRY(h, hipStreamBeginCapture(w->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_step(h, w, p, nullptr, nullptr, w->cap_stream, &n);
+    const hipError_t ec = hipStreamEndCapture(w->cap_stream, &graph);
+    if (rc) return rc;
+    if (ec != hipSuccess) return fail(h, DSG_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ec));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(h, DSG_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    w->step_graphs.emplace(p.key(), std::make_pair(exec, n));
+    if (getenv("DSG_GRAPH_VERBOSE")) fprintf(stderr, "[dsg-graph] captured step body key=%d (sc %d s1 %d s2 %d euler %d coins %d%d): %d forwards\n",
+                                             p.key(), p.sc_slot, p.s1, p.s2, (int)p.euler, (int)p.coin1, (int)p.coin2, n);
+    return 0;
+}
+
+// replay the step body of plan p on the caller's stream
+int replay_step(dsg_handle h, Workspace *w, const StepPlan &p, hipStream_t s, int *nfe) {
+    auto it = w->step_graphs.find(p.key());
+    if (it == w->step_graphs.end()) return fail(h, DSG_ERR_STATE, "step body %d was not captured", p.key());
+    HIP_TRY(h, hipGraphLaunch(it->second.first, s));
+    *nfe += it->second.second;
+    h->last_stats.graph_replays += it->second.second;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1126,6 +1246,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "fused_patch_embed") h->opt_fused_pe = value != 0;
     else if (n == "fused_rowstats") h->opt_fused_rowstats = value != 0;
     else if (n == "fused_qkv_attn") h->opt_fused_qkv_attn = value != 0;
+    else if (n == "loop_graph") h->opt_loop_graph = value != 0;
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
         if (h->opt_gemm_bf16 && h->finalized) if (int rc = ensure_bf16_weights(h)) return rc;
@@ -1135,11 +1256,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
         if (h->opt_gemm_split && h->finalized) if (int rc = ensure_split_weights(h)) return rc;
     }
     else return fail(h, DSG_ERR_INVALID, "unknown option '%s'", name);
-    // captured graphs bake the kernel selection
-    for (auto &kv : h->ws) {
-        if (kv.second->graph) { (void)hipGraphExecDestroy(kv.second->graph); kv.second->graph = nullptr; }
-        if (kv.second->graph_uniform) { (void)hipGraphExecDestroy(kv.second->graph_uniform); kv.second->graph_uniform = nullptr; }
-    }
+    drop_graphs(h);   // captured graphs bake the kernel selection
     return DSG_OK;
 }
 
@@ -1153,6 +1270,7 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "fused_patch_embed") *value = h->opt_fused_pe;
     else if (n == "fused_rowstats") *value = h->opt_fused_rowstats;
     else if (n == "fused_qkv_attn") *value = h->opt_fused_qkv_attn;
+    else if (n == "loop_graph") *value = h->opt_loop_graph;
     else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
     else if (n == "gemm_split") *value = h->opt_gemm_split;
     else return fail(h, DSG_ERR_INVALID, "unknown option '%s'", name);
@@ -1277,67 +1395,61 @@ int dsg_sample(dsg_handle h, const dsg_sampler_cfg *cfg, int32_t B, const uint8_
     HIP_TRY(h, hipMemcpyAsync(w->flags, flags, (size_t)B * h->N, hipMemcpyDeviceToDevice, s));
     // x0 = init * sigma(t0) (edm.py:326, :346-347)
     launch_init(CStatePtrs{init_adj, init_node}, t_steps[0], seed, 0u, w->flags, StatePtrs{w->x_adj, w->x_node}, d, s);
-    const bool use_graph = cfg->use_graph != 0;
-    // sigma is batch-uniform (edm.py:371): one noise embedding + (scale,shift) row per step, computed once for all steps
+    const bool use_graph = cfg->use_graph != 0 && !gt_adj && h->taps.empty();
+    // per-step tables on the device: the loop's scalars (StepRow) and, since sigma is batch-uniform (edm.py:371), one noise
+    // embedding + (scale,shift) row per step for all blocks, computed once for all steps in three GEMMs with M = T
+    if (h->tab_cap < T) {
+        drop_graphs(h);   // the captured step bodies bake the table addresses
+        for (float **q : {&h->tab_sig, &h->tab_cn, &h->tab_pe, &h->tab_e0, &h->tab_e1, &h->tab_aff}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+        if (h->tab_step) { (void)hipFree(h->tab_step); h->tab_step = nullptr; }
+        h->tab_cap = 0;
+        HIP_TRY(h, hipMalloc((void **)&h->tab_sig, sizeof(float) * T));
+        HIP_TRY(h, hipMalloc((void **)&h->tab_cn, sizeof(float) * T));
+        HIP_TRY(h, hipMalloc((void **)&h->tab_pe, sizeof(float) * (size_t)T * h->E));
+        HIP_TRY(h, hipMalloc((void **)&h->tab_e0, sizeof(float) * (size_t)T * NOISE_EMB));
+        HIP_TRY(h, hipMalloc((void **)&h->tab_e1, sizeof(float) * (size_t)T * NOISE_EMB));
+        HIP_TRY(h, hipMalloc((void **)&h->tab_aff, sizeof(float) * (size_t)T * h->aff_n));
+        HIP_TRY(h, hipMalloc((void **)&h->tab_step, sizeof(StepRow) * (size_t)T));
+        h->tab_cap = T;
+    }
+    std::vector<StepRow> rows(T);
+    for (int i = 0; i < T; i++) {
+        volatile float t_prime = t_hat[i] + hs[i];  // alpha = 1 (edm.py:391)
+        rows[i] = StepRow{nz[i], t_hat[i], 1.0f / t_hat[i], 1.0f / t_prime, hs[i], {0, 0, 0}};
+    }
+    RunCtl ctl_host{0, 0, (unsigned long long)seed, noise_adj, noise_node};
+    HIP_TRY(h, hipMemcpyAsync(h->tab_step, rows.data(), sizeof(StepRow) * T, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(w->ctl, &ctl_host, sizeof(RunCtl), hipMemcpyHostToDevice, s));
     if (!gt_adj) {
-        if (h->tab_cap < T) {
-            for (float **q : {&h->tab_sig, &h->tab_cn, &h->tab_pe, &h->tab_e0, &h->tab_e1, &h->tab_aff}) { if (*q) (void)hipFree(*q); *q = nullptr; }
-            h->tab_cap = 0;
-            HIP_TRY(h, hipMalloc((void **)&h->tab_sig, sizeof(float) * T));
-            HIP_TRY(h, hipMalloc((void **)&h->tab_cn, sizeof(float) * T));
-            HIP_TRY(h, hipMalloc((void **)&h->tab_pe, sizeof(float) * (size_t)T * h->E));
-            HIP_TRY(h, hipMalloc((void **)&h->tab_e0, sizeof(float) * (size_t)T * NOISE_EMB));
-            HIP_TRY(h, hipMalloc((void **)&h->tab_e1, sizeof(float) * (size_t)T * NOISE_EMB));
-            HIP_TRY(h, hipMalloc((void **)&h->tab_aff, sizeof(float) * (size_t)T * h->aff_n));
-            h->tab_cap = T;
-        }
         HIP_TRY(h, hipMemcpyAsync(h->tab_sig, t_hat.data(), sizeof(float) * T, hipMemcpyHostToDevice, s));
         launch_cnoise(h->tab_sig, h->tab_cn, T, s);
         embed_rows(h, h->tab_cn, T, h->tab_pe, h->tab_e0, h->tab_e1, h->tab_aff, s);
-        HIP_TRY(h, hipStreamSynchronize(s));  // t_hat (host vector) must outlive the async copy; once per sample() call
     }
-    int sc_slot = -1;  // which d_* buffer holds the current self-cond, -1 = None
-    int call = 0, snap_k = 0;
-    int64_t nfe = 0;
-    for (int i = 0; i < T; i++) {
-        // churn (edm.py:355-366)
-        CStatePtrs nptr{noise_adj ? noise_adj + (size_t)i * sa : nullptr, noise_node ? noise_node + (size_t)i * sn : nullptr};
-        launch_churn(CStatePtrs{w->x_adj, w->x_node}, nptr, nz[i], seed, (uint32_t)i, w->flags, StatePtrs{w->xh_adj, w->xh_node}, d, s);
-        launch_fill_f32(w->sig, t_hat[i], B, s);
-        const CStatePtrs xh{w->xh_adj, w->xh_node};
-        const float inv_t = 1.0f / t_hat[i];
+    HIP_TRY(h, hipStreamSynchronize(s));  // the host vectors above must outlive their async copies; once per sample() call
+    // the static plan of every step (edm.py:350-427): buffer rotation, Euler/Heun update, the pre-drawn coins
+    std::vector<StepPlan> plans(T);
+    int call = 0, snap_k = 0, nfe = 0;
+    {
+        int sc_slot = -1;  // which d_* buffer holds the current self-cond, -1 = None
         auto free_slot = [&](int a, int b2) { for (int k = 0; k < 3; k++) if (k != a && k != b2) return k; return 0; };
-        // stage 1
-        const int s1 = free_slot(sc_slot, -1);
-        CStatePtrs D1;
-        if (gt_adj) D1 = CStatePtrs{gt_adj, gt_node};
-        else {
-            if (int rc = precond_core(h, w, xh, sc_slot >= 0 ? w->d_adj[sc_slot] : nullptr, sc_slot >= 0 ? w->d_node[sc_slot] : nullptr,
-                                      coin_buf[call++] != 0, StatePtrs{w->d_adj[s1], w->d_node[s1]}, use_graph, s, &nfe,
-                                      h->tab_aff + (size_t)i * h->aff_n))
-                return rc;
-            D1 = CStatePtrs{w->d_adj[s1], w->d_node[s1]};
+        for (int i = 0; i < T; i++) {
+            StepPlan &p = plans[i];
+            p.sc_slot = sc_slot;
+            p.s1 = free_slot(sc_slot, -1);
+            p.s2 = free_slot(p.s1, -1);
+            p.euler = !cfg->heun || i == T - 1;   // edm.py:394-396
+            p.coin1 = !gt_adj && coin_buf[call] != 0;
+            p.coin2 = !gt_adj && !p.euler && coin_buf[call + 1] != 0;
+            if (!gt_adj) call += p.euler ? 1 : 2;
+            if (!gt_adj && h->cfg.self_condition) sc_slot = p.euler ? p.s1 : p.s2;   // edm.py:423-424: sc <- last denoised
         }
-        if (!cfg->heun || i == T - 1) {  // edm.py:394-396
-            launch_euler(xh, D1, inv_t, hs[i], w->flags, StatePtrs{w->x_adj, w->x_node}, d, s);
-            if (!gt_adj && h->cfg.self_condition) sc_slot = s1;
-        } else {
-            // stage 2 re-evaluates at (x_hat, sigma(t_hat)) with self-cond = D1 (edm.py:400-405)
-            const int s2 = free_slot(s1, -1);
-            CStatePtrs D2;
-            if (gt_adj) D2 = D1;
-            else {
-                const bool sc = h->cfg.self_condition;
-                if (int rc = precond_core(h, w, xh, sc ? w->d_adj[s1] : nullptr, sc ? w->d_node[s1] : nullptr, coin_buf[call++] != 0,
-                                          StatePtrs{w->d_adj[s2], w->d_node[s2]}, use_graph, s, &nfe, h->tab_aff + (size_t)i * h->aff_n))
-                    return rc;
-                D2 = CStatePtrs{w->d_adj[s2], w->d_node[s2]};
-            }
-            volatile float t_prime = t_hat[i] + hs[i];  // alpha = 1 (edm.py:391)
-            const float inv_tp = 1.0f / t_prime;
-            launch_heun(xh, D1, D2, inv_t, inv_tp, hs[i], w->flags, StatePtrs{w->x_adj, w->x_node}, d, s);
-            if (!gt_adj && h->cfg.self_condition) sc_slot = s2;
-        }
+    }
+    const bool step_graphs = use_graph && h->opt_loop_graph;
+    if (step_graphs)
+        for (int i = 0; i < T; i++) if (int rc = ensure_step_graph(h, w, plans[i])) return rc;   // at most ten distinct bodies
+    for (int i = 0; i < T; i++) {
+        if (step_graphs) { if (int rc = replay_step(h, w, plans[i], s, &nfe)) return rc; }
+        else if (int rc = enqueue_step(h, w, plans[i], gt_adj, gt_node, s, &nfe, use_graph)) return rc;
         // interim snapshots (edm.py:429-432)
         while (snap_k < n_snap && snap_steps && snap_steps[snap_k] == i) {
             if (snap_adj) HIP_TRY(h, hipMemcpyAsync(snap_adj + (size_t)snap_k * sa, w->x_adj, sizeof(float) * sa, hipMemcpyDeviceToDevice, s));

@@ -131,6 +131,26 @@ void launch_euler(CStatePtrs xhat, CStatePtrs D, float inv_t, float h, const uin
 void launch_heun(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, float inv_t, float inv_tp, float h, const uint8_t *flags,
                  StatePtrs x, Dims d, hipStream_t s);
 void launch_fill_f32(float *p, float v, int64_t n, hipStream_t s);
+
+// ---- reverse-loop kernels driven by a DEVICE step counter, so that one captured step body can be replayed for every step ----
+// Per-step scalars, computed on the host up front exactly as before (dsg_sigma_schedule) and uploaded once per sample() call.
+struct StepRow { float noise_coef, sigma, inv_t, inv_tp, h; int pad[3]; };
+// Per-run control block at a fixed device address: the step counter the kernels index StepRow[] / the noise streams with.
+struct RunCtl { int step; int pad; unsigned long long seed; const float *noise_adj; const float *noise_node; };
+// x_hat = mask(x + coef[step]*eps), eps = recorded noise[step] (ctl->noise_*) or Philox(seed, step+1)
+void launch_churn_tab(CStatePtrs x, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs xhat, Dims d, hipStream_t s);
+// in = c_in(sigma[step]) * x
+void launch_precond_in_tab(CStatePtrs x, const StepRow *tab, const RunCtl *ctl, StatePtrs in, Dims d, hipStream_t s);
+// D = mask(c_skip*x + c_out*F) at sigma[step]
+void launch_precond_out_tab(CStatePtrs x, CStatePtrs F, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs D, Dims d,
+                            hipStream_t s);
+void launch_euler_tab(CStatePtrs xhat, CStatePtrs D, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs x, Dims d,
+                      hipStream_t s);
+void launch_heun_tab(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags,
+                     StatePtrs x, Dims d, hipStream_t s);
+// dst[0..n) = table[step][0..n)  (the step's (scale,shift) row), and ctl->step += 1
+void launch_step_row(const float *table, int n, const RunCtl *ctl, float *dst, hipStream_t s);
+void launch_step_advance(RunCtl *ctl, hipStream_t s);
 void launch_decode_bits(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,
                         int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d, hipStream_t s);
 

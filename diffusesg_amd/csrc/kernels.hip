@@ -1718,6 +1718,106 @@ void launch_heun(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, float inv_t, flo
     hipLaunchKernelGGL(heun_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xhat, D1, D2, inv_t, inv_tp, h, flags, x, d);
 }
 
+// ---- table-driven variants: identical arithmetic, scalars from StepRow[ctl->step] (one captured step body serves every step) ----
+__global__ void churn_tab_kernel(CStatePtrs x, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs xhat, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_elems(d)) return;
+    const int step = ctl->step;
+    const float coef = tab[step].noise_coef;
+    const ElemIdx e = elem_index(idx, d, flags);
+    const float xv = e.is_adj ? x.adj[e.off] : x.node[e.off];
+    float eps;
+    if (ctl->noise_adj) {
+        const size_t sa = (size_t)d.B * d.Ca * d.N * d.N, sn = (size_t)d.B * d.N * d.Cn;
+        eps = e.is_adj ? ctl->noise_adj[(size_t)step * sa + e.off] : ctl->noise_node[(size_t)step * sn + e.off];
+    } else eps = (coef != 0.f && e.valid) ? philox_normal(ctl->seed, (uint32_t)step + 1u, idx) : 0.f;
+    const float v = e.valid ? FADD(xv, FMUL(coef, eps)) : 0.f;  // edm.py:361-366
+    if (e.is_adj) xhat.adj[e.off] = v; else xhat.node[e.off] = v;
+}
+void launch_churn_tab(CStatePtrs x, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs xhat, Dims d, hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(churn_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, tab, ctl, flags, xhat, d);
+}
+__global__ void precond_in_tab_kernel(CStatePtrs x, const StepRow *tab, const RunCtl *ctl, StatePtrs in, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_elems(d)) return;
+    const ElemIdx e = elem_index(idx, d, nullptr);
+    const float s = tab[ctl->step].sigma;
+    const float c_in = __fdiv_rn(1.0f, __fsqrt_rn(FADD(0.25f, FMUL(s, s))));       // objectives/edm.py:125
+    if (e.is_adj) in.adj[e.off] = FMUL(c_in, x.adj[e.off]);
+    else in.node[e.off] = FMUL(c_in, x.node[e.off]);
+}
+void launch_precond_in_tab(CStatePtrs x, const StepRow *tab, const RunCtl *ctl, StatePtrs in, Dims d, hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(precond_in_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, tab, ctl, in, d);
+}
+__global__ void precond_out_tab_kernel(CStatePtrs x, CStatePtrs F, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags,
+                                       StatePtrs D, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_elems(d)) return;
+    const ElemIdx e = elem_index(idx, d, flags);
+    const float s = tab[ctl->step].sigma;
+    const float s2 = FADD(FMUL(s, s), 0.25f);
+    const float c_skip = __fdiv_rn(0.25f, s2);                                       // objectives/edm.py:123
+    const float c_out = __fdiv_rn(FMUL(s, 0.5f), __fsqrt_rn(s2));                    // objectives/edm.py:124
+    const float xv = e.is_adj ? x.adj[e.off] : x.node[e.off];
+    const float fv = e.is_adj ? F.adj[e.off] : F.node[e.off];
+    const float v = e.valid ? FADD(FMUL(c_skip, xv), FMUL(c_out, fv)) : 0.f;         // precond.py:102-105
+    if (e.is_adj) D.adj[e.off] = v; else D.node[e.off] = v;
+}
+void launch_precond_out_tab(CStatePtrs x, CStatePtrs F, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs D, Dims d,
+                            hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(precond_out_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, F, tab, ctl, flags, D, d);
+}
+__global__ void euler_tab_kernel(CStatePtrs xhat, CStatePtrs D, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs x,
+                                 Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_elems(d)) return;
+    const StepRow r = tab[ctl->step];
+    const ElemIdx e = elem_index(idx, d, flags);
+    const float xh = e.is_adj ? xhat.adj[e.off] : xhat.node[e.off];
+    const float dn = e.is_adj ? D.adj[e.off] : D.node[e.off];
+    const float dc = FSUB(FMUL(r.inv_t, xh), FMUL(r.inv_t, dn));     // edm.py:384-385
+    const float v = e.valid ? FADD(xh, FMUL(r.h, dc)) : 0.f;         // edm.py:395-396, :421-422
+    if (e.is_adj) x.adj[e.off] = v; else x.node[e.off] = v;
+}
+void launch_euler_tab(CStatePtrs xhat, CStatePtrs D, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs x, Dims d,
+                      hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(euler_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xhat, D, tab, ctl, flags, x, d);
+}
+__global__ void heun_tab_kernel(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, const StepRow *tab, const RunCtl *ctl,
+                                const uint8_t *flags, StatePtrs x, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_elems(d)) return;
+    const StepRow r = tab[ctl->step];
+    const ElemIdx e = elem_index(idx, d, flags);
+    const float xh = e.is_adj ? xhat.adj[e.off] : xhat.node[e.off];
+    const float d1 = e.is_adj ? D1.adj[e.off] : D1.node[e.off];
+    const float d2 = e.is_adj ? D2.adj[e.off] : D2.node[e.off];
+    const float dc = FSUB(FMUL(r.inv_t, xh), FMUL(r.inv_t, d1));        // edm.py:384-385
+    const float xp = FADD(xh, FMUL(r.h, dc));                           // edm.py:389-390 (alpha = 1)
+    const float dp = FSUB(FMUL(r.inv_tp, xp), FMUL(r.inv_tp, d2));      // edm.py:414-417
+    const float avg = FADD(FMUL(0.5f, dc), FMUL(0.5f, dp));
+    const float v = e.valid ? FADD(xh, FMUL(r.h, avg)) : 0.f;           // edm.py:418-422
+    if (e.is_adj) x.adj[e.off] = v; else x.node[e.off] = v;
+}
+void launch_heun_tab(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags,
+                     StatePtrs x, Dims d, hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(heun_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xhat, D1, D2, tab, ctl, flags, x, d);
+}
+__global__ void step_row_kernel(const float *table, int n, const RunCtl *ctl, float *dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = table[(size_t)ctl->step * n + i];
+}
+void launch_step_row(const float *table, int n, const RunCtl *ctl, float *dst, hipStream_t s) {
+    hipLaunchKernelGGL(step_row_kernel, dim3((n + 255) / 256), dim3(256), 0, s, table, n, ctl, dst);
+}
+__global__ void step_advance_kernel(RunCtl *ctl) { ctl->step += 1; }
+void launch_step_advance(RunCtl *ctl, hipStream_t s) { hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, ctl); }
+
 __global__ void fill_kernel(float *p, float v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;

@@ -65,7 +65,10 @@ typedef struct dsg_sampler_cfg {
     int32_t heun;                      /* 1: solver='heun', 0: 'euler' */
     float S_churn, S_min, S_max, S_noise;
     double sigma_min, sigma_max, rho;  /* 0.002, 80, 7 */
-    int32_t use_graph;                 /* 1: replay the network forward from a captured hipGraph */
+    int32_t use_graph;                 /* 1: replay captured hipGraphs: whole step bodies of the loop (churn, preconditioning, the
+                                          network forwards, the Euler/Heun update; per-step scalars come from a device table
+                                          indexed by a device step counter), or with option "loop_graph" = 0 only the network
+                                          forward; 0: every kernel is launched eagerly */
     int32_t reserved;
 } dsg_sampler_cfg;
 
@@ -73,7 +76,7 @@ typedef struct dsg_sampler_cfg {
 typedef struct dsg_sample_stats {
     int64_t precond_calls;             /* 2T-1 (heun) or T (euler) */
     int64_t net_forwards;              /* precond_calls + number of coins that fired */
-    int64_t graph_replays;
+    int64_t graph_replays;             /* network forwards that ran from replayed graphs (== net_forwards with use_graph) */
 } dsg_sample_stats;
 
 int dsg_create(const dsg_config *cfg, dsg_handle *out);
@@ -142,6 +145,8 @@ int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t
  *   "fused_attn" (C=96 attention block), "fused_mlp", "fused_mlp_maxc" (96|192), "fused_readout", "fused_patch_embed",
  *   "fused_rowstats" (modulate+SiLU and LayerNorm statistics in the producing GEMM's epilogue instead of row kernels),
  *   "fused_qkv_attn" (C >= 192, 8x8 windows: QKV projection + window attention in one kernel, q/k/v never reach HBM).
+ * Reverse loop: "loop_graph" = 1 (default): dsg_sample replays one captured hipGraph per step (a handful of distinct step bodies:
+ *   first / steady / last step x the two self-conditioning coins); 0: the round-1 scheme, only the network forward is a graph.
  * Precision modes (default: exact fp32 MFMA everywhere):
  *   "gemm_split" = 1: every GEMM as six bf16-MFMA partial products of hi/mid/lo (3 x bf16 = 24-bit) operand splits with
  *       fp32 accumulation -- fp32-level accuracy, the 1e-4 parity bar still holds; 1.3-1.6x faster GEMMs (power-bound).

@@ -796,3 +796,35 @@ def test_coco_batch512_properties():
     assert float(per_graph.max()) <= BF16_MAX_RTOL, f"worst graph {int(per_graph.argmax())}: {float(per_graph.max()):.2e}"
     assert float(per_graph.max()) > 1e-5, "bf16 mode did not engage"
     assert torch.all(bn[~f] == 0)
+
+
+def test_step_graphs_reused_across_runs_match_eager():
+    """The captured step bodies of the reverse loop are cached per (self-cond slot, update, coins) combination and replayed
+    back to back with nothing in between (no snapshots); runs with different coin sequences reuse each other's graphs and
+    capture the combinations they are first to meet.  Every run must equal the eager launch sequence bit for bit.
+    (Regression: a first version kept D2D-copy and memset nodes inside the captured body; on ROCm 7.2 those raced with the
+    neighbouring kernel nodes once graphs were reused across runs -- the body is kernel nodes only now.)"""
+    from diffusesg_amd.model import build_network
+    cfg = Y.CONFIGS["tiny"]()
+    net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")
+    flags = torch.from_numpy(W.synth_flags(4, cfg.max_node_num, Y.SAMPLER_VALID)).cuda()
+    T_ = 120
+
+    def run(use_graph, coin_seed):
+        smp = make_sampler(T_, use_graph=use_graph)
+        np.random.seed(coin_seed)
+        oa, on = smp.sample(net, flags, num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj, seed=2, return_device=True)
+        torch.cuda.synchronize()
+        return oa.clone(), on.clone(), dict(smp.last_stats)
+
+    refs = {k: run(False, k) for k in (1, 2, 3, 4)}
+    for order in ((1, 2, 3, 4), (4, 3, 2, 1, 2)):
+        net.model._ensure_handle().set_option("loop_graph", 1)   # drops the cached graphs: this order captures them afresh
+        for k in order:
+            oa, on, st = run(True, k)
+            assert st["graph_replays"] == st["net_forwards"] == refs[k][2]["net_forwards"]
+            assert torch.equal(oa, refs[k][0]) and torch.equal(on, refs[k][1]), f"coin sequence {k} in order {order}"
+    # the round-1 scheme (only the network forward is a graph) stays available and agrees as well
+    net.model._ensure_handle().set_option("loop_graph", 0)
+    oa, on, st = run(True, 3)
+    assert torch.equal(oa, refs[3][0]) and st["graph_replays"] == st["net_forwards"]
