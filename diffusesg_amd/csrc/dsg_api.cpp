@@ -866,13 +866,13 @@ bool run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, cons
         g.W = b.qkv_wf; g.bias = b.qkv_bf; g.N = 3 * C;
         WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
         bool attn_done = false;
-        if (h->opt_fused_qkv_attn && b.ws == 8 && !h->opt_gemm_bf16 && !h->opt_gemm_split) {
+        if (h->opt_fused_qkv_attn && (b.ws == 8 || b.ws == 10) && !h->opt_gemm_bf16 && !h->opt_gemm_split) {
             // LN1 -> QKV -> softmax(q k^T + bias) v in one kernel: q, k, v of (two windows, one head) stay in LDS
             g.attn_bias = b.biasT; g.wg = wg; g.attn_batch = B; g.C = w->att; g.ldc = C;
             char tg_[96];
             if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) g.prof = h->prof_gemm + 2 * (h->prof_gemm_used++);
             if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm+attn M=%d N=%d K=%d ln=%d heads=%d", g.M, g.N, g.K, g.ln_part ? 2 : 1, b.heads);
-            ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)M * 3.0 * C * C + 4.0 * (double)M * 64.0 * (double)C, tg_);
+            ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)M * 3.0 * C * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, tg_);
             attn_done = launch_gemm_qkv_attn(g, s);
         }
         if (!attn_done) {
@@ -1514,6 +1514,49 @@ int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_
     }
     if (gemm_inkernel_ms_out) *gemm_inkernel_ms_out = gemm_inkernel_ms;
     return DSG_OK;
+}
+
+int dsg_debug_gemm(int32_t M, int32_t N, int32_t K, const float *A, const float *W, const float *bias, const float *ln_stats,
+                   const float *res, int32_t act, int32_t mode, float *C, void *stream) {
+    if (M < 1 || N < 1 || K < 32 || K % 32 != 0 || !A || !W || !C || act < 0 || act > 2 || mode < 0 || mode > 2) return DSG_ERR_INVALID;
+    if (!gelu_table()) return DSG_ERR_HIP;
+    hipStream_t s = (hipStream_t)stream;
+    void *wlp = nullptr;
+    if (mode == 1) { if (hipMalloc(&wlp, (size_t)N * K * 2) != hipSuccess) return DSG_ERR_HIP; launch_f32_to_bf16(W, wlp, (size_t)N * K, s); }
+    if (mode == 2) { if (hipMalloc(&wlp, (size_t)N * K * 6) != hipSuccess) return DSG_ERR_HIP; launch_f32_split3(W, wlp, (size_t)N * K, s); }
+    GemmArgs g;
+    g.A = A; g.lda = K; g.K1 = K; g.K = K; g.M = M; g.N = N; g.W = W; g.bias = bias; g.ln_stats = ln_stats; g.act = act;
+    if (res) { g.res = res; g.ldres = N; }
+    g.C = C; g.ldc = N;
+    if (mode == 1) g.Wb = wlp;
+    if (mode == 2) g.Ws3 = wlp;
+    launch_gemm(g, s);
+    const hipError_t e = hipStreamSynchronize(s);
+    if (wlp) (void)hipFree(wlp);
+    return (e == hipSuccess && hipGetLastError() == hipSuccess) ? DSG_OK : DSG_ERR_HIP;
+}
+
+int dsg_train_inputs(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *clean_adj, const float *clean_node,
+                     const uint8_t *flags, const float *rnd_sigma, const float *eps_adj, const float *eps_node, uint64_t seed,
+                     float *out_sigmas, float *out_weights, float *out_noisy_adj, float *out_noisy_node, void *stream) {
+    if (B < 1 || N < 1 || c_adj < 1 || c_node < 1 || !clean_adj || !clean_node || !flags || !out_sigmas || !out_weights ||
+        !out_noisy_adj || !out_noisy_node || ((eps_adj == nullptr) != (eps_node == nullptr)))
+        return DSG_ERR_INVALID;
+    launch_train_inputs(CStatePtrs{clean_adj, clean_node}, rnd_sigma, CStatePtrs{eps_adj, eps_node}, seed, flags, out_sigmas, out_weights,
+                        StatePtrs{out_noisy_adj, out_noisy_node}, Dims{B, N, c_adj, c_node}, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? DSG_OK : DSG_ERR_HIP;
+}
+
+int dsg_rainbow_loss(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *pred_adj, const float *pred_node,
+                     const float *target_adj, const float *target_node, const uint8_t *flags, const float *loss_weight,
+                     float edge_loss_weight, float node_loss_weight, float iou_loss_weight, float *out_loss_adj, float *out_loss_node,
+                     void *stream) {
+    if (B < 1 || N < 1 || c_adj < 1 || c_node < 1 || !pred_adj || !pred_node || !target_adj || !target_node || !flags || !out_loss_adj ||
+        !out_loss_node || (iou_loss_weight != 0.f && c_node < 4))
+        return DSG_ERR_INVALID;
+    launch_rainbow_loss(CStatePtrs{pred_adj, pred_node}, CStatePtrs{target_adj, target_node}, flags, loss_weight, edge_loss_weight,
+                        node_loss_weight, iou_loss_weight, out_loss_adj, out_loss_node, Dims{B, N, c_adj, c_node}, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? DSG_OK : DSG_ERR_HIP;
 }
 
 int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, int32_t n_adj_type,

@@ -151,6 +151,15 @@ void launch_heun_tab(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, const StepRo
 // dst[0..n) = table[step][0..n)  (the step's (scale,shift) row), and ctl->step += 1
 void launch_step_row(const float *table, int n, const RunCtl *ctl, float *dst, hipStream_t s);
 void launch_step_advance(RunCtl *ctl, hipStream_t s);
+// ---- training-time objective and loss, forward only ----
+// sigma_b = exp(rnd_b*1.2 - 1.2), weight_b = (sigma^2 + .25)/(sigma*.5)^2, noisy = clean + mask(eps*sigma) (adjacency: the sum
+// is masked); rnd / eps: given tensors, or Philox(seed) streams when null (objectives/edm.py:160-180, :239-281)
+void launch_train_inputs(CStatePtrs clean, const float *rnd, CStatePtrs eps, uint64_t seed, const uint8_t *flags, float *sigmas,
+                         float *weights, StatePtrs noisy, Dims d, hipStream_t s);
+// NodeAdjRainbowLoss(reduction='none') + the trainer's bbox IoU term: per-sample losses [B] (rainbow_loss.py:37-101,
+// trainer_node_adj.py:130-159); one block per sample, fixed-order reduction
+void launch_rainbow_loss(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w,
+                         float *loss_adj, float *loss_node, Dims d, hipStream_t s);
 void launch_decode_bits(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,
                         int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d, hipStream_t s);
 

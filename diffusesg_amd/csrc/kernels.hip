@@ -47,10 +47,11 @@ __device__ unsigned long long *g_diag_buf = nullptr;
 //   * the epilogue uses buffer stores / loads with scalar row offsets.
 // -------------------------------------------------------------------------------------------------
 // EPI (epilogue extension, see GemmArgs): 0 none; 1 row-statistics partials; 2 batch-uniform modulate+SiLU + partials;
-// 3 per-sample modulate+SiLU + partials; 4 fused window attention: the tile is (two 64-token windows) x (q|k|v of one head),
-// tile rows are gathered through the window partition / cyclic shift (diffusesg.py:28-57, :246-256), q, k, v go to LDS
-// instead of HBM and softmax(q k^T + bias) v runs from there (same operand scheme as window_attn_kernel below).
-template <bool LN, int ACT, bool RES, int EPI>
+// 3 per-sample modulate+SiLU + partials; 4 fused window attention: the tile is (two 64-token windows | one 100-token window
+// padded to 128 rows) x (q|k|v of one head), tile rows are gathered through the window partition / cyclic shift
+// (diffusesg.py:28-57, :246-256), q, k, v go to LDS instead of HBM and softmax(q k^T + bias) v runs from there (same operand
+// scheme as window_attn_kernel below; padded key slots carry -1e30 in the bias table, padded rows are never stored).
+template <bool LN, int ACT, bool RES, int EPI, int WS = 8>   // WS: window side of the fused attention (EPI == 4): 8 or 10
 __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (GBM + GBN) * GLD];
     constexpr int BUF = (GBM + GBN) * GLD;
@@ -67,14 +68,15 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     unsigned long long prof_t0 = 0;
     if (g.prof && tid == 0) prof_t0 = __builtin_amdgcn_s_memrealtime();
 
-    // EPI == 4: tile row r -> token row of the activation: window 2*tm + r/64, position r%64 inside the (shifted) window
-    const int a_res = g.wg.res, a_nwr = (EPI == 4) ? a_res / 8 : 1, a_nW = a_nwr * a_nwr, a_T = a_res * a_res;
+    // EPI == 4: tile row r -> token row of the activation: window WPT*tm + r/Wp, position r%Wp inside the (shifted) window
+    constexpr int A_WT = WS * WS, A_WP = (A_WT + 31) / 32 * 32, A_KT = A_WP / 32, A_WPT = GBM / A_WP;   // 64/64/2/2 or 100/128/4/1
+    const int a_res = g.wg.res, a_nwr = (EPI == 4) ? a_res / WS : 1, a_nW = a_nwr * a_nwr, a_T = a_res * a_res;
     const int a_nwin = g.attn_batch * a_nW;
-    auto win_row = [&](int r) -> int {   // global row of tile row r, or -1 if its window does not exist
-        const int gw = 2 * tm + (r >> 6), pos = r & 63;
-        if (gw >= a_nwin) return -1;
+    auto win_row = [&](int r) -> int {   // global row of tile row r, or -1 if the window / the position does not exist
+        const int gw = A_WPT * tm + r / A_WP, pos = r % A_WP;
+        if (gw >= a_nwin || pos >= A_WT) return -1;
         const int b = gw / a_nW, w = gw - b * a_nW, wi = w / a_nwr, wj = w - wi * a_nwr;
-        int ti = wi * 8 + (pos >> 3) + g.wg.shift, tj = wj * 8 + (pos & 7) + g.wg.shift;
+        int ti = wi * WS + pos / WS + g.wg.shift, tj = wj * WS + pos % WS + g.wg.shift;
         if (ti >= a_res) ti -= a_res;
         if (tj >= a_res) tj -= a_res;
         return b * a_T + ti * a_res + tj;
@@ -257,41 +259,38 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
         }
         if (tid < GBM) toks[tid] = my_tok;
         __syncthreads();
-        const int wl = wave >> 1, qh = wave & 1;
-        const int gw = 2 * tm + wl;
-        if (gw < a_nwin) {               // wave-uniform: the second window of the last tile may not exist
-            f32x4 kf[2][4], qf[4];
-            float vf[2][16];
-#pragma unroll
-            for (int kt = 0; kt < 2; kt++) {
-#pragma unroll
-                for (int sx = 0; sx < 4; sx++)
-                    kf[kt][sx] = *reinterpret_cast<const f32x4 *>(Ks + (64 * wl + 32 * kt + lrow) * GLD + 8 * sx + 4 * lhalf);
-#pragma unroll
-                for (int r = 0; r < 16; r++) vf[kt][r] = Vs[(64 * wl + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * GLD + lrow];
-            }
+        const int wl = wave / A_KT, qh = wave % A_KT;   // window of the tile / 32-query block inside the window
+        const int gw = A_WPT * tm + wl;
+        if (gw < a_nwin && 32 * qh < A_WT) {   // wave-uniform: the last tile's second window may not exist
+            const int wbase = A_WP * wl;
+            f32x4 qf[4];
 #pragma unroll
             for (int sx = 0; sx < 4; sx++) qf[sx] = *reinterpret_cast<const f32x4 *>(Qs + (32 * wave + lrow) * GLD + 8 * sx + 4 * lhalf);
             const int wtype = g.wg.shift > 0 ? gw % a_nW : 0;
-            const rsrc_t rsB = make_rsrc(g.attn_bias + ((size_t)wtype * g.wg.heads + tn) * 4096, 4096u * 4u);
-            const unsigned boff = (unsigned)(4 * lhalf * 64 + 32 * qh + lrow) * 4u;
-            f32x16 sacc[2];
+            const rsrc_t rsB = make_rsrc(g.attn_bias + ((size_t)wtype * g.wg.heads + tn) * (A_WP * A_WP), (unsigned)(A_WP * A_WP) * 4u);
+            const unsigned boff = (unsigned)(4 * lhalf * A_WP + 32 * qh + lrow) * 4u;
+            f32x16 sacc[A_KT];
             float mx = -3.0e38f;
 #pragma unroll
-            for (int kt = 0; kt < 2; kt++) {
+            for (int kt = 0; kt < A_KT; kt++) {
+                f32x4 kf[4];
 #pragma unroll
-                for (int r = 0; r < 16; r++) sacc[kt][r] = buf_load1(rsB, boff, (unsigned)((32 * kt + (r & 3) + 8 * (r >> 2)) * 64) * 4u);
+                for (int sx = 0; sx < 4; sx++)
+                    kf[sx] = *reinterpret_cast<const f32x4 *>(Ks + (wbase + 32 * kt + lrow) * GLD + 8 * sx + 4 * lhalf);
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    sacc[kt][r] = buf_load1(rsB, boff, (unsigned)((32 * kt + (r & 3) + 8 * (r >> 2)) * A_WP) * 4u);
 #pragma unroll
                 for (int sx = 0; sx < 4; sx++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[kt][sx][t], qf[sx][t], sacc[kt], 0, 0, 0);
+                    for (int t = 0; t < 4; t++) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[sx][t], qf[sx][t], sacc[kt], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 2; kt++)
+            for (int kt = 0; kt < A_KT; kt++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - mx);   // scores carry the log2(e) factor
@@ -304,9 +303,13 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
 #pragma unroll
             for (int r = 0; r < 16; r++) oacc[r] = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 2; kt++)
+            for (int kt = 0; kt < A_KT; kt++) {
+                float vf[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r] * inv, vf[kt][r], oacc, 0, 0, 0);
+                for (int r = 0; r < 16; r++) vf[r] = Vs[(wbase + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * GLD + lrow];
+#pragma unroll
+                for (int r = 0; r < 16; r++) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r] * inv, vf[r], oacc, 0, 0, 0);
+            }
             // O tile: column d = lrow of head tn, row = query (r&3)+8(r>>2)+4*half of this wave's 32 tokens
             const rsrc_t rsO = make_rsrc(g.C, (unsigned)g.M * g.ldc * 4u);
 #pragma unroll
@@ -463,13 +466,15 @@ void launch_gemm(const GemmArgs &g, hipStream_t s) {
 
 bool launch_gemm_qkv_attn(const GemmArgs &g, hipStream_t s) {
     const WinGeom &wg = g.wg;
-    if (wg.ws != 8 || wg.res % 8 != 0 || wg.C != 32 * wg.heads || g.N != 3 * wg.C || g.K % GBK != 0 || g.act != ACT_NONE || g.res ||
-        g.A2 || !g.attn_bias || !(g.ln_stats || g.ln_part) || g.Wb || g.Ws3)
+    if ((wg.ws != 8 && wg.ws != 10) || wg.res % wg.ws != 0 || wg.C != 32 * wg.heads || g.N != 3 * wg.C || g.K % GBK != 0 ||
+        g.act != ACT_NONE || g.res || g.A2 || !g.attn_bias || !(g.ln_stats || g.ln_part) || g.Wb || g.Ws3)
         return false;
-    const int n_windows = g.attn_batch * (wg.res / 8) * (wg.res / 8);
-    const int tiles_m = (n_windows + 1) / 2, tiles_n = wg.heads;
+    const int n_windows = g.attn_batch * (wg.res / wg.ws) * (wg.res / wg.ws);
+    const int wpt = wg.ws == 8 ? 2 : 1;   // windows per 128-row tile: two of 64 tokens, or one of 100 padded to 128
+    const int tiles_m = (n_windows + wpt - 1) / wpt, tiles_n = wg.heads;
     const dim3 grid(((tiles_m + 7) / 8) * 8 * tiles_n), block(256);
-    hipLaunchKernelGGL((gemm4_f32_kernel<true, ACT_NONE, false, 4>), grid, block, 0, s, g, tiles_m, tiles_n);
+    if (wg.ws == 8) hipLaunchKernelGGL((gemm4_f32_kernel<true, ACT_NONE, false, 4, 8>), grid, block, 0, s, g, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm4_f32_kernel<true, ACT_NONE, false, 4, 10>), grid, block, 0, s, g, tiles_m, tiles_n);
     return true;
 }
 
@@ -955,15 +960,16 @@ void launch_fused_readout96(const float *x, const float *gam, const float *bet, 
 // coalesced), Y^T = Wpe . in^T on the matrix cores, LayerNorm over the 96 outputs (split over registers and the two
 // half-waves), modulate, SiLU, 16-B stores.  KP = in_chans rounded up to 32.
 // =================================================================================================
-template <int KP>
+template <int KP, int CA = 0, int CN = 0>   // CA, CN > 0: compile-time channel counts (the index divisions become multiplies)
 __global__ __launch_bounds__(256, 2) void fused_patch_embed96_kernel(const float *__restrict__ adj, const float *__restrict__ node,
                                                                     const float *__restrict__ sc_adj, const float *__restrict__ sc_node,
                                                                     const int *__restrict__ has_sc, const uint8_t *__restrict__ flags,
                                                                     const float *__restrict__ Wp, const float *__restrict__ bias,
                                                                     const float *__restrict__ gam, const float *__restrict__ bet,
                                                                     const float *__restrict__ aff, int aff_ld, int aff_off,
-                                                                    float *__restrict__ x, int B, int N, int Ca, int Cn, int self_cond) {
+                                                                    float *__restrict__ x, int B, int N, int Ca_rt, int Cn_rt, int self_cond) {
     constexpr int C = 96, S = KP / 8;
+    const int Ca = CA > 0 ? CA : Ca_rt, Cn = CN > 0 ? CN : Cn_rt;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int T = N * N, M = B * T;
@@ -1054,8 +1060,10 @@ bool launch_fused_patch_embed96(const float *adj, const float *node, const float
     const int M = B * N * N;
     const dim3 grid((M + 127) / 128), block(256);
 #define PE_ARGS adj, node, sc_adj, sc_node, has_sc, flags, Wp, bias, gam, bet, aff, aff_ld, aff_off, x, B, N, Ca, Cn, self_cond
-    if (Kp == 32) hipLaunchKernelGGL(fused_patch_embed96_kernel<32>, grid, block, 0, s, PE_ARGS);
-    else if (Kp == 64) hipLaunchKernelGGL(fused_patch_embed96_kernel<64>, grid, block, 0, s, PE_ARGS);
+    if (Kp == 64 && Ca == 6 && Cn == 12) hipLaunchKernelGGL((fused_patch_embed96_kernel<64, 6, 12>), grid, block, 0, s, PE_ARGS);       // VG bits
+    else if (Kp == 64 && Ca == 3 && Cn == 12) hipLaunchKernelGGL((fused_patch_embed96_kernel<64, 3, 12>), grid, block, 0, s, PE_ARGS);  // COCO bits
+    else if (Kp == 32) hipLaunchKernelGGL((fused_patch_embed96_kernel<32>), grid, block, 0, s, PE_ARGS);
+    else if (Kp == 64) hipLaunchKernelGGL((fused_patch_embed96_kernel<64>), grid, block, 0, s, PE_ARGS);
     else return false;
 #undef PE_ARGS
     return true;
@@ -1824,6 +1832,100 @@ __global__ void fill_kernel(float *p, float v, int64_t n) {
 }
 void launch_fill_f32(float *p, float v, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
+}
+
+// Training-time objective (forward): R/runner/objectives/edm.py:160-180 (sigma ~ exp(N(P_mean, P_std)), loss weight) and
+// :239-281 / graph_utils.add_sym_normal_noise with non_symmetric=True (noisy inputs).  Op-by-op fp32 rounding like torch.
+__global__ void train_inputs_kernel(CStatePtrs clean, const float *rnd, CStatePtrs eps, uint64_t seed, const uint8_t *flags,
+                                    float *sigmas, float *weights, StatePtrs noisy, Dims d) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    auto sigma_of = [&](int b) {
+        const float r = rnd ? rnd[b] : philox_normal(seed, 0x7000u, (uint64_t)b);
+        return expf(FADD(FMUL(r, 1.2f), -1.2f));                                        // edm.py:176-177
+    };
+    if (idx < (size_t)d.B) {
+        const float s = sigma_of((int)idx), sd = FMUL(s, 0.5f);
+        sigmas[idx] = s;
+        weights[idx] = __fdiv_rn(FADD(FMUL(s, s), 0.25f), FMUL(sd, sd));                // edm.py:178
+    }
+    if (idx >= total_elems(d)) return;
+    const ElemIdx e = elem_index(idx, d, flags);
+    const float s = sigma_of(e.b);
+    const float ev = eps.adj ? (e.is_adj ? eps.adj[e.off] : eps.node[e.off]) : philox_normal(seed, 0x7001u, idx);
+    const float nz = FMUL(ev, s);
+    if (e.is_adj) noisy.adj[e.off] = e.valid ? FADD(clean.adj[e.off], nz) : 0.f;        // graph_utils.py:139-144
+    else noisy.node[e.off] = FADD(clean.node[e.off], e.valid ? nz : 0.f);               // edm.py:249-256
+}
+void launch_train_inputs(CStatePtrs clean, const float *rnd, CStatePtrs eps, uint64_t seed, const uint8_t *flags, float *sigmas,
+                         float *weights, StatePtrs noisy, Dims d, hipStream_t s) {
+    const size_t n = total_elems(d);
+    hipLaunchKernelGGL(train_inputs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, clean, rnd, eps, seed, flags, sigmas,
+                       weights, noisy, d);
+}
+
+// NodeAdjRainbowLoss.forward(reduction='none') (R/loss/rainbow_loss.py:37-101) and the bbox IoU term of the trainer
+// (R/runner/trainer/trainer_node_adj.py:130-159, type 'iou').  One 256-thread block per sample; every thread sums a fixed
+// strided subset in double, the block adds the 256 partials in a fixed tree: deterministic.
+__global__ __launch_bounds__(256) void rainbow_loss_kernel(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w,
+                                                           float edge_w, float node_w, float iou_w, float *loss_adj, float *loss_node,
+                                                           Dims d) {
+    __shared__ double red[3][256];
+    __shared__ int cnt[2];
+    const int b = blockIdx.x, tid = threadIdx.x, N = d.N, Ca = d.Ca, Cn = d.Cn;
+    const uint8_t *f = flags + (size_t)b * N;
+    if (tid == 0) {
+        int n = 0, nt = 0;
+        for (int i = 0; i < N; i++) n += f[i] ? 1 : 0;
+        for (int k = 0; k < d.B * N; k++) nt += flags[k] ? 1 : 0;
+        cnt[0] = n; cnt[1] = nt;
+    }
+    const float wb = w ? w[b] : 1.0f;
+    double sa = 0.0, sn = 0.0, si = 0.0;
+    const size_t na = (size_t)Ca * N * N;
+    for (size_t k = tid; k < na; k += 256) {
+        const int j = k % N, i = (k / N) % N;
+        if (f[i] && f[j]) { const float dv = pred.adj[(size_t)b * na + k] - tgt.adj[(size_t)b * na + k]; sa += (double)(dv * dv * wb); }
+    }
+    const size_t nn = (size_t)N * Cn;
+    for (size_t k = tid; k < nn; k += 256) {
+        const int i = k / Cn;
+        if (f[i]) { const float dv = pred.node[(size_t)b * nn + k] - tgt.node[(size_t)b * nn + k]; sn += (double)(dv * dv * wb); }
+    }
+    if (iou_w != 0.f)
+        for (int i = tid; i < N; i += 256)
+            if (f[i]) {
+                float bx[2][4];
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const float *src = (q ? tgt.node : pred.node) + ((size_t)b * N + i) * Cn + (Cn - 4);
+                    const float cx = __fdiv_rn(FADD(src[0], 1.0f), 2.0f), cy = __fdiv_rn(FADD(src[1], 1.0f), 2.0f);
+                    const float bw = __fdiv_rn(FADD(src[2], 1.0f), 2.0f), bh = __fdiv_rn(FADD(src[3], 1.0f), 2.0f);
+                    const float v[4] = {FSUB(cx, FMUL(0.5f, bw)), FSUB(cy, FMUL(0.5f, bh)), FADD(cx, FMUL(0.5f, bw)), FADD(cy, FMUL(0.5f, bh))};
+#pragma unroll
+                    for (int t = 0; t < 4; t++) bx[q][t] = fminf(fmaxf(v[t], 0.0f), 1.0f);
+                }
+                const float a0 = FMUL(FSUB(bx[0][2], bx[0][0]), FSUB(bx[0][3], bx[0][1]));
+                const float a1 = FMUL(FSUB(bx[1][2], bx[1][0]), FSUB(bx[1][3], bx[1][1]));
+                const float iw = fmaxf(FSUB(fminf(bx[0][2], bx[1][2]), fmaxf(bx[0][0], bx[1][0])), 0.0f);
+                const float ih = fmaxf(FSUB(fminf(bx[0][3], bx[1][3]), fmaxf(bx[0][1], bx[1][1])), 0.0f);
+                const float inter = FMUL(iw, ih), iou = __fdiv_rn(inter, FSUB(FADD(a0, a1), inter));
+                si += (double)(-FMUL(iou, iou));
+            }
+    red[0][tid] = sa; red[1][tid] = sn; red[2][tid] = si;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; red[2][tid] += red[2][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double n = (double)cnt[0];
+        loss_adj[b] = (float)(red[0][0] / (n * n) / (double)Ca) * edge_w;
+        loss_node[b] = (float)(red[1][0] / n / (double)Cn) * node_w + (iou_w != 0.f ? iou_w * (float)(red[2][0] / (double)cnt[1]) * wb : 0.f);
+    }
+}
+void launch_rainbow_loss(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w,
+                         float *loss_adj, float *loss_node, Dims d, hipStream_t s) {
+    hipLaunchKernelGGL(rainbow_loss_kernel, dim3(d.B), dim3(256), 0, s, pred, tgt, flags, w, edge_w, node_w, iou_w, loss_adj, loss_node, d);
 }
 
 // Post-decode of 'bits' samples (sampler_node_adj.py:222-285, attribute_code.py:319-328):

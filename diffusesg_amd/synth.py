@@ -107,3 +107,24 @@ def decode_case(name: str):
     adj.reshape(-1)[::7] = 0.0
     node.reshape(-1)[::5] = 0.0
     return cfg, flags, adj, node
+
+
+# ---- training-time forward fixture (trainer_node_adj.py:96-163 in 'test' mode: objective -> model -> loss) ----
+TRAIN_VALID = [8, 5, 3, 6]
+
+
+def train_case(name: str = "tiny", B: int = 4, seed: int = 7):
+    """clean +-1 'bits' graphs with bbox channels in (-1,1), the N(0,1) draws of the objective generator in its draw order
+    (sigma [B], adjacency noise, node noise) and the self-conditioning coin of the one preconditioned call."""
+    cfg = CONFIGS[name]()
+    n = cfg.max_node_num
+    flags = W.synth_flags(B, n, TRAIN_VALID)
+    clean_adj = W.mask_adj(np.sign(W.normal(seed, f"trn/{name}/adj", (B, cfg.c_adj, n, n))).astype(np.float32), flags)
+    node = np.sign(W.normal(seed, f"trn/{name}/node", (B, n, cfg.c_node))).astype(np.float32)
+    node[..., -4:] = (2.0 * W.uniform01(seed, f"trn/{name}/bbox", B * n * 4) - 1.0).astype(np.float32).reshape(B, n, 4) * 0.8
+    clean_node = W.mask_node(node, flags)
+    rnd = W.normal(seed, f"trn/{name}/rnd", (B,))
+    eps_adj = W.normal(seed, f"trn/{name}/eps_adj", (B, cfg.c_adj, n, n))
+    eps_node = W.normal(seed, f"trn/{name}/eps_node", (B, n, cfg.c_node))
+    coin = float(W.coins(seed, f"trn/{name}", 1)[0])
+    return cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin

@@ -1,0 +1,145 @@
+"""Training-time forward path (first half): what a test-loss / training step computes BEFORE backward.
+
+  NodeAdjEDMObjectiveGeneratorHip <-> runner.objectives.edm.NodeAdjEDMObjectiveGenerator   (R/runner/objectives/edm.py:215-281)
+  NodeAdjRainbowLossHip           <-> loss.rainbow_loss.NodeAdjRainbowLoss                  (R/loss/rainbow_loss.py:6-101)
+  eval_loss_step                  <-> node_adj_move_forward_one_epoch(mode='test') body     (R/runner/trainer/trainer_node_adj.py:96-167)
+
+Same constructor kwargs, call signatures and return conventions as the reference classes; the arithmetic runs in libdsg.so
+(`dsg_train_inputs`, `dsg_rainbow_loss`, and the preconditioned network through `NodeAdjPrecondHip`).  Backward, the optimiser,
+EMA and DDP are NOT built: `mode='train'` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as _lib
+
+P_MEAN, P_STD, SIGMA_DATA = -1.2, 1.2, 0.5   # get_edm_params(), objectives/edm.py:60-63
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class NodeAdjEDMObjectiveGeneratorHip(object):
+    """`get_training_objective_generator` builds it with precond = sigma_dist = 'edm', symmetric_noise=False
+    (learning_utils.py:20-30)."""
+
+    def __init__(self, precond, sigma_dist, *, other_params=None, dev="cuda", objective="edm", symmetric_noise=False):
+        assert objective in ["diffusion", "score", "edm"]
+        assert precond in ["vp", "ve", "edm"] and sigma_dist in ["vp", "ve", "edm"]
+        if precond != "edm" or sigma_dist != "edm":
+            raise NotImplementedError("only precond = sigma_dist = 'edm' (both reference YAMLs)")
+        if symmetric_noise:
+            raise NotImplementedError("symmetric_noise=True is not used for scene graphs (learning_utils.py:29)")
+        self.precond, self.sigma_dist, self.other_params = precond, sigma_dist, other_params
+        self.objective, self.dev, self.symmetric_noise = objective, torch.device(dev), False
+        self.seed = 1234
+        self._calls = 0
+
+    @torch.no_grad()
+    def get_input_output(self, clean_adjs, clean_x=None, node_flags=None, *args, rnd_sigma=None, noise=None, seed=None, **kwargs):
+        """-> (net_input_a, net_input_x, net_cond, net_target_a, net_target_x, (c_skip, c_out, c_in, c_noise, sigmas, weights)),
+        edm.py:258-281.  Extra keyword-only knobs: `rnd_sigma` [B] and `noise=(eps_adj, eps_node)` replay recorded N(0,1)
+        draws (parity tests); otherwise the library's Philox streams of `seed` (default: self.seed + call count)."""
+        if node_flags.dim() != 2:
+            raise NotImplementedError("node-only ablation ([B,N,N] node_flags) is out of scope")
+        L = _lib.load()
+        dev = self.dev
+        B, n = node_flags.shape
+        adj = clean_adjs.to(device=dev, dtype=torch.float32)
+        adj4 = (adj.unsqueeze(1) if adj.dim() == 3 else adj).contiguous()
+        x = clean_x.to(device=dev, dtype=torch.float32)
+        x3 = (x.unsqueeze(-1) if x.dim() == 2 else x).contiguous()
+        ca, cn = adj4.shape[1], x3.shape[2]
+        fl = node_flags.to(device=dev).to(torch.uint8).contiguous()
+        f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()
+        rnd = f32(rnd_sigma)
+        ea, en = (None, None) if noise is None else (f32(noise[0]).reshape(adj4.shape), f32(noise[1]).reshape(x3.shape))
+        sig, wts = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        na, nx = torch.empty_like(adj4), torch.empty_like(x3)
+        if seed is None:
+            seed = self.seed + self._calls
+        self._calls += 1
+        st = torch.cuda.current_stream(dev).cuda_stream
+        rc = L.dsg_train_inputs(B, n, ca, cn, _p(adj4), _p(x3), _p(fl), _p(rnd), _p(ea), _p(en), C.c_uint64(int(seed)), _p(sig), _p(wts),
+                                _p(na), _p(nx), C.c_void_p(st))
+        if rc != 0:
+            raise _lib.DsgError(f"dsg_train_inputs: status {rc}")
+        # get_preconditioning_params, edm branch (objectives/edm.py:122-126): returned for the caller's bookkeeping only
+        s2 = sig ** 2 + SIGMA_DATA ** 2
+        c_skip, c_out, c_in, c_noise = SIGMA_DATA ** 2 / s2, sig * SIGMA_DATA / s2.sqrt(), 1 / s2.sqrt(), sig.log() / 4
+        na = na[:, 0] if adj.dim() == 3 else na
+        nx = nx[..., 0] if x.dim() == 2 else nx
+        return na, nx, sig, clean_adjs, clean_x, (c_skip, c_out, c_in, c_noise, sig, wts)
+
+
+class NodeAdjRainbowLossHip(torch.nn.Module):
+    def __init__(self, edge_loss_weight, node_loss_weight, objective, flag_reweight=False):
+        super().__init__()
+        assert objective in ["score", "diffusion", "edm"], "Loss mode {:s} is not supported!".format(objective)
+        if objective == "score":
+            raise NotImplementedError
+        self.edge_loss_weight, self.node_loss_weight = edge_loss_weight, node_loss_weight
+        self.flag_reweight, self.objective = flag_reweight, objective
+
+    @torch.no_grad()
+    def forward(self, net_pred_a, net_pred_x, net_target_a, net_target_x, net_cond, adjs_perturbed=None, adjs_gt=None,
+                x_perturbed=None, x_gt=None, node_flags=None, loss_weight=None, cond_val=None, flag_matching=False,
+                reduction="mean", iou_loss_weight=0.0):
+        """rainbow_loss.py:24-35.  reduction 'none'/None -> per-sample (loss_adj [B], loss_node [B]); 'mean' follows the
+        reference's expression literally (:84-86: a [B] tensor, both terms scaled by edge_loss_weight).
+        `iou_loss_weight` (not a reference kwarg) adds the trainer's bbox term on the device (trainer_node_adj.py:130-159)."""
+        if flag_matching:
+            raise ValueError("Graph matching is not supported for node-adj loss!")
+        if node_flags.dim() != 2:
+            raise NotImplementedError("node-only ablation ([B,N,N] node_flags) is out of scope")
+        L = _lib.load()
+        dev = net_pred_a.device
+        B, n = node_flags.shape
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32)
+        a4 = lambda t: (f32(t).unsqueeze(1) if t.dim() == 3 else f32(t)).contiguous()
+        x3 = lambda t: (f32(t).unsqueeze(-1) if t.dim() == 2 else f32(t)).contiguous()
+        pa, ta, px, tx = a4(net_pred_a), a4(net_target_a), x3(net_pred_x), x3(net_target_x)
+        fl = node_flags.to(device=dev).to(torch.uint8).contiguous()
+        w = None if loss_weight is None else f32(loss_weight).reshape(-1).contiguous()
+        la, ln = torch.empty(B, device=dev), torch.empty(B, device=dev)
+        none = reduction is None or reduction == "none"
+        if not none and reduction != "mean":
+            raise NotImplementedError(reduction)
+        # 'mean' (:84-86) sums over the whole batch, divides by the per-sample entry counts and applies edge_loss_weight to
+        # both terms; it is recovered below from unit-weight per-sample sums
+        ew, nw = (self.edge_loss_weight, self.node_loss_weight) if none else (1.0, 1.0)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        rc = L.dsg_rainbow_loss(B, n, pa.shape[1], px.shape[2], _p(pa), _p(px), _p(ta), _p(tx), _p(fl), _p(w), float(ew), float(nw),
+                                float(iou_loss_weight if none else 0.0), _p(la), _p(ln), C.c_void_p(st))
+        if rc != 0:
+            raise _lib.DsgError(f"dsg_rainbow_loss: status {rc}")
+        if none:
+            return la, ln
+        cnt = node_flags.to(device=dev).sum(dim=-1).to(torch.float32)
+        tot_a = (la * cnt ** 2 * pa.shape[1]).sum()          # undo the per-sample normalisation: plain masked weighted sums
+        tot_x = (ln * cnt * px.shape[2]).sum()
+        return tot_a / cnt ** 2 * self.edge_loss_weight, tot_x / cnt * self.edge_loss_weight
+
+
+def eval_loss_step(model, train_obj_gen, loss_func, adjs_gt, nodes_gt, node_flags, mode="test", iou_loss_type="iou",
+                   iou_loss_weight=0.0, **replay):
+    """One iteration of node_adj_move_forward_one_epoch in 'test' mode (trainer_node_adj.py:96-167): objective -> model pass
+    under no_grad -> per-sample losses -> loss = adj.mean() + node.mean().  Returns (loss, reg_loss_adj, reg_loss_node, sigmas)."""
+    if mode != "test":
+        raise NotImplementedError("mode='train' needs backward / optimiser / EMA, which are not built (SURVEY §8f-4)")
+    if iou_loss_weight > 0.0 and iou_loss_type != "iou":
+        raise NotImplementedError("only iou_loss_type='iou' (the YAML default) is built")
+    net_input_a, net_input_x, net_cond, net_target_a, net_target_x, (c_skip, c_out, c_in, c_noise, sigmas, weights) = \
+        train_obj_gen.get_input_output(adjs_gt, nodes_gt, node_flags, **replay)
+    with torch.no_grad():
+        net_output_a, net_output_x = model(adjs=net_input_a, nodes=net_input_x, node_flags=node_flags, sigmas=sigmas)
+    reg_loss_adj, reg_loss_node = loss_func(net_pred_a=net_output_a, net_pred_x=net_output_x, net_target_a=net_target_a,
+                                            net_target_x=net_target_x, net_cond=net_cond, adjs_perturbed=net_input_a, adjs_gt=adjs_gt,
+                                            x_perturbed=net_input_x, x_gt=nodes_gt, node_flags=node_flags, loss_weight=weights,
+                                            reduction="none", iou_loss_weight=iou_loss_weight)
+    loss = reg_loss_adj.mean() + reg_loss_node.mean()
+    return loss, reg_loss_adj, reg_loss_node, sigmas

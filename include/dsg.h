@@ -181,6 +181,33 @@ int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node
                     int32_t *out_adj /*[B,N,N]*/, int32_t *out_node /*[B,N]*/, float *out_bbox /*[B,N,4] or NULL*/,
                     void *stream);
 
+/* Debug / verification: one GEMM of the library, C[M,N] = act(LN?(A)[M,K] . W[N,K]^T + bias) (+ res), in a chosen arithmetic
+ * (mode 0: fp32 MFMA; 1: bf16 operands, fp32 accumulate -- "gemm_bf16"; 2: three-way split bf16 -- "gemm_split"); act 0 none,
+ * 1 GELU, 2 SiLU; ln_stats [M,2] (mean, rstd) or NULL.  Device pointers, K % 32 == 0, synchronises `stream`.  Lets a test diff
+ * WHOLE output matrices between the arithmetic modes (a rare wrong 16-lane group is invisible to sampled checks). */
+int dsg_debug_gemm(int32_t M, int32_t N, int32_t K, const float *A, const float *W, const float *bias, const float *ln_stats,
+                   const float *res, int32_t act, int32_t mode, float *C, void *stream);
+
+/* ---- training-time forward (first half: what a test-loss / training step computes before backward) ----
+ * No handle: these only need the tensor dimensions.  Return DSG_OK / DSG_ERR_INVALID / DSG_ERR_HIP.
+ *
+ * dsg_train_inputs <-> NodeAdjEDMObjectiveGenerator.get_input_output   R/runner/objectives/edm.py:160-180, :239-281
+ *   (precond = sigma_dist = 'edm', symmetric_noise = False: learning_utils.py:25-29)
+ *   sigma_b = exp(rnd_b*1.2 - 1.2); weight_b = (sigma^2 + 0.25)/(0.5 sigma)^2;
+ *   noisy_adj = mask(clean_adj + eps_adj*sigma_b); noisy_node = clean_node + mask(eps_node*sigma_b)
+ *   rnd_sigma [B] / eps_adj / eps_node: the N(0,1) draws (device pointers) or NULL = the library's Philox streams of `seed`. */
+int dsg_train_inputs(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *clean_adj, const float *clean_node,
+                     const uint8_t *flags, const float *rnd_sigma, const float *eps_adj, const float *eps_node, uint64_t seed,
+                     float *out_sigmas, float *out_weights, float *out_noisy_adj, float *out_noisy_node, void *stream);
+/* dsg_rainbow_loss <-> NodeAdjRainbowLoss.forward(reduction='none')    R/loss/rainbow_loss.py:37-101
+ *   plus the trainer's bounding-box term with iou_loss_type 'iou'      R/runner/trainer/trainer_node_adj.py:130-159
+ *   (last four node channels; 0 switches it off).  Outputs: per-sample losses [B]; the step's scalar loss is
+ *   mean(out_loss_adj) + mean(out_loss_node) (trainer_node_adj.py:167). */
+int dsg_rainbow_loss(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *pred_adj, const float *pred_node,
+                     const float *target_adj, const float *target_node, const uint8_t *flags, const float *loss_weight,
+                     float edge_loss_weight, float node_loss_weight, float iou_loss_weight, float *out_loss_adj, float *out_loss_node,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -743,3 +743,94 @@ int dsgref_decode_bits(dsgref *h, int B, const float *adj, const float *node, co
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* training-time objective and loss, forward only (first half)                   */
+/* ------------------------------------------------------------------------------------------ */
+/* NodeAdjEDMObjectiveGenerator.get_input_output (R/runner/objectives/edm.py:160-180, :239-281) with sigma_dist = precond =
+ * 'edm' and symmetric_noise = False (learning_utils.py:25-29):
+ *   sigma_b  = exp(rnd_b * P_std + P_mean),  P_mean = -1.2, P_std = 1.2          (:176-177)
+ *   weight_b = (sigma^2 + sigma_data^2) / (sigma * sigma_data)^2, sigma_data = .5 (:178)
+ *   noisy_adj  = mask_adjs(clean_adj + eps_adj * sigma_b)   (graph_utils.add_sym_normal_noise, non_symmetric=True: :133-148)
+ *   noisy_node = clean_node + mask_nodes(eps_node * sigma_b)                      (:246-254)
+ * rnd [B], eps_adj, eps_node are the N(0,1) draws in the reference's draw order (sigma, adjacency, node). */
+NO_FMA int dsgref_train_inputs(dsgref *h, int B, const float *clean_adj, const float *clean_node, const uint8_t *flags,
+                               const float *rnd, const float *eps_adj, const float *eps_node, float *sigmas, float *weights,
+                               float *noisy_adj, float *noisy_node) {
+    const int N = h->N, Ca = h->c_adj, Cn = h->c_node;
+    for (int b = 0; b < B; b++) {
+        const float s = expf(rnd[b] * 1.2f + (-1.2f));
+        sigmas[b] = s;
+        const float sd = s * 0.5f;
+        weights[b] = (s * s + 0.25f) / (sd * sd);
+        const uint8_t *f = flags + (size_t)b * N;
+        for (int c = 0; c < Ca; c++)
+            for (int i = 0; i < N; i++)
+                for (int j = 0; j < N; j++) {
+                    const size_t k = (((size_t)b * Ca + c) * N + i) * N + j;
+                    noisy_adj[k] = (f[i] && f[j]) ? clean_adj[k] + eps_adj[k] * s : 0.0f;
+                }
+        for (int i = 0; i < N; i++)
+            for (int c = 0; c < Cn; c++) {
+                const size_t k = ((size_t)b * N + i) * Cn + c;
+                noisy_node[k] = clean_node[k] + (f[i] ? eps_node[k] * s : 0.0f);
+            }
+    }
+    return 0;
+}
+
+/* NodeAdjRainbowLoss.forward(..., reduction='none') (R/loss/rainbow_loss.py:37-101) for [B,C,N,N] / [B,N,C] tensors, plus the
+ * bounding-box IoU term of the trainer (R/runner/trainer/trainer_node_adj.py:130-159, iou_loss_type 'iou'; torchvision's
+ * box_convert cxcywh->xyxy and box_iou restated: inter / (area_a + area_b - inter)):
+ *   loss_adj_b  = sum(mask * w_b * (pred - target)^2) / n_b^2 / C_adj  * edge_loss_weight
+ *   loss_node_b = sum(mask * w_b * (pred - target)^2) / n_b   / C_node * node_loss_weight
+ *                 + iou_w * w_b * sum_i f_i * (-(iou_i)^2) / n_total      (n_total = valid nodes of the WHOLE batch: the
+ *                   reference divides by node_flags.view(-1).sum(), trainer_node_adj.py:158)
+ * Accumulation in double, so that the fixture comparison measures the device kernel's summation, not this one's. */
+int dsgref_rainbow_loss(dsgref *h, int B, const float *pred_adj, const float *pred_node, const float *tgt_adj, const float *tgt_node,
+                        const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w, float *loss_adj,
+                        float *loss_node) {
+    const int N = h->N, Ca = h->c_adj, Cn = h->c_node;
+    long n_total = 0;
+    for (size_t k = 0; k < (size_t)B * N; k++) n_total += flags[k] ? 1 : 0;
+    for (int b = 0; b < B; b++) {
+        const uint8_t *f = flags + (size_t)b * N;
+        int n = 0;
+        for (int i = 0; i < N; i++) n += f[i] ? 1 : 0;
+        const float wb = w ? w[b] : 1.0f;
+        double sa = 0.0, sn = 0.0, si = 0.0;
+        for (int c = 0; c < Ca; c++)
+            for (int i = 0; i < N; i++)
+                for (int j = 0; j < N; j++)
+                    if (f[i] && f[j]) {
+                        const size_t k = (((size_t)b * Ca + c) * N + i) * N + j;
+                        const float d = pred_adj[k] - tgt_adj[k];
+                        sa += (double)(d * d * wb);
+                    }
+        for (int i = 0; i < N; i++)
+            if (f[i]) {
+                for (int c = 0; c < Cn; c++) {
+                    const size_t k = ((size_t)b * N + i) * Cn + c;
+                    const float d = pred_node[k] - tgt_node[k];
+                    sn += (double)(d * d * wb);
+                }
+                if (iou_w != 0.0f) { /* trainer_node_adj.py:131-143 */
+                    float bx[2][4];
+                    for (int q = 0; q < 2; q++) {
+                        const float *src = (q ? tgt_node : pred_node) + ((size_t)b * N + i) * Cn + (Cn - 4);
+                        const float cx = (src[0] + 1.0f) / 2.0f, cy = (src[1] + 1.0f) / 2.0f, bw = (src[2] + 1.0f) / 2.0f, bh = (src[3] + 1.0f) / 2.0f;
+                        const float v[4] = {cx - 0.5f * bw, cy - 0.5f * bh, cx + 0.5f * bw, cy + 0.5f * bh};
+                        for (int t = 0; t < 4; t++) bx[q][t] = fminf(fmaxf(v[t], 0.0f), 1.0f);
+                    }
+                    const float a0 = (bx[0][2] - bx[0][0]) * (bx[0][3] - bx[0][1]), a1 = (bx[1][2] - bx[1][0]) * (bx[1][3] - bx[1][1]);
+                    const float iw = fmaxf(fminf(bx[0][2], bx[1][2]) - fmaxf(bx[0][0], bx[1][0]), 0.0f);
+                    const float ih = fmaxf(fminf(bx[0][3], bx[1][3]) - fmaxf(bx[0][1], bx[1][1]), 0.0f);
+                    const float inter = iw * ih, iou = inter / (a0 + a1 - inter);
+                    si += (double)(-(iou * iou));
+                }
+            }
+        loss_adj[b] = (float)(sa / ((double)n * (double)n) / (double)Ca) * edge_w;
+        loss_node[b] = (float)(sn / (double)n / (double)Cn) * node_w + (iou_w != 0.0f ? iou_w * (float)(si / (double)n_total) * wb : 0.0f);
+    }
+    return 0;
+}

@@ -48,6 +48,8 @@ def lib():
         L.dsgref_precond.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_int] + [C.c_void_p] * 2
         L.dsgref_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10
         L.dsgref_sigma_steps.argtypes = [C.c_void_p, C.c_void_p]
+        L.dsgref_train_inputs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 10
+        L.dsgref_rainbow_loss.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_void_p] * 2
         L.dsgref_decode_bits.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 3
         _lib = L
     return _lib
@@ -165,3 +167,26 @@ class Oracle:
         lib().dsgref_decode_bits(self._h, B, _p(adj), _p(node), _p(fl), int(n_adj_type), int(n_node_type),
                                  c.c_node - 4 if bbox else c.c_node, _p(qa), _p(qn), _p(bb))
         return qa, qn, bb
+
+    def train_inputs(self, clean_adj, clean_node, flags, rnd, eps_adj, eps_node):
+        """objectives/edm.py:239-281 with replayed draws -> (sigmas [B], weights [B], noisy_adj, noisy_node)"""
+        B = flags.shape[0]
+        sa, sn = self._shapes(B)
+        ca, cn, ea, en = (_f32(x).reshape(s) for x, s in ((clean_adj, sa), (clean_node, sn), (eps_adj, sa), (eps_node, sn)))
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        rn = _f32(rnd)
+        sig, wts = np.empty(B, np.float32), np.empty(B, np.float32)
+        na, nn = np.empty(sa, np.float32), np.empty(sn, np.float32)
+        lib().dsgref_train_inputs(self._h, B, _p(ca), _p(cn), _p(fl), _p(rn), _p(ea), _p(en), _p(sig), _p(wts), _p(na), _p(nn))
+        return sig, wts, na, nn
+
+    def rainbow_loss(self, pred_adj, pred_node, tgt_adj, tgt_node, flags, loss_weight=None, edge_w=1.0, node_w=1.0, iou_w=0.0):
+        """loss/rainbow_loss.py:37-101 (reduction='none') + the trainer's IoU term -> (loss_adj [B], loss_node [B])"""
+        B = flags.shape[0]
+        sa, sn = self._shapes(B)
+        pa, pn, ta, tn = (_f32(x).reshape(s) for x, s in ((pred_adj, sa), (pred_node, sn), (tgt_adj, sa), (tgt_node, sn)))
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        w = _f32(loss_weight)
+        la, ln = np.empty(B, np.float32), np.empty(B, np.float32)
+        lib().dsgref_rainbow_loss(self._h, B, _p(pa), _p(pn), _p(ta), _p(tn), _p(fl), _p(w), edge_w, node_w, iou_w, _p(la), _p(ln))
+        return la, ln

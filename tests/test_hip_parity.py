@@ -828,3 +828,134 @@ def test_step_graphs_reused_across_runs_match_eager():
     net.model._ensure_handle().set_option("loop_graph", 0)
     oa, on, st = run(True, 3)
     assert torch.equal(oa, refs[3][0]) and st["graph_replays"] == st["net_forwards"]
+
+
+# ---- training-time forward (first half): objective generator, model pass with per-sample sigmas, loss ----
+def test_train_forward_vs_reference_fixture():
+    """tests/golden/train_forward.npz (tools/gen_golden.py::gen_train_forward: the reference's NodeAdjEDMObjectiveGenerator,
+    NodeAdjPrecond(DiffuseSG) called as the trainer calls it, NodeAdjRainbowLoss(reduction='none') + the trainer's IoU term):
+    the HIP objective kernel on replayed draws, the whole test-loss step, and the loss kernel on the reference's own outputs"""
+    from diffusesg_amd.train import NodeAdjEDMObjectiveGeneratorHip, NodeAdjRainbowLossHip, eval_loss_step
+    g = load("train_forward.npz")
+    cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case("tiny")
+    gen = NodeAdjEDMObjectiveGeneratorHip(precond="edm", sigma_dist="edm", other_params=None, dev="cuda", symmetric_noise=False)
+    loss_func = NodeAdjRainbowLossHip(edge_loss_weight=1.0, node_loss_weight=1.0, flag_reweight=False, objective="edm")
+    na, nx, cond, ta, tx, (c_skip, c_out, c_in, c_noise, sigmas, weights) = gen.get_input_output(
+        T(clean_adj), T(clean_node), T(flags), rnd_sigma=T(rnd), noise=(T(eps_adj), T(eps_node)))
+    np.testing.assert_allclose(sigmas.cpu().numpy(), g["tiny_sigmas"], rtol=2e-6)
+    np.testing.assert_allclose(weights.cpu().numpy(), g["tiny_weights"], rtol=4e-6)
+    assert_close(na.cpu().numpy(), g["tiny_noisy_adj"], 1e-6, "noisy adj")
+    assert_close(nx.cpu().numpy(), g["tiny_noisy_node"], 1e-6, "noisy node")
+    np.testing.assert_allclose(c_noise.cpu().numpy(), np.log(g["tiny_sigmas"]) / 4, rtol=1e-5)
+    f = torch.from_numpy(flags).cuda()
+    assert torch.all(na.permute(0, 2, 3, 1)[~f] == 0) and torch.equal(nx[~f], T(clean_node)[~f])   # node: only the noise is masked
+    # the loss kernel on the reference's own model outputs: isolates the reduction (bar 1e-5)
+    la, ln = loss_func(T(g["tiny_pred_adj"]), T(g["tiny_pred_node"]), T(clean_adj), T(clean_node), cond, node_flags=T(flags),
+                       loss_weight=weights, reduction="none", iou_loss_weight=1.0)
+    np.testing.assert_allclose(la.cpu().numpy(), g["tiny_loss_adj"], rtol=2e-5)
+    np.testing.assert_allclose(ln.cpu().numpy(), g["tiny_loss_node"], rtol=2e-5, atol=2e-5)
+    la0, ln0 = loss_func(T(g["tiny_pred_adj"]), T(g["tiny_pred_node"]), T(clean_adj), T(clean_node), cond, node_flags=T(flags),
+                         loss_weight=weights, reduction="none")
+    np.testing.assert_allclose(ln0.cpu().numpy(), g["tiny_loss_node_noiou"], rtol=2e-5)
+    # the whole step the way the trainer runs it in 'test' mode, coin replayed through NumPy's global generator
+    real = np.random.rand
+    np.random.rand = lambda: coin
+    try:
+        loss, ra, rn, sg = eval_loss_step(net_for("tiny"), gen, loss_func, T(clean_adj), T(clean_node), T(flags), mode="test",
+                                          iou_loss_type="iou", iou_loss_weight=1.0, rnd_sigma=T(rnd), noise=(T(eps_adj), T(eps_node)))
+    finally:
+        np.random.rand = real
+    np.testing.assert_allclose(ra.cpu().numpy(), g["tiny_loss_adj"], rtol=5e-4)
+    np.testing.assert_allclose(rn.cpu().numpy(), g["tiny_loss_node"], rtol=5e-4, atol=1e-4)
+    assert abs(float(loss) - float(g["tiny_loss"])) <= 5e-4 * abs(float(g["tiny_loss"]))
+    with pytest.raises(NotImplementedError):
+        eval_loss_step(net_for("tiny"), gen, loss_func, T(clean_adj), T(clean_node), T(flags), mode="train")
+
+
+def test_train_objective_device_draws_and_loss_vs_oracle():
+    """library-drawn training noise: log sigma ~ N(-1.2, 1.2^2), added noise has std sigma_b on valid entries and is exactly
+    masked, one seed = one draw; and the loss kernel against the oracle at the VG shape (B = 64)"""
+    from oracle.oracle import Oracle
+    from diffusesg_amd.train import NodeAdjEDMObjectiveGeneratorHip, NodeAdjRainbowLossHip
+    cfg = Y.CONFIGS["vg"]()
+    n, B = cfg.max_node_num, 64
+    flags = W.synth_flags(B, n, [30, 64, 1, 17])
+    clean_adj = W.mask_adj(np.sign(W.normal(3, "trn/vg/a", (B, cfg.c_adj, n, n))).astype(np.float32), flags)
+    clean_node = W.mask_node(np.sign(W.normal(3, "trn/vg/x", (B, n, cfg.c_node))).astype(np.float32) * 0.7, flags)
+    gen = NodeAdjEDMObjectiveGeneratorHip(precond="edm", sigma_dist="edm", dev="cuda")
+    na, nx, _, _, _, (_, _, _, _, sig, wts) = gen.get_input_output(T(clean_adj), T(clean_node), T(flags), seed=11)
+    na2, nx2, _, _, _, (_, _, _, _, sig2, _) = gen.get_input_output(T(clean_adj), T(clean_node), T(flags), seed=11)
+    na3, _, _, _, _, (_, _, _, _, sig3, _) = gen.get_input_output(T(clean_adj), T(clean_node), T(flags), seed=12)
+    assert torch.equal(na, na2) and torch.equal(sig, sig2) and not torch.equal(sig, sig3) and not torch.equal(na, na3)
+    f = torch.from_numpy(flags).cuda()
+    assert torch.all(na.permute(0, 2, 3, 1)[~f] == 0) and torch.all(na.permute(0, 3, 2, 1)[~f] == 0)
+    b = 1   # the fully valid graph: 6*64*64 noise samples
+    z = ((na[b] - T(clean_adj)[b]) / sig[b]).flatten().cpu().numpy()
+    assert abs(z.mean()) < 4 / np.sqrt(z.size) and abs(z.std() - 1) < 4 / np.sqrt(2 * z.size)
+    np.testing.assert_allclose(wts.cpu().numpy(), ((sig ** 2 + 0.25) / (sig * 0.5) ** 2).cpu().numpy(), rtol=1e-5)
+    big = torch.ones(4096, 8, dtype=torch.bool)
+    _, _, _, _, _, (_, _, _, _, sg, _) = gen.get_input_output(torch.zeros(4096, 1, 8, 8), torch.zeros(4096, 8, 5), big, seed=5)
+    ls = sg.log().cpu().numpy()
+    assert abs(ls.mean() + 1.2) < 4 * 1.2 / 64 and abs(ls.std() - 1.2) < 4 * 1.2 / np.sqrt(2 * 4096)
+    # loss kernel vs the oracle on arbitrary predictions
+    pa, px = W.normal(5, "trn/vg/pa", clean_adj.shape), W.normal(5, "trn/vg/px", clean_node.shape)
+    wv = wts.cpu().numpy()
+    loss_func = NodeAdjRainbowLossHip(edge_loss_weight=1.5, node_loss_weight=0.5, objective="edm")
+    la, ln = loss_func(T(pa), T(px), T(clean_adj), T(clean_node), sig, node_flags=T(flags), loss_weight=wts, reduction="none",
+                       iou_loss_weight=1.0)
+    ra, rn = Oracle(cfg, W.synth_state_dict(cfg, 0)).rainbow_loss(pa, px, clean_adj, clean_node, flags, wv, 1.5, 0.5, 1.0)
+    np.testing.assert_allclose(la.cpu().numpy(), ra, rtol=1e-5)
+    np.testing.assert_allclose(ln.cpu().numpy(), rn, rtol=1e-5, atol=1e-6)
+    # 'mean' follows the reference's literal expression (rainbow_loss.py:84-86)
+    ma, mx = loss_func(T(pa), T(px), T(clean_adj), T(clean_node), sig, node_flags=T(flags), loss_weight=wts, reduction="mean")
+    cnt = flags.sum(-1).astype(np.float64)
+    m = flags[:, None, :, None] & flags[:, None, None, :]
+    tot_a = (((pa - clean_adj) ** 2).astype(np.float64) * wv[:, None, None, None] * m).sum()
+    np.testing.assert_allclose(ma.cpu().numpy(), tot_a / cnt ** 2 * 1.5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K,ln,act,res", [(65536, 768, 192, 1, 1, 0), (16384, 384, 1536, 0, 0, 1), (4096, 2304, 768, 1, 0, 0)])
+def test_whole_matrix_diff_between_gemm_arithmetics(M, N, K, ln, act, res):
+    """EVERY element of a GEMM at the VG B=64 shapes, in the three arithmetic modes (dsg_debug_gemm):
+      * split-bf16 vs fp32 on the same operands: fp32-level agreement everywhere (1e-4 of the output scale);
+      * bf16 mode vs the fp32 kernel fed operands already rounded to bf16 (its products are then exact, only the summation
+        order differs): 1e-4 as well -- a bar that a wrong 16-lane group / output row (the rare event seen while building
+        kernels_lp.hip in round 1: rows off by 1e-2..1e-1) cannot pass, unlike the 5e-2 tolerance of the end-to-end bf16 tests.
+    tools/pk_hazard.cpp and a rebuild of kernels_lp.hip WITH packed-f32 ops (profiles/r2/pk_hazard.txt) show that event
+    is not reproducible from packed VALU instructions next to bf16 MFMAs; this test keeps watching the kernels themselves."""
+    import ctypes as C
+    from diffusesg_amd import lib as L
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(1234 + M + N)
+    A = torch.randn(M, K, device="cuda", generator=gen)
+    Wt = torch.randn(N, K, device="cuda", generator=gen) * (1.0 / K ** 0.5)
+    bias = torch.randn(N, device="cuda", generator=gen) * 0.1
+    stats = torch.stack([torch.full((M,), 0.1), torch.full((M,), 0.9)], dim=1).contiguous().cuda() if ln else None
+    R = torch.randn(M, N, device="cuda", generator=gen) if res else None
+    p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+
+    def run(mode, a, w):
+        out = torch.empty(M, N, device="cuda")
+        rc = lib.dsg_debug_gemm(M, N, K, p(a), p(w), p(bias), p(stats), p(R), act, mode, p(out), None)
+        assert rc == 0
+        return out
+    c32 = run(0, A, Wt)
+    scale = float(c32.abs().max())
+    d_split = float((run(2, A, Wt) - c32).abs().max()) / scale
+    assert d_split <= 1e-4, f"split-bf16 vs fp32: {d_split:.2e}"
+    if not ln:   # (with LN the bf16 kernel rounds AFTER the fp32 normalisation FMA: pre-round the normalised operand instead)
+        Ab, s2 = A.to(torch.bfloat16).to(torch.float32), None
+    else:
+        # the kernel's A path: fmaf(a, rstd, -mean*rstd) in fp32, then round to bf16 (exact fma via float64)
+        rstd32, nmr32 = np.float32(0.9), np.float32(-np.float32(0.1) * np.float32(0.9))
+        Ab = (A.double() * float(rstd32) + float(nmr32)).to(torch.float32).to(torch.bfloat16).to(torch.float32)
+    Wb = Wt.to(torch.bfloat16).to(torch.float32)
+    keep = stats
+    if ln:
+        stats = torch.stack([torch.zeros(M), torch.ones(M)], dim=1).contiguous().cuda()   # identity normalisation for the reference run
+    ref = run(0, Ab, Wb)
+    stats = keep
+    got = run(1, A, Wt)
+    d_bf16 = float((got - ref).abs().max()) / scale
+    rows_off = int(((got - ref).abs().max(dim=1).values > 1e-3 * scale).sum())
+    assert d_bf16 <= 1e-4 and rows_off == 0, f"bf16 mode vs fp32-on-rounded-operands: {d_bf16:.2e}, rows beyond 1e-3: {rows_off}"

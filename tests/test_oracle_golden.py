@@ -121,3 +121,29 @@ def test_decode_bits_matches_reference(name):
     assert np.array_equal(qa, g[f"{name}_q_adj"].astype(np.int32)) and np.array_equal(qn, g[f"{name}_q_node"].astype(np.int32))
     assert np.array_equal(bb, g[f"{name}_bbox"])
     assert (qa == n_adj - 1).sum() > 0 and (qn == n_node - 1).sum() > 0   # the clamp is exercised
+
+
+def test_train_forward_matches_reference():
+    """forward half of a training / test-loss step (trainer_node_adj.py:96-163 in 'test' mode) against tests/golden/
+    train_forward.npz: the objective generator's sigmas / weights / noisy inputs from replayed draws, the preconditioned
+    model with per-sample sigmas, the masked sigma-weighted MSE per sample and the bounding-box IoU term"""
+    g = load("train_forward.npz")
+    cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case("tiny")
+    orc = make_oracle(cfg)
+    sig, wts, na, nn = orc.train_inputs(clean_adj, clean_node, flags, rnd, eps_adj, eps_node)
+    np.testing.assert_allclose(sig, g["tiny_sigmas"], rtol=1e-6)
+    np.testing.assert_allclose(wts, g["tiny_weights"], rtol=2e-6)
+    assert_close(na, g["tiny_noisy_adj"], 1e-6, "noisy adj")
+    assert_close(nn, g["tiny_noisy_node"], 1e-6, "noisy node")
+    pa, pn = orc.precond(na, nn, flags, sig, None, None, coin=coin < 0.5)
+    assert_close(pa, g["tiny_pred_adj"], FWD_RTOL, "model output adj")
+    assert_close(pn, g["tiny_pred_node"], FWD_RTOL, "model output node")
+    la0, ln0 = orc.rainbow_loss(g["tiny_pred_adj"], g["tiny_pred_node"], clean_adj, clean_node, flags, wts)
+    np.testing.assert_allclose(la0, g["tiny_loss_adj_noiou"], rtol=1e-5)
+    np.testing.assert_allclose(ln0, g["tiny_loss_node_noiou"], rtol=1e-5)
+    la, ln = orc.rainbow_loss(g["tiny_pred_adj"], g["tiny_pred_node"], clean_adj, clean_node, flags, wts, iou_w=1.0)
+    np.testing.assert_allclose(la, g["tiny_loss_adj"], rtol=1e-5)
+    np.testing.assert_allclose(ln, g["tiny_loss_node"], rtol=1e-5, atol=1e-5)
+    # end to end through the oracle's own model output: loss = adj.mean() + node.mean() (trainer_node_adj.py:167)
+    la, ln = orc.rainbow_loss(pa, pn, clean_adj, clean_node, flags, wts, iou_w=1.0)
+    assert abs(float(la.mean() + ln.mean()) - float(g["tiny_loss"])) <= 1e-3 * abs(float(g["tiny_loss"]))

@@ -304,6 +304,85 @@ def gen_decode(out):
     np.savez_compressed(os.path.join(out, "decode.npz"), **res)
 
 
+def gen_train_forward(DiffuseSG, NodeAdjPrecond, out):
+    """G7: the forward half of a training / test-loss step (R/runner/trainer/trainer_node_adj.py:96-163, mode 'test'):
+    NodeAdjEDMObjectiveGenerator.get_input_output (imported; its torch.randn / randn_like draws replayed from the portable
+    streams), the preconditioned model called the way the trainer calls it (kwargs, per-sample sigmas; the self-conditioning
+    coin replayed), NodeAdjRainbowLoss(reduction='none') (imported) and the trainer's bounding-box IoU term.  torchvision is
+    not installed here, so its two helpers used by that term are restated in torch: box_convert('cxcywh'->'xyxy') and the
+    diagonal of box_iou = inter / (area_a + area_b - inter)."""
+    import model.precond.precond as P
+    from loss.rainbow_loss import NodeAdjRainbowLoss
+    from runner.objectives.edm import NodeAdjEDMObjectiveGenerator
+    res = {}
+    for name in ("tiny",):
+        cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case(name)
+        net = build_ref_net(DiffuseSG, cfg)
+        model = NodeAdjPrecond("edm", net, cfg.self_condition, symmetric_noise=False).eval()
+        gen = NodeAdjEDMObjectiveGenerator(precond="edm", sigma_dist="edm", other_params=None, dev="cpu", symmetric_noise=False)
+        draws = _Replay([rnd, eps_adj, eps_node])   # draw order: sigmas (:176), adjacency noise (graph_utils:139), node noise (:249)
+
+        def fake_randn(*size, **kw):
+            v = draws.pop()
+            return torch.from_numpy(np.ascontiguousarray(v).copy())
+
+        def fake_randn_like(x, **kw):
+            v = draws.pop()
+            return torch.from_numpy(np.ascontiguousarray(v).reshape(tuple(x.shape)).copy()).to(x.dtype)
+
+        real_r, real_rl, real_rand = torch.randn, torch.randn_like, P.np.random.rand
+        torch.randn, torch.randn_like = fake_randn, fake_randn_like
+        P.np.random.rand = lambda: coin
+        try:
+            adjs_gt, nodes_gt, node_flags = t(clean_adj.copy()), t(clean_node.copy()), t(flags)
+            net_input_a, net_input_x, net_cond, net_target_a, net_target_x, (c_skip, c_out, c_in, c_noise, sigmas, weights) = \
+                gen.get_input_output(adjs_gt, nodes_gt, node_flags)
+            assert draws.i == 3
+            with torch.no_grad():   # mode == 'test' (:109-111)
+                net_output_a, net_output_x = model(adjs=net_input_a, nodes=net_input_x, node_flags=node_flags, sigmas=sigmas)
+        finally:
+            torch.randn, torch.randn_like, P.np.random.rand = real_r, real_rl, real_rand
+        loss_func = NodeAdjRainbowLoss(edge_loss_weight=1.0, node_loss_weight=1.0, flag_reweight=False, objective="edm")
+        reg_loss_adj, reg_loss_node = loss_func(net_pred_a=net_output_a, net_pred_x=net_output_x, net_target_a=net_target_a,
+                                                net_target_x=net_target_x, net_cond=net_cond, adjs_perturbed=net_input_a,
+                                                adjs_gt=adjs_gt, x_perturbed=net_input_x, x_gt=nodes_gt, node_flags=node_flags,
+                                                loss_weight=weights, reduction='none')
+        res[f"{name}_loss_adj_noiou"], res[f"{name}_loss_node_noiou"] = reg_loss_adj.numpy().copy(), reg_loss_node.numpy().copy()
+        # IoU term (:130-159), iou_loss_type == 'iou', iou_loss_weight == 1.0 (both reference YAMLs)
+        iou_loss_weight = 1.0
+
+        def box_convert_cxcywh_xyxy(b):
+            cx, cy, w, h = b.unbind(-1)
+            return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+        def box_iou_diag(a, b):
+            area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+            area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+            lt, rb = torch.max(a[:, :2], b[:, :2]), torch.min(a[:, 2:], b[:, 2:])
+            wh = (rb - lt).clamp(min=0)
+            inter = wh[:, 0] * wh[:, 1]
+            return inter / (area_a + area_b - inter)
+        net_output_x_bbox = (net_output_x[..., -4:] + 1.0) / 2.0
+        net_target_x_bbox = (net_target_x[..., -4:] + 1.0) / 2.0
+        net_output_x_bbox = box_convert_cxcywh_xyxy(net_output_x_bbox).clamp(min=0.0, max=1.0)
+        net_target_x_bbox = box_convert_cxcywh_xyxy(net_target_x_bbox).clamp(min=0.0, max=1.0)
+        bbox_iou = box_iou_diag(net_output_x_bbox.view(-1, 4), net_target_x_bbox.view(-1, 4))
+        node_iou_loss = -(bbox_iou.view(-1)) ** 2.0
+        node_flags_t = node_flags.view(-1)
+        node_iou_loss = node_iou_loss * node_flags_t.to(torch.float32)
+        node_iou_loss = node_iou_loss.view(-1, node_flags.shape[1])
+        # (the reference divides by node_flags_t.sum(dim=-1), the TOTAL number of valid nodes of the batch -- :158)
+        node_iou_loss = node_iou_loss.sum(dim=-1) / node_flags_t.sum(dim=-1).to(torch.float32)
+        reg_loss_node_iou = reg_loss_node + iou_loss_weight * node_iou_loss * weights
+        loss = reg_loss_adj.mean() + reg_loss_node_iou.mean()
+        for k, v in dict(sigmas=sigmas, weights=weights, noisy_adj=net_input_a, noisy_node=net_input_x, pred_adj=net_output_a,
+                         pred_node=net_output_x, loss_adj=reg_loss_adj, loss_node=reg_loss_node_iou).items():
+            res[f"{name}_{k}"] = v.numpy().copy()
+        res[f"{name}_loss"] = np.array(float(loss))
+        print(f"train forward {name}: sigmas {sigmas.numpy()}, loss_adj {reg_loss_adj.numpy()}, loss_node {reg_loss_node_iou.numpy()}, loss {float(loss):.6f}")
+    np.savez_compressed(os.path.join(out, "train_forward.npz"), **res)
+
+
 def check_channel_table():
     """diffusesg_amd.spec.sg_channels (data restated from sg_utils.py:348-409) against the imported reference function."""
     from utils.sg_utils import get_node_adj_num_type
@@ -330,6 +409,8 @@ def main():
     check_channel_table()
     if args.only in ("", "decode"):
         gen_decode(args.out)
+    if args.only in ("", "train"):
+        gen_train_forward(DiffuseSG, NodeAdjPrecond, args.out)
     if args.only in ("", "fwd"):
         gen_forward(DiffuseSG, args.out)
     if args.only in ("", "precond"):
