@@ -108,10 +108,12 @@ struct dsg_handle_s {
     // folded read-out (E = 96): Fa = F1.W2.W1.W0^T packed fragment-major, fa; F2 padded+packed; node: Gext [E,128]
     float *ro_fap = nullptr, *ro_fa = nullptr, *ro_f2p = nullptr, *ro_gext = nullptr;
     float *ro0_wf = nullptr, *ro0_bf = nullptr;  // read_out.0 ([out,in]) with the final norm's gamma/beta folded in
+    float *merge_wf[DSG_MAX_LAYERS] = {}, *merge_bf[DSG_MAX_LAYERS] = {};   // PatchMerging reduction with its LayerNorm(4C) folded in
     std::vector<void *> derived_allocs;
     std::map<int, std::unique_ptr<Workspace>> ws;
     // kernel-selection options (dsg_set_option); defaults may be overridden once by DSG_* environment variables
     bool opt_fused_attn = true, opt_fused_mlp = true, opt_fused_readout = true, opt_fused_pe = true;
+    bool opt_fused_merge = true;      // PatchMerging: gather + LayerNorm(4C) inside the reduction GEMM's A path (no merge_ln kernel)
     bool opt_loop_graph = true;       // capture whole step bodies of the reverse loop (0: only the network forward is a graph)
     bool opt_fused_qkv_attn = true;   // QKV projection + 64-token window attention in one kernel (q, k, v never reach HBM)
     bool opt_fused_rowstats = true;   // modulate+SiLU and LayerNorm statistics in the producing GEMM's epilogue (fp32 kernel)
@@ -519,6 +521,7 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     h->opt_fused_rowstats = env_on("DSG_FUSED_ROWSTATS", true);
     h->opt_fused_qkv_attn = env_on("DSG_FUSED_QKV_ATTN", true);
     h->opt_loop_graph = env_on("DSG_LOOP_GRAPH", true);
+    h->opt_fused_merge = env_on("DSG_FUSED_MERGE", true);
     if (getenv("DSG_FUSED_MLP_MAXC")) h->opt_fused_mlp_maxc = atoi(getenv("DSG_FUSED_MLP_MAXC"));
     h->opt_gemm_bf16 = env_on("DSG_GEMM_BF16", false);
     h->opt_gemm_split = env_on("DSG_GEMM_SPLIT", false);
@@ -631,6 +634,12 @@ int dsg_finalize_weights(dsg_handle h) {
                                      WT(h, b.prefix + ".norm2.bias"), Hd, C, &b.fc1_wf, &b.fc1_bf)) return rc;
             }
     }
+    for (int l = 0; l + 1 < L; l++) {   // PatchMerging: norm(4C) folded into reduction (no bias in the reference: the folded bias is W.beta)
+        const std::string pm = "down_layers." + std::to_string(l) + ".downsample";
+        const int C = E << l;
+        if (int rc = fold_ln(h, WT(h, pm + ".reduction.weight"), nullptr, WT(h, pm + ".norm.weight"), WT(h, pm + ".norm.bias"), 2 * C, 4 * C,
+                             &h->merge_wf[l], &h->merge_bf[l])) return rc;
+    }
     // patch_embed.proj [E,Cin,1,1] -> [E,Kp] zero padded
     {
         std::vector<float> src((size_t)E * h->Cin), dst((size_t)E * h->Kp, 0.f);
@@ -735,6 +744,7 @@ int dsg_finalize_weights(dsg_handle h) {
                 h->gemm_weights.push_back({b.qkv_wf, (size_t)3 * b.C * b.C});
                 h->gemm_weights.push_back({b.fc1_wf, (size_t)c.mlp_ratio * b.C * b.C});
             }
+    for (int l = 0; l + 1 < L; l++) h->gemm_weights.push_back({h->merge_wf[l], (size_t)8 * (E << l) * (E << l)});
     h->gemm_weights.push_back({h->aff_w, (size_t)h->aff_n * NOISE_EMB});
     h->gemm_weights.push_back({h->pe_w, (size_t)E * h->Kp});
     h->gemm_weights.push_back({h->ro0_wf, (size_t)E * E});
@@ -833,8 +843,9 @@ void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStre
 // a block's input also applies that block's modulate+SiLU and leaves per-column-tile (sum, sumsq) partials of the stored rows
 // in w->stats, from which the consuming GEMM forms the LayerNorm statistics -- mod_stats / ln_stats launches disappear.
 bool rowstats_on(dsg_handle h) { return h->opt_fused_rowstats && !h->opt_gemm_bf16 && !h->opt_gemm_split && h->taps.empty(); }
-// does block `nb` take its input pre-modulated with LN1 partials?  (the C = 96 fused attention kernel modulates itself)
-bool wants_premod(dsg_handle h, const BlockPlan *nb) { return nb && rowstats_on(h) && !(h->opt_fused_attn && nb->wqp); }
+// does block `nb` take its input pre-modulated?  Generic blocks also read the LN1 partials the producer leaves; the C = 96 fused
+// attention kernel only skips its own modulate+SiLU (twice: prologue and shortcut) and keeps computing LN1 itself.
+bool wants_premod(dsg_handle h, const BlockPlan *nb) { return nb && rowstats_on(h); }
 // attach "modulate for block nb + row statistics" to the GEMM that writes nb's input (M rows = B * T tokens of nb's level)
 void attach_premod(dsg_handle h, Workspace *w, GemmArgs &g, const BlockPlan *nb) {
     if (!wants_premod(h, nb)) return;
@@ -844,8 +855,11 @@ void attach_premod(dsg_handle h, Workspace *w, GemmArgs &g, const BlockPlan *nb)
 
 // One Swin block (diffusesg.py:232-277) on x [B*T, C] in place.  premod: x is already modulated and w->stats holds the LN1
 // partials (attach_premod on the producer).  next: the block that consumes this block's output directly (same width), or null.
-// Returns true if `next`'s input was left pre-modulated.
-bool run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, const BlockPlan *next, hipStream_t s) {
+// want_stats: leave (sum, sumsq) partials of the block's OUTPUT rows in w->stats even without a next block (PatchMerging
+// reads them).  Returns what the producer left behind: .premod -- next's input is pre-modulated (+ its LN1 partials);
+// .stats_parts -- > 0: partials of the un-modulated output rows with that many pairs per row.
+struct BlockOut { bool premod; int stats_parts; };
+BlockOut run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, const BlockPlan *next, bool want_stats, hipStream_t s) {
     const int B = w->B, T = b.res * b.res, C = b.C, M = B * T, Hd = h->cfg.mlp_ratio * C;
     const std::string &p = b.prefix;
     const bool fuse = rowstats_on(h);
@@ -856,7 +870,7 @@ bool run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, cons
         WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
         P_KERN(PK_FUSED, 2.0 * (double)M * C * 4.0 * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C,
                launch_fused_attn96(w->x, w->aff, w->aff_ld, b.aff_off, WT(h, p + ".norm1.weight"), WT(h, p + ".norm1.bias"), b.wqp,
-                                   b.bqkv_s, b.biasT, b.wpp, WT(h, p + ".attn.proj.bias"), B, wg, s));
+                                   b.bqkv_s, b.biasT, b.wpp, WT(h, p + ".attn.proj.bias"), B, wg, premod, s));
     } else {
         // x <- silu(shift + x*(1+scale)) (also the shortcut), LayerNorm-1 statistics
         if (!premod) P_KERN(PK_ROW, 0.0, launch_mod_stats(w->x, w->aff, w->aff_ld, b.aff_off, w->stats, B, T, C, s));
@@ -890,10 +904,11 @@ bool run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, cons
     }
     if (mlp_fused) {
         // LN2 + fc1 + GELU + fc2 + residual in one kernel, hidden activations never leave the register file
+        const bool st = want_stats && fuse;
         P_KERN(PK_FUSED, 4.0 * (double)M * (double)C * (double)Hd,
                launch_fused_mlp(w->x, WT(h, p + ".norm2.weight"), WT(h, p + ".norm2.bias"), b.w1p, WT(h, p + ".mlp.fc1.bias"), b.w2p,
-                                WT(h, p + ".mlp.fc2.bias"), M, C, s));
-        return false;   // the fused MLP has no modulate epilogue: the next block runs its own mod_stats
+                                WT(h, p + ".mlp.fc2.bias"), M, C, st ? w->stats : nullptr, s));
+        return BlockOut{false, st ? 1 : 0};   // the fused MLP has no modulate epilogue: the next block runs its own mod_stats
     }
     const bool ln2_part = fuse && !(h->opt_fused_attn && b.wqp);   // the proj GEMM above left the partials
     if (!ln2_part) P_KERN(PK_ROW, 0.0, launch_ln_stats(w->x, w->stats, M, C, s));
@@ -909,8 +924,10 @@ bool run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, cons
     g.W = WT(h, p + ".mlp.fc2.weight"); g.bias = WT(h, p + ".mlp.fc2.bias");
     g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
     attach_premod(h, w, g, next);
+    const bool st = !g.stats_out && want_stats && fuse;
+    if (st) g.stats_out = w->stats;   // plain row statistics of the output (EPI 1)
     P_GEMM_LP(g);
-    return g.stats_out != nullptr;
+    return BlockOut{g.mod_aff != nullptr, st ? (C + 95) / 96 : 0};
 }
 
 // PositionalEmbedding + map_layer0/1 + all affine linears for `rows` noise labels (diffusesg.py:768-771, :238, :574)
@@ -932,6 +949,9 @@ void embed_rows(dsg_handle h, const float *c_noise, int rows, float *pe, float *
 
 // DiffuseSG.forward on the workspace's fixed buffers: (in_adj,in_node,sc_*,flags,c_noise) -> (f_adj,f_node)
 void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
+    // the fused PatchMerging writes the coarser level into the other activation buffer and swaps the two names; put them back
+    // on every exit so that each forward (and each captured graph) starts from the same assignment
+    struct SwapGuard { Workspace *w; float *x, *y; ~SwapGuard() { w->x = x; w->y = y; } } swap_guard{w, w->x, w->y};
     const dsg_config &c = h->cfg;
     const int B = w->B, N = h->N, E = h->E, L = h->L, T0 = N * N;
     char name[64];
@@ -942,13 +962,17 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
         embed_rows(h, w->c_noise, B, w->pe, w->emb0, w->emb, w->aff, s);
     }
     // input assembly + PatchEmbed (diffusesg.py:784-802, 562-577)
-    bool pe_done = false;
+    bool pe_done = false, pe_premod = false;
     if (h->opt_fused_pe && h->pe_wp) {
         ProfScope ps_(h, s, PK_FUSED, 2.0 * (double)B * T0 * E * h->Cin, "launch_fused_patch_embed96");
+        // the first block's modulate+SiLU rides along when that block is the fused C = 96 attention kernel (which then skips it)
+        const BlockPlan *b0 = h->down[0].empty() ? nullptr : &h->down[0][0];
+        pe_premod = wants_premod(h, b0) && h->opt_fused_attn && b0->wqp;
         pe_done = launch_fused_patch_embed96(w->in_adj, w->in_node, w->cur_sc_adj, w->cur_sc_node, w->cur_has_sc, w->flags, h->pe_wp,
                                              WT(h, "patch_embed.proj.bias"), WT(h, "patch_embed.norm.weight"),
-                                             WT(h, "patch_embed.norm.bias"), w->aff, w->aff_ld, h->pe_aff_off, w->x, B, N, h->Ca, h->Cn,
-                                             c.self_condition, h->Kp, s);
+                                             WT(h, "patch_embed.norm.bias"), w->aff, w->aff_ld, h->pe_aff_off, pe_premod ? b0->aff_off : -1,
+                                             w->x, B, N, h->Ca, h->Cn, c.self_condition, h->Kp, s);
+        pe_premod = pe_premod && pe_done;
     }
     if (!pe_done) {
         P_KERN(PK_ELEM, 0.0, launch_assemble(w->in_adj, w->in_node, w->cur_sc_adj, w->cur_sc_node, w->cur_has_sc, w->flags, w->tok_in, B, N, h->Ca, h->Cn,
@@ -962,26 +986,42 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     }
     tap(h, "patch_embed", w->x, (size_t)B * T0 * E, s);
     // encoder (diffusesg.py:745-748)
-    bool premod = false;   // is w->x already modulated for the next block, with its LN1 partials in w->stats?
+    bool premod = pe_premod;   // is w->x already modulated for the next block (generic blocks: with LN1 partials in w->stats)?
+    int merge_parts = 0;       // > 0: w->stats holds partials of the level's final output rows (for the fused PatchMerging)
     for (int l = 0; l < L; l++) {
         const int C = E << l, res = N >> l, T = res * res;
         for (size_t j = 0; j < h->down[l].size(); j++) {
             // the consumer of this block's output: the next block of the level; after the deepest level the first decoder
             // block (no upsample there); otherwise PatchMerging, which takes the un-modulated tensor
             const BlockPlan *next = j + 1 < h->down[l].size() ? &h->down[l][j + 1] : (l == L - 1 && !h->up[0].empty() ? &h->up[0][0] : nullptr);
-            premod = run_block(h, w, h->down[l][j], premod, next, s);
+            // the level's last block leaves row statistics for the fused PatchMerging
+            const bool for_merge = !next && l < L - 1 && h->opt_fused_merge && rowstats_on(h) && C % 32 == 0;
+            const BlockOut bo = run_block(h, w, h->down[l][j], premod, next, for_merge, s);
+            premod = bo.premod; merge_parts = bo.stats_parts;
             snprintf(name, sizeof(name), "down%d.block%d", l, (int)j);
             tap(h, name, w->x, (size_t)B * T * C, s);
         }
         if (l < L - 1) {
             const std::string p = "down_layers." + std::to_string(l) + ".downsample";
-            P_KERN(PK_ROW, 0.0, launch_merge_ln(w->x, WT(h, p + ".norm.weight"), WT(h, p + ".norm.bias"), w->y, B, res, C, s));
             g = GemmArgs();
-            g.A = w->y; g.lda = 4 * C; g.K1 = 4 * C; g.K = 4 * C; g.M = B * T / 4; g.N = 2 * C;
-            g.W = WT(h, p + ".reduction.weight"); g.C = w->x; g.ldc = 2 * C; g.C2 = w->skips[l]; g.ldc2 = 2 * C;
+            g.K1 = 4 * C; g.K = 4 * C; g.M = B * T / 4; g.N = 2 * C;
+            if (merge_parts > 0) {
+                // 2x2 gather, LayerNorm(4C) (statistics from the four source rows' partials, gamma/beta folded into the weight)
+                // and the reduction in one GEMM: the merged [B*T/4, 4C] tensor is never written
+                g.A = w->x; g.lda = C; g.a4_res = res; g.ln_part = w->stats; g.ln_nparts = merge_parts;
+                g.W = h->merge_wf[l]; g.bias = h->merge_bf[l];
+                g.C = w->y; g.ldc = 2 * C;   // cannot overwrite x while other tiles still gather from it: write y, then swap
+            } else {
+                P_KERN(PK_ROW, 0.0, launch_merge_ln(w->x, WT(h, p + ".norm.weight"), WT(h, p + ".norm.bias"), w->y, B, res, C, s));
+                g.A = w->y; g.lda = 4 * C;
+                g.W = WT(h, p + ".reduction.weight"); g.C = w->x; g.ldc = 2 * C;
+            }
+            g.C2 = w->skips[l]; g.ldc2 = 2 * C;
             attach_premod(h, w, g, h->down[l + 1].empty() ? nullptr : &h->down[l + 1][0]);   // the skip copy (C2) stays un-modulated
             P_GEMM_LP(g);
-            premod = g.stats_out != nullptr;
+            premod = g.mod_aff != nullptr;
+            if (merge_parts > 0) std::swap(w->x, w->y);   // the new level's activation lives in the other buffer from here on
+            merge_parts = 0;
         }
         snprintf(name, sizeof(name), "down%d", l);
         tap(h, name, w->x, l < L - 1 ? (size_t)B * (T / 4) * 2 * C : (size_t)B * T * C, s);
@@ -1004,13 +1044,13 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
             g.W = WT(h, p + ".post_linear.weight"); g.C = w->x; g.ldc = C;
             attach_premod(h, w, g, h->up[i].empty() ? nullptr : &h->up[i][0]);
             P_GEMM_LP(g);
-            premod = g.stats_out != nullptr;
+            premod = g.mod_aff != nullptr;
             snprintf(name, sizeof(name), "up%d.upsample", i);
             tap(h, name, w->x, (size_t)B * T * C, s);
         }
         for (size_t j = 0; j < h->up[i].size(); j++) {
             const BlockPlan *next = j + 1 < h->up[i].size() ? &h->up[i][j + 1] : nullptr;   // then PatchBreakup / the read-out
-            premod = run_block(h, w, h->up[i][j], premod, next, s);
+            premod = run_block(h, w, h->up[i][j], premod, next, false, s).premod;
             snprintf(name, sizeof(name), "up%d.block%d", i, (int)j);
             tap(h, name, w->x, (size_t)B * T * C, s);
         }
@@ -1247,6 +1287,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "fused_rowstats") h->opt_fused_rowstats = value != 0;
     else if (n == "fused_qkv_attn") h->opt_fused_qkv_attn = value != 0;
     else if (n == "loop_graph") h->opt_loop_graph = value != 0;
+    else if (n == "fused_merge") h->opt_fused_merge = value != 0;
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
         if (h->opt_gemm_bf16 && h->finalized) if (int rc = ensure_bf16_weights(h)) return rc;
@@ -1271,6 +1312,7 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "fused_rowstats") *value = h->opt_fused_rowstats;
     else if (n == "fused_qkv_attn") *value = h->opt_fused_qkv_attn;
     else if (n == "loop_graph") *value = h->opt_loop_graph;
+    else if (n == "fused_merge") *value = h->opt_fused_merge;
     else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
     else if (n == "gemm_split") *value = h->opt_gemm_split;
     else return fail(h, DSG_ERR_INVALID, "unknown option '%s'", name);

@@ -44,6 +44,10 @@ struct GemmArgs {
     // fused QKV projection + window attention (8x8 windows; launch_gemm_qkv_attn): W = qkv weight [3C,K] (q rows pre-scaled),
     // bias = qkv bias [3C]; a block computes q|k|v of ONE head for TWO windows (rows gathered through the window partition /
     // cyclic shift), runs softmax(q k^T + attn_bias) v from LDS and stores the head's 32 output columns to C [M, wg.C]
+    // PatchMerging gather in the A path (diffusesg.py:323-332): logical A row m = (b, i, j) of the coarse grid is
+    // cat[x(2i,2j), x(2i+1,2j), x(2i,2j+1), x(2i+1,2j+1)] of the fine activation g.A [B, a4_res^2, K/4]; no copy is ever
+    // materialised.  LayerNorm(4C) statistics come from the four source rows' partials (ln_part, ln_nparts per source row).
+    int a4_res = 0;                              // > 0 selects the gather; needs ln_part, no A2
     const float *attn_bias = nullptr;            // [nWt][heads][64][64] key-major, log2(e)-scaled (build_bias_table)
     WinGeom wg{0, 0, 0, 0, 0};
     int attn_batch = 0;
@@ -59,14 +63,15 @@ void launch_f32_split3(const float *src, void *dst, size_t n, hipStream_t s);
 const float *gelu_table();
 
 // x <- x + fc2(GELU(fc1(LN(x)))) with fragment-major packed weights (pack_mlp_weights in dsg_api.cpp); C in {96,192}
+// stats_out (optional): [M][1][2] (sum, sumsq) of the rows written back, in the GEMM epilogue's partial format
 void launch_fused_mlp(float *x, const float *gam, const float *bet, const float *W1p, const float *b1, const float *W2p,
-                      const float *b2, int M, int C, hipStream_t s);
+                      const float *b2, int M, int C, float *stats_out, hipStream_t s);
 
 // input assembly + 1x1 conv + LayerNorm + modulate+SiLU in one kernel (E = 96, in_chans <= 64); false if unsupported
 bool launch_fused_patch_embed96(const float *adj, const float *node, const float *sc_adj, const float *sc_node, const int *has_sc,
                                 const uint8_t *flags, const float *Wp, const float *bias, const float *gam, const float *bet,
-                                const float *aff, int aff_ld, int aff_off, float *x, int B, int N, int Ca, int Cn, int self_cond, int Kp,
-                                hipStream_t s);
+                                const float *aff, int aff_ld, int aff_off, int aff_off2, float *x, int B, int N, int Ca, int Cn,
+                                int self_cond, int Kp, hipStream_t s);   // aff_off2 >= 0: also apply that block's modulate+SiLU
 // final LN + folded read_out/adj-head chain + masked adjacency output, and the LN(x) pooling for the node head (E = 96)
 // pool_part [B*N][readout_pool_segments(N)][96]: per-tile partial sums, reduced in fixed order into pool_ext [B*N,128]
 int readout_pool_segments(int N);
@@ -77,7 +82,7 @@ void launch_fused_readout96(const float *x, const float *gam, const float *bet, 
 // windows of at most 64 tokens; packed weights from pack_attn_weights in dsg_api.cpp
 void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, const float *gam, const float *bet, const float *Wqp,
                          const float *bqkv, const float *biasT, const float *Wpp, const float *bproj, int B, const WinGeom &g,
-                         hipStream_t s);
+                         bool premod, hipStream_t s);   // premod: x is already modulated by the producing kernel
 // qkv [B*T, 3C] token order -> out [B*T, C] token order; biasT [nWt][heads][Wp][Wp] (key-major)
 void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s);
 

@@ -51,7 +51,8 @@ __device__ unsigned long long *g_diag_buf = nullptr;
 // padded to 128 rows) x (q|k|v of one head), tile rows are gathered through the window partition / cyclic shift
 // (diffusesg.py:28-57, :246-256), q, k, v go to LDS instead of HBM and softmax(q k^T + bias) v runs from there (same operand
 // scheme as window_attn_kernel below; padded key slots carry -1e30 in the bias table, padded rows are never stored).
-template <bool LN, int ACT, bool RES, int EPI, int WS = 8>   // WS: window side of the fused attention (EPI == 4): 8 or 10
+// AMODE 1: PatchMerging gather in the A path (GemmArgs::a4_res).
+template <bool LN, int ACT, bool RES, int EPI, int WS = 8, int AMODE = 0>   // WS: window side of the fused attention (EPI == 4): 8 or 10
 __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (GBM + GBN) * GLD];
     constexpr int BUF = (GBM + GBN) * GLD;
@@ -82,10 +83,14 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
         return b * a_T + ti * a_res + tj;
     };
     // block-uniform descriptors: base = first row of the tile, range = the valid rows (out-of-range reads give 0)
-    const rsrc_t rsA1 = (EPI == 4) ? make_rsrc(g.A, (unsigned)g.M * g.lda * 4u) : make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
+    const int a4_C = g.K >> 2;   // AMODE 1: channels of one source row
+    const rsrc_t rsA1 = (EPI == 4) ? make_rsrc(g.A, (unsigned)g.M * g.lda * 4u)
+                        : (AMODE == 1) ? make_rsrc(g.A, (unsigned)g.M * (unsigned)g.K * 4u)   // 4*M fine rows of K/4 floats
+                                       : make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
     const rsrc_t rsA2 = make_rsrc(g.A2 ? g.A2 + (size_t)m0 * g.lda2 : g.A, g.A2 ? (unsigned)rows_m * g.lda2 * 4u : 0u);
     const rsrc_t rsW = (EPI == 4) ? make_rsrc(g.W, (unsigned)(3 * g.wg.C) * g.K * 4u) : make_rsrc(g.W + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 4u);
     unsigned voffA1[4], voffA2[4], voffW[3];
+    unsigned voffA4[4][4];   // AMODE 1: [part][staging row]
     float a_rstd[4], a_nmr[4];
     int my_tok = -1;   // EPI == 4: token row of tile row `tid` (threads 0..127), for the output scatter
     if (EPI == 4 && tid < GBM) my_tok = win_row(tid);
@@ -99,7 +104,24 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
             grow = win_row(r);
             voffA1[p] = grow >= 0 ? ((unsigned)grow * g.lda + 4u * c4) * 4u : 0x7fffffffu;
         }
-        if (LN) {
+        if (AMODE == 1) {
+            // coarse row -> its four fine rows (order x00, x10, x01, x11: part q has di = q&1, dj = q>>1); LayerNorm(4C)
+            // statistics = the four rows' partial (sum, sumsq) pairs added in a fixed order
+            const int m = min(m0 + r, g.M - 1), r2 = g.a4_res >> 1, T2 = r2 * r2;
+            const int b = m / T2, t = m - b * T2, i = t / r2, j = t - i * r2;
+            float sm = 0.f, sq = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int srow = b * g.a4_res * g.a4_res + (2 * i + (q & 1)) * g.a4_res + 2 * j + (q >> 1);
+                voffA4[q][p] = ((unsigned)srow * (unsigned)a4_C + 4u * c4) * 4u;
+                const float *pp = g.ln_part + (size_t)srow * g.ln_nparts * 2;
+                for (int tt = 0; tt < g.ln_nparts; tt++) { sm += pp[2 * tt]; sq += pp[2 * tt + 1]; }
+            }
+            const float invk = 1.0f / (float)g.K;
+            const float mean = sm * invk, rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);
+            a_rstd[p] = rstd;
+            a_nmr[p] = -mean * rstd;
+        } else if (LN) {
             const int m = (EPI == 4) ? max(grow, 0) : min(m0 + r, g.M - 1);
             float mean, rstd;
             if (g.ln_part) {   // partial (sum, sumsq) per 96-column tile of the producer: [M][nparts][2], added in tile order
@@ -143,7 +165,23 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
         kc = kc < nk ? kc : nk - 1;  // the tail iterations re-load a valid chunk they never use
         const bool second = kc >= nk1;
         const unsigned soffA = (unsigned)(second ? kc - nk1 : kc) * (GBK * 4u), soffW = (unsigned)kc * (GBK * 4u);
-        if (second) {
+        if (AMODE == 1) {
+            const int cpp = a4_C / GBK, q = kc / cpp;   // chunks per part; part of this chunk (block-uniform)
+            const unsigned soff4 = (unsigned)(kc - q * cpp) * (GBK * 4u);
+            if (q == 0) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) st.a[p] = buf_load4(rsA1, voffA4[0][p], soff4);
+            } else if (q == 1) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) st.a[p] = buf_load4(rsA1, voffA4[1][p], soff4);
+            } else if (q == 2) {
+#pragma unroll
+                for (int p = 0; p < 4; p++) st.a[p] = buf_load4(rsA1, voffA4[2][p], soff4);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; p++) st.a[p] = buf_load4(rsA1, voffA4[3][p], soff4);
+            }
+        } else if (second) {
 #pragma unroll
             for (int p = 0; p < 4; p++) st.a[p] = buf_load4(rsA2, voffA2[p], soffA);
         } else {
@@ -441,6 +479,15 @@ void launch_gemm(const GemmArgs &g, hipStream_t s) {
     const bool ln = g.ln_stats != nullptr || g.ln_part != nullptr, res = g.res != nullptr;
 #define GEMM_CASE(L, A, R) hipLaunchKernelGGL((gemm4_f32_kernel<L, A, R, 0>), grid, block, 0, s, g, tiles_m, tiles_n)
 #define GEMM_EPI(R, E) hipLaunchKernelGGL((gemm4_f32_kernel<false, ACT_NONE, R, E>), grid, block, 0, s, g, tiles_m, tiles_n)
+    if (g.a4_res > 0) {   // PatchMerging gather + LayerNorm(4C) from partials; epilogue: plain, or premod + stats (dual store allowed)
+        if (!g.ln_part || g.A2 || g.act != ACT_NONE || res || (g.K >> 2) % GBK != 0 || (g.stats_out && !g.mod_aff)) {
+            fprintf(stderr, "dsg: launch_gemm: unsupported PatchMerging-gather GEMM\n"); abort();
+        }
+#define GEMM_MERGE(E) hipLaunchKernelGGL((gemm4_f32_kernel<true, ACT_NONE, false, E, 8, 1>), grid, block, 0, s, g, tiles_m, tiles_n)
+        if (!g.stats_out) GEMM_MERGE(0); else if (g.mod_ld == 0) GEMM_MERGE(2); else GEMM_MERGE(3);
+#undef GEMM_MERGE
+        return;
+    }
     if (g.stats_out) {   // epilogue extensions: only the shapes the forward uses (plain A path, no activation)
         if (ln || g.act != ACT_NONE) { fprintf(stderr, "dsg: launch_gemm: stats_out with LN/activation is not built\n"); abort(); }
         const int epi = !g.mod_aff ? 1 : (g.mod_ld == 0 ? 2 : 3);
@@ -494,7 +541,8 @@ template <int C>
 __global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float *__restrict__ x, const float *__restrict__ gam,
                                                            const float *__restrict__ bet, const float *__restrict__ W1p,
                                                            const float *__restrict__ b1, const float *__restrict__ W2p,
-                                                           const float *__restrict__ b2, const float *__restrict__ gelu_tab, int M) {
+                                                           const float *__restrict__ b2, const float *__restrict__ gelu_tab, int M,
+                                                           float *__restrict__ stats_out) {
     constexpr int S = C / 8, CT = C / 32, NT = 4 * C / 32;
     __shared__ __attribute__((aligned(16))) float gtab[GELU_TAB_FLOATS];
     gelu_tab_to_lds(gtab, gelu_tab, threadIdx.x, 256);
@@ -570,6 +618,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float
                     oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[ct * 4 + g][t], hacc[4 * g + t], oacc[ct], 0, 0, 0);
     }
     // epilogue: channel of oacc[ct][4g+t] is 32ct + 8g + 4*half + t -- the same pattern as the input fragments
+    float rs = 0.f, rq = 0.f;   // (sum, sumsq) of the row written back: a row is split over the two half-waves
     if (ok) {
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
@@ -580,17 +629,22 @@ __global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float
                 const f32x4 bv = *reinterpret_cast<const f32x4 *>(b2 + c + 4 * lhalf);
                 f32x4 o;
 #pragma unroll
-                for (int t = 0; t < 4; t++) o[t] = oacc[ct][4 * g + t] + bv[t] + xv[t];
+                for (int t = 0; t < 4; t++) { o[t] = oacc[ct][4 * g + t] + bv[t] + xv[t]; rs += o[t]; rq = fmaf(o[t], o[t], rq); }
                 *reinterpret_cast<f32x4 *>(xr + c) = o;
             }
+    }
+    if (stats_out) {   // same format as the GEMM epilogue's partials with one column tile... C/96 tiles folded into one pair
+        rs += __shfl_xor(rs, 32, 64);
+        rq += __shfl_xor(rq, 32, 64);
+        if (ok && lhalf == 0) { stats_out[2 * (size_t)m] = rs; stats_out[2 * (size_t)m + 1] = rq; }
     }
 }
 
 void launch_fused_mlp(float *x, const float *gam, const float *bet, const float *W1p, const float *b1, const float *W2p,
-                      const float *b2, int M, int C, hipStream_t s) {
+                      const float *b2, int M, int C, float *stats_out, hipStream_t s) {
     const dim3 grid((M + 127) / 128), block(256);
-    if (C == 96) hipLaunchKernelGGL(fused_mlp_kernel<96>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, g_gelu_tab_dev, M);
-    else if (C == 192) hipLaunchKernelGGL(fused_mlp_kernel<192>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, g_gelu_tab_dev, M);
+    if (C == 96) hipLaunchKernelGGL(fused_mlp_kernel<96>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, g_gelu_tab_dev, M, stats_out);
+    else if (C == 192) hipLaunchKernelGGL(fused_mlp_kernel<192>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, g_gelu_tab_dev, M, stats_out);
 }
 
 // =================================================================================================
@@ -604,7 +658,7 @@ void launch_fused_mlp(float *x, const float *gam, const float *bet, const float 
 //   O^T      = V[r] x P[r]   (lane = query, register = d)  ->  Y^T += Wproj[:, head] x O^T[r]
 // No LDS, no barrier, no intermediate tensor in HBM; weights are read as pre-packed fragment-major 1-KiB wave loads.
 // =================================================================================================
-template <int MB>
+template <int MB, bool PREMOD = false>   // PREMOD: x arrives already modulated (the producer applied silu(shift + x(1+scale)))
 __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict__ x, const float *__restrict__ aff, int aff_ld,
                                                              int aff_off, const float *__restrict__ gam,
                                                              const float *__restrict__ bet, const float *__restrict__ Wqp,
@@ -649,7 +703,7 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
             const f32x4 sh = *reinterpret_cast<const f32x4 *>(shift + 8 * s);
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-                xn[mb][s][t] = silu_exact(sh[t] + v[t] * (sc[t] + 1.0f));
+                xn[mb][s][t] = PREMOD ? v[t] : silu_exact(sh[t] + v[t] * (sc[t] + 1.0f));
                 sum += xn[mb][s][t];
             }
         }
@@ -794,7 +848,7 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
                 const f32x4 bp = *reinterpret_cast<const f32x4 *>(bproj + c + 4 * lhalf);
                 f32x4 o;
 #pragma unroll
-                for (int t = 0; t < 4; t++) o[t] = silu_exact(sh[t] + v[t] * (sc[t] + 1.0f)) + yacc[mb][ct][4 * gq + t] + bp[t];
+                for (int t = 0; t < 4; t++) o[t] = (PREMOD ? v[t] : silu_exact(sh[t] + v[t] * (sc[t] + 1.0f))) + yacc[mb][ct][4 * gq + t] + bp[t];
                 *reinterpret_cast<f32x4 *>(xrow[mb] + c) = o;
             }
     }
@@ -802,14 +856,14 @@ __global__ __launch_bounds__(256, 1) void fused_attn96_kernel(float *__restrict_
 
 void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, const float *gam, const float *bet, const float *Wqp,
                          const float *bqkv, const float *biasT, const float *Wpp, const float *bproj, int B, const WinGeom &g,
-                         hipStream_t s) {
+                         bool premod, hipStream_t s) {
     const int nW = (g.res / g.ws) * (g.res / g.ws), n_windows = B * nW;
     const int MB = (g.ws * g.ws + 31) / 32;
     const dim3 grid((n_windows + 3) / 4), block(256);
-    if (MB == 1)
-        hipLaunchKernelGGL(fused_attn96_kernel<1>, grid, block, 0, s, x, aff, aff_ld, aff_off, gam, bet, Wqp, bqkv, biasT, Wpp, bproj, g, n_windows);
-    else
-        hipLaunchKernelGGL(fused_attn96_kernel<2>, grid, block, 0, s, x, aff, aff_ld, aff_off, gam, bet, Wqp, bqkv, biasT, Wpp, bproj, g, n_windows);
+#define FA(MB_, PM_) hipLaunchKernelGGL((fused_attn96_kernel<MB_, PM_>), grid, block, 0, s, x, aff, aff_ld, aff_off, gam, bet, Wqp, bqkv, biasT, Wpp, bproj, g, n_windows)
+    if (MB == 1) { if (premod) FA(1, true); else FA(1, false); }
+    else { if (premod) FA(2, true); else FA(2, false); }
+#undef FA
 }
 
 // =================================================================================================
@@ -966,7 +1020,7 @@ __global__ __launch_bounds__(256, 2) void fused_patch_embed96_kernel(const float
                                                                     const int *__restrict__ has_sc, const uint8_t *__restrict__ flags,
                                                                     const float *__restrict__ Wp, const float *__restrict__ bias,
                                                                     const float *__restrict__ gam, const float *__restrict__ bet,
-                                                                    const float *__restrict__ aff, int aff_ld, int aff_off,
+                                                                    const float *__restrict__ aff, int aff_ld, int aff_off, int aff_off2,
                                                                     float *__restrict__ x, int B, int N, int Ca_rt, int Cn_rt, int self_cond) {
     constexpr int C = 96, S = KP / 8;
     const int Ca = CA > 0 ? CA : Ca_rt, Cn = CN > 0 ? CN : Cn_rt;
@@ -1049,17 +1103,23 @@ __global__ __launch_bounds__(256, 2) void fused_patch_embed96_kernel(const float
                 const float n = (acc[nt][4 * g + t] - mean) * rstd * gg[t] + bb[t];
                 o[t] = silu_exact(sh[t] + n * (sc[t] + 1.0f));
             }
+            if (aff_off2 >= 0) {   // the first Swin block's modulate+SiLU on top (it then takes its input pre-modulated)
+                const float *scale2 = aff + (size_t)b * aff_ld + aff_off2 + 4 * lhalf;
+                const f32x4 sc2 = *reinterpret_cast<const f32x4 *>(scale2 + e), sh2 = *reinterpret_cast<const f32x4 *>(scale2 + C + e);
+#pragma unroll
+                for (int t = 0; t < 4; t++) o[t] = silu_exact(sh2[t] + o[t] * (sc2[t] + 1.0f));
+            }
             *reinterpret_cast<f32x4 *>(xr + e) = o;
         }
 }
 
 bool launch_fused_patch_embed96(const float *adj, const float *node, const float *sc_adj, const float *sc_node, const int *has_sc,
                                 const uint8_t *flags, const float *Wp, const float *bias, const float *gam, const float *bet,
-                                const float *aff, int aff_ld, int aff_off, float *x, int B, int N, int Ca, int Cn, int self_cond, int Kp,
-                                hipStream_t s) {
+                                const float *aff, int aff_ld, int aff_off, int aff_off2, float *x, int B, int N, int Ca, int Cn,
+                                int self_cond, int Kp, hipStream_t s) {
     const int M = B * N * N;
     const dim3 grid((M + 127) / 128), block(256);
-#define PE_ARGS adj, node, sc_adj, sc_node, has_sc, flags, Wp, bias, gam, bet, aff, aff_ld, aff_off, x, B, N, Ca, Cn, self_cond
+#define PE_ARGS adj, node, sc_adj, sc_node, has_sc, flags, Wp, bias, gam, bet, aff, aff_ld, aff_off, aff_off2, x, B, N, Ca, Cn, self_cond
     if (Kp == 64 && Ca == 6 && Cn == 12) hipLaunchKernelGGL((fused_patch_embed96_kernel<64, 6, 12>), grid, block, 0, s, PE_ARGS);       // VG bits
     else if (Kp == 64 && Ca == 3 && Cn == 12) hipLaunchKernelGGL((fused_patch_embed96_kernel<64, 3, 12>), grid, block, 0, s, PE_ARGS);  // COCO bits
     else if (Kp == 32) hipLaunchKernelGGL((fused_patch_embed96_kernel<32>), grid, block, 0, s, PE_ARGS);
