@@ -842,7 +842,7 @@ void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStre
 // Row-kernel fusion (fp32 GEMM kernel only; off while debug taps want the un-modulated block outputs): the GEMM that produces
 // a block's input also applies that block's modulate+SiLU and leaves per-column-tile (sum, sumsq) partials of the stored rows
 // in w->stats, from which the consuming GEMM forms the LayerNorm statistics -- mod_stats / ln_stats launches disappear.
-bool rowstats_on(dsg_handle h) { return h->opt_fused_rowstats && !h->opt_gemm_bf16 && !h->opt_gemm_split && h->taps.empty(); }
+bool rowstats_on(dsg_handle h) { return h->opt_fused_rowstats && !h->opt_gemm_split && h->taps.empty(); }   // fp32 and bf16 GEMM kernels
 // does block `nb` take its input pre-modulated?  Generic blocks also read the LN1 partials the producer leaves; the C = 96 fused
 // attention kernel only skips its own modulate+SiLU (twice: prologue and shortcut) and keeps computing LN1 itself.
 bool wants_premod(dsg_handle h, const BlockPlan *nb) { return nb && rowstats_on(h); }
@@ -995,7 +995,7 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
             // block (no upsample there); otherwise PatchMerging, which takes the un-modulated tensor
             const BlockPlan *next = j + 1 < h->down[l].size() ? &h->down[l][j + 1] : (l == L - 1 && !h->up[0].empty() ? &h->up[0][0] : nullptr);
             // the level's last block leaves row statistics for the fused PatchMerging
-            const bool for_merge = !next && l < L - 1 && h->opt_fused_merge && rowstats_on(h) && C % 32 == 0;
+            const bool for_merge = !next && l < L - 1 && h->opt_fused_merge && rowstats_on(h) && !h->opt_gemm_bf16 && C % 32 == 0;
             const BlockOut bo = run_block(h, w, h->down[l][j], premod, next, for_merge, s);
             premod = bo.premod; merge_parts = bo.stats_parts;
             snprintf(name, sizeof(name), "down%d.block%d", l, (int)j);

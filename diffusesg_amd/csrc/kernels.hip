@@ -89,6 +89,28 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
                                        : make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
     const rsrc_t rsA2 = make_rsrc(g.A2 ? g.A2 + (size_t)m0 * g.lda2 : g.A, g.A2 ? (unsigned)rows_m * g.lda2 * 4u : 0u);
     const rsrc_t rsW = (EPI == 4) ? make_rsrc(g.W, (unsigned)(3 * g.wg.C) * g.K * 4u) : make_rsrc(g.W + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 4u);
+    // one row's partial (sum, sumsq) pairs [nparts][2], added in tile order; every load independent of the others, so a
+    // thread's rows cost one memory latency in the prologue
+    auto row_partials = [&](const float *pp, float &sm, float &sq) {
+        if (g.ln_nparts == 1) {
+            const float2 a = *reinterpret_cast<const float2 *>(pp);
+            sm = a.x; sq = a.y;
+        } else if (g.ln_nparts == 2) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(pp);
+            sm = a[0] + a[2]; sq = a[1] + a[3];
+        } else if (g.ln_nparts == 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(pp), b = *reinterpret_cast<const f32x4 *>(pp + 4);
+            sm = (a[0] + a[2]) + (b[0] + b[2]); sq = (a[1] + a[3]) + (b[1] + b[3]);
+        } else if (g.ln_nparts == 8) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(pp), b = *reinterpret_cast<const f32x4 *>(pp + 4),
+                        c = *reinterpret_cast<const f32x4 *>(pp + 8), d = *reinterpret_cast<const f32x4 *>(pp + 12);
+            sm = ((a[0] + a[2]) + (b[0] + b[2])) + ((c[0] + c[2]) + (d[0] + d[2]));
+            sq = ((a[1] + a[3]) + (b[1] + b[3])) + ((c[1] + c[3]) + (d[1] + d[3]));
+        } else {
+            sm = 0.f; sq = 0.f;
+            for (int t = 0; t < g.ln_nparts; t++) { sm += pp[2 * t]; sq += pp[2 * t + 1]; }
+        }
+    };
     unsigned voffA1[4], voffA2[4], voffW[3];
     unsigned voffA4[4][4];   // AMODE 1: [part][staging row]
     float a_rstd[4], a_nmr[4];
@@ -109,14 +131,14 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
             // statistics = the four rows' partial (sum, sumsq) pairs added in a fixed order
             const int m = min(m0 + r, g.M - 1), r2 = g.a4_res >> 1, T2 = r2 * r2;
             const int b = m / T2, t = m - b * T2, i = t / r2, j = t - i * r2;
-            float sm = 0.f, sq = 0.f;
+            float psm[4], psq[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int srow = b * g.a4_res * g.a4_res + (2 * i + (q & 1)) * g.a4_res + 2 * j + (q >> 1);
                 voffA4[q][p] = ((unsigned)srow * (unsigned)a4_C + 4u * c4) * 4u;
-                const float *pp = g.ln_part + (size_t)srow * g.ln_nparts * 2;
-                for (int tt = 0; tt < g.ln_nparts; tt++) { sm += pp[2 * tt]; sq += pp[2 * tt + 1]; }
+                row_partials(g.ln_part + (size_t)srow * g.ln_nparts * 2, psm[q], psq[q]);
             }
+            const float sm = (psm[0] + psm[1]) + (psm[2] + psm[3]), sq = (psq[0] + psq[1]) + (psq[2] + psq[3]);
             const float invk = 1.0f / (float)g.K;
             const float mean = sm * invk, rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);
             a_rstd[p] = rstd;
@@ -125,23 +147,8 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
             const int m = (EPI == 4) ? max(grow, 0) : min(m0 + r, g.M - 1);
             float mean, rstd;
             if (g.ln_part) {   // partial (sum, sumsq) per 96-column tile of the producer: [M][nparts][2], added in tile order
-                const float *pp = g.ln_part + (size_t)m * g.ln_nparts * 2;
                 float sm, sq;
-                if (g.ln_nparts == 2) {          // all loads of a row independent: one memory latency in the prologue
-                    const f32x4 a = *reinterpret_cast<const f32x4 *>(pp);
-                    sm = a[0] + a[2]; sq = a[1] + a[3];
-                } else if (g.ln_nparts == 4) {
-                    const f32x4 a = *reinterpret_cast<const f32x4 *>(pp), b = *reinterpret_cast<const f32x4 *>(pp + 4);
-                    sm = (a[0] + a[2]) + (b[0] + b[2]); sq = (a[1] + a[3]) + (b[1] + b[3]);
-                } else if (g.ln_nparts == 8) {
-                    const f32x4 a = *reinterpret_cast<const f32x4 *>(pp), b = *reinterpret_cast<const f32x4 *>(pp + 4),
-                                c = *reinterpret_cast<const f32x4 *>(pp + 8), d = *reinterpret_cast<const f32x4 *>(pp + 12);
-                    sm = ((a[0] + a[2]) + (b[0] + b[2])) + ((c[0] + c[2]) + (d[0] + d[2]));
-                    sq = ((a[1] + a[3]) + (b[1] + b[3])) + ((c[1] + c[3]) + (d[1] + d[3]));
-                } else {
-                    sm = 0.f; sq = 0.f;
-                    for (int t = 0; t < g.ln_nparts; t++) { sm += pp[2 * t]; sq += pp[2 * t + 1]; }
-                }
+                row_partials(g.ln_part + (size_t)m * g.ln_nparts * 2, sm, sq);
                 const float invk = 1.0f / (float)g.K;
                 mean = sm * invk;
                 rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);

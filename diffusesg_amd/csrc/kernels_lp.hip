@@ -40,7 +40,9 @@ __device__ __forceinline__ void split3_bits(float a, unsigned &h, unsigned &m, u
 }
 constexpr int HBK = 64, HLD = 72;  // k per chunk, LDS row stride in bf16 elements (144 B: 16-B aligned, conflict-free)
 
-template <bool LN, int ACT, bool RES>
+// EPI: the same epilogue extensions as gemm4_f32_kernel (kernels.hip): 1 row-statistics partials, 2 / 3 the next block's
+// modulate+SiLU (batch-uniform / per-sample) + partials; LN statistics may come from a producer's partials (g.ln_part).
+template <bool LN, int ACT, bool RES, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (GBM + GBN) * HLD];
     constexpr int BUF = (GBM + GBN) * HLD;
@@ -65,7 +67,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
         voffA2[p] = ((unsigned)r * g.lda2 + 4u * ca) * 4u;
         if (LN) {
             const int m = min(m0 + r, g.M - 1);
-            const float mean = g.ln_stats[2 * m], rstd = g.ln_stats[2 * m + 1];
+            float mean, rstd;
+            if (g.ln_part) {   // [M][nparts][2] partial (sum, sumsq) pairs of the producing GEMM, added in tile order
+                const float *pp = g.ln_part + (size_t)m * g.ln_nparts * 2;
+                float sm = 0.f, sq = 0.f;
+                if (g.ln_nparts == 2) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(pp);
+                    sm = a[0] + a[2]; sq = a[1] + a[3];
+                } else if (g.ln_nparts == 4) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(pp), b = *reinterpret_cast<const f32x4 *>(pp + 4);
+                    sm = (a[0] + a[2]) + (b[0] + b[2]); sq = (a[1] + a[3]) + (b[1] + b[3]);
+                } else {
+                    for (int t = 0; t < g.ln_nparts; t++) { sm += pp[2 * t]; sq += pp[2 * t + 1]; }
+                }
+                const float invk = 1.0f / (float)g.K;
+                mean = sm * invk;
+                rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);
+            } else {
+                mean = g.ln_stats[2 * m]; rstd = g.ln_stats[2 * m + 1];
+            }
             a_rstd[p] = rstd; a_nmr[p] = -mean * rstd;
         }
     }
@@ -141,6 +161,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
     const rsrc_t rsR = make_rsrc(RES ? g.res + (size_t)m0 * g.ldres : g.C, RES ? (unsigned)rows_m * g.ldres * 4u : 0u);
     const unsigned rowl = (unsigned)(wave * 32 + 4 * lhalf);
     const unsigned OOB = 0x7fffffffu;
+    float *ldsf = reinterpret_cast<float *>(lds);   // the K loop's tiles are dead after its last barrier
+    float st_s[16], st_q[16];
+    int brow[16];
+    if (EPI >= 1) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) { st_s[r] = 0.f; st_q[r] = 0.f; }
+    }
+    if (EPI == 3) {   // per-sample (scale,shift): row -> sample through a 128-entry LDS table
+        int *bt = reinterpret_cast<int *>(ldsf) + 4 * 2304;
+        if (tid < GBM) bt[tid] = min(m0 + tid, g.M - 1) / g.mod_T;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) brow[r] = bt[rowl + (r & 3) + 8 * (r >> 2)];
+    }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int n = n0 + 32 * j + lrow;
@@ -149,6 +183,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
         const unsigned vC = nok ? (rowl * g.ldc + (unsigned)n) * 4u : OOB;
         const unsigned vC2 = nok ? (rowl * g.ldc2 + (unsigned)n) * 4u : OOB;
         const unsigned vR = nok ? (rowl * g.ldres + (unsigned)n) * 4u : OOB;
+        float msc = 0.f, msh = 0.f;
+        if (EPI == 2 && nok) { msc = g.mod_aff[g.mod_off + n] + 1.0f; msh = g.mod_aff[g.mod_off + g.N + n]; }
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const unsigned rr = (unsigned)((r & 3) + 8 * (r >> 2));
@@ -156,9 +192,34 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
             if (ACT == ACT_GELU) v = gelu_f(v);
             else if (ACT == ACT_SILU) v = silu_exact(v);
             if (RES) v += buf_load1(rsR, vR, rr * g.ldres * 4u);
-            buf_store1(v, rsC, vC, rr * g.ldc * 4u);
             if (g.C2) buf_store1(v, rsC2, vC2, rr * g.ldc2 * 4u);
+            if (EPI == 3 && nok) {
+                const float *ar = g.mod_aff + (size_t)brow[r] * g.mod_ld + g.mod_off + n;
+                msc = ar[0] + 1.0f; msh = ar[g.N];
+            }
+            if (EPI >= 2) v = silu_exact(fmaf(v, msc, msh));
+            if (EPI >= 1 && nok) { st_s[r] += v; st_q[r] = fmaf(v, v, st_q[r]); }
+            buf_store1(v, rsC, vC, rr * g.ldc * 4u);
         }
+    }
+    if (EPI >= 1) {   // row statistics of the stored tile: per-wave LDS transpose, fixed-order sums (see gemm4_f32_kernel)
+        float *red = ldsf + wave * 2304;   // [2 quantities][32 rows][36]
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            red[row * GLD + lrow] = st_s[r];
+            red[(32 + row) * GLD + lrow] = st_q[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float *src = red + (lhalf * 32 + lrow) * GLD;
+        float tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4 *>(src + 4 * i);
+            tot += (q4[0] + q4[1]) + (q4[2] + q4[3]);
+        }
+        const rsrc_t rsP = make_rsrc(g.stats_out + (size_t)m0 * tiles_n * 2, (unsigned)(rows_m * tiles_n) * 8u);   // [M][tiles_n][2]
+        buf_store1(tot, rsP, (unsigned)(((wave * 32 + lrow) * tiles_n + tn) * 2 + lhalf) * 4u, 0u);
     }
 }
 
@@ -416,7 +477,18 @@ bool launch_gemm_lp(const GemmArgs &g_in, hipStream_t s) {
     const bool split = g.Ws3 != nullptr;
     const int tiles_m = (g.M + (split ? 256 : GBM) - 1) / (split ? 256 : GBM);
     const dim3 grid(round_up8(tiles_m) * tiles_n), block(256);
-    const bool ln = g.ln_stats != nullptr, res = g.res != nullptr;
+    const bool ln = g.ln_stats != nullptr || g.ln_part != nullptr, res = g.res != nullptr;
+    if (g.a4_res > 0 || g.attn_bias) return false;               // fp32-kernel-only features
+    if (split && (g.stats_out || g.ln_part)) return false;       // the split kernel has no epilogue extensions
+    if (g.stats_out) {
+        if (ln || g.act != ACT_NONE) return false;
+        const int epi = !g.mod_aff ? 1 : (g.mod_ld == 0 ? 2 : 3);
+#define LP_EPI(R, E) hipLaunchKernelGGL((gemm_bf16_kernel<false, ACT_NONE, R, E>), grid, block, 0, s, g, tiles_m, tiles_n)
+        if (res) { if (epi == 1) LP_EPI(true, 1); else if (epi == 2) LP_EPI(true, 2); else LP_EPI(true, 3); }
+        else { if (epi == 1) LP_EPI(false, 1); else if (epi == 2) LP_EPI(false, 2); else LP_EPI(false, 3); }
+#undef LP_EPI
+        return true;
+    }
 #define GEMM_CASE(L, A, R)                                                                                     \
     do {                                                                                                       \
         if (split) hipLaunchKernelGGL((gemm_split2_kernel<L, A, R, 4>), grid, block, 0, s, g, tiles_m, tiles_n); \

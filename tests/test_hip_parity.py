@@ -504,6 +504,13 @@ def test_bf16_gemm_mode_vs_reference(name, fused):
     assert ra_ <= BF16_RMS_RTOL and rn_ <= BF16_RMS_RTOL
     if not fused:
         assert max(ea, en) > 1e-5, "bf16 mode did not engage (error is at the fp32 level)"
+    # the bf16 kernel's own modulate / row-statistics epilogue (default on) against the row-kernel path in the same arithmetic:
+    # identical up to where a 1e-7 difference in a statistic flips a bf16 rounding
+    h.set_option("fused_rowstats", 0)
+    oa2, on2 = net(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
+    assert rms_rel(oa2.cpu().numpy(), oa.cpu().numpy()) <= 3e-3 and rms_rel(on2.cpu().numpy(), on.cpu().numpy()) <= 3e-3
+    assert_close(oa2.cpu().numpy(), g["sc_adj_out"], BF16_MAX_RTOL, f"{name} adj (bf16 GEMMs, row kernels)")
+    h.set_option("fused_rowstats", 1)
     h.set_option("gemm_bf16", 0)
     oa, on = net(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
     assert_close(oa.cpu().numpy(), g["sc_adj_out"], FWD_RTOL, f"{name} adj (back to fp32)")
