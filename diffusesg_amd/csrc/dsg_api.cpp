@@ -113,6 +113,7 @@ struct dsg_handle_s {
     std::map<int, std::unique_ptr<Workspace>> ws;
     // kernel-selection options (dsg_set_option); defaults may be overridden once by DSG_* environment variables
     bool opt_fused_attn = true, opt_fused_mlp = true, opt_fused_readout = true, opt_fused_pe = true;
+    bool opt_fused_merge_small = false;   // also fuse PatchMerging below the size where it pays (tests force it on)
     bool opt_fused_merge = true;      // PatchMerging: gather + LayerNorm(4C) inside the reduction GEMM's A path (no merge_ln kernel)
     bool opt_loop_graph = true;       // capture whole step bodies of the reverse loop (0: only the network forward is a graph)
     bool opt_fused_qkv_attn = true;   // QKV projection + 64-token window attention in one kernel (q, k, v never reach HBM)
@@ -995,7 +996,10 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
             // block (no upsample there); otherwise PatchMerging, which takes the un-modulated tensor
             const BlockPlan *next = j + 1 < h->down[l].size() ? &h->down[l][j + 1] : (l == L - 1 && !h->up[0].empty() ? &h->up[0][0] : nullptr);
             // the level's last block leaves row statistics for the fused PatchMerging
-            const bool for_merge = !next && l < L - 1 && h->opt_fused_merge && rowstats_on(h) && !h->opt_gemm_bf16 && C % 32 == 0;
+            // (below ~8k merged rows the reduction GEMM is a single partial wave of tiles and the gather + LayerNorm FMA in its
+            // long K loop costs more than the small merge_ln launch it replaces: measured 103 vs 81 + 13 us at M = 4096, K = 1536)
+            const bool for_merge = !next && l < L - 1 && h->opt_fused_merge && rowstats_on(h) && !h->opt_gemm_bf16 && C % 32 == 0 &&
+                                   (B * T / 4 >= 8192 || h->opt_fused_merge_small);
             const BlockOut bo = run_block(h, w, h->down[l][j], premod, next, for_merge, s);
             premod = bo.premod; merge_parts = bo.stats_parts;
             snprintf(name, sizeof(name), "down%d.block%d", l, (int)j);
@@ -1287,7 +1291,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "fused_rowstats") h->opt_fused_rowstats = value != 0;
     else if (n == "fused_qkv_attn") h->opt_fused_qkv_attn = value != 0;
     else if (n == "loop_graph") h->opt_loop_graph = value != 0;
-    else if (n == "fused_merge") h->opt_fused_merge = value != 0;
+    else if (n == "fused_merge") { h->opt_fused_merge = value != 0; h->opt_fused_merge_small = value > 1; }   // 2: at every size
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
         if (h->opt_gemm_bf16 && h->finalized) if (int rc = ensure_bf16_weights(h)) return rc;
@@ -1312,7 +1316,7 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "fused_rowstats") *value = h->opt_fused_rowstats;
     else if (n == "fused_qkv_attn") *value = h->opt_fused_qkv_attn;
     else if (n == "loop_graph") *value = h->opt_loop_graph;
-    else if (n == "fused_merge") *value = h->opt_fused_merge;
+    else if (n == "fused_merge") *value = h->opt_fused_merge ? (h->opt_fused_merge_small ? 2 : 1) : 0;
     else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
     else if (n == "gemm_split") *value = h->opt_gemm_split;
     else return fail(h, DSG_ERR_INVALID, "unknown option '%s'", name);

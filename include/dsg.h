@@ -144,7 +144,9 @@ int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t
  * fall back to the generic GEMM + attention + row-kernel path (all combinations are parity-tested):
  *   "fused_attn" (C=96 attention block), "fused_mlp", "fused_mlp_maxc" (96|192), "fused_readout", "fused_patch_embed",
  *   "fused_rowstats" (modulate+SiLU and LayerNorm statistics in the producing GEMM's epilogue instead of row kernels),
- *   "fused_qkv_attn" (C >= 192, 8x8 windows: QKV projection + window attention in one kernel, q/k/v never reach HBM).
+ *   "fused_qkv_attn" (8x8 / 10x10 windows: QKV projection + window attention in one kernel, q/k/v never reach HBM),
+ *   "fused_merge" (PatchMerging's 2x2 gather + LayerNorm(4C) inside the reduction GEMM's A path; 1: where it pays (>= 8192 merged
+ *   rows), 2: at every size, 0: merge_ln kernel).
  * Reverse loop: "loop_graph" = 1 (default): dsg_sample replays one captured hipGraph per step (a handful of distinct step bodies:
  *   first / steady / last step x the two self-conditioning coins); 0: the round-1 scheme, only the network forward is a graph.
  * Precision modes (default: exact fp32 MFMA everywhere):

@@ -380,6 +380,19 @@ def test_generic_path_matches_reference(name):
         assert_close(oa.cpu().numpy(), g["sc_adj_out"], FWD_RTOL, f"{name} adj (+{opt})")
         assert_close(on.cpu().numpy(), g["sc_node_out"], FWD_RTOL, f"{name} node (+{opt})")
         h.set_option(opt, 0)
+    # PatchMerging inside the reduction GEMM needs the row partials ("fused_rowstats"); 2 = also at these small sizes, where
+    # the library would not choose it by itself.  Once on the generic path, once with everything on.
+    h.set_option("fused_rowstats", 1)
+    h.set_option("fused_merge", 2)
+    assert h.get_option("fused_merge") == 2
+    oa, on = net(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
+    assert_close(oa.cpu().numpy(), g["sc_adj_out"], FWD_RTOL, f"{name} adj (generic + fused merge)")
+    assert_close(on.cpu().numpy(), g["sc_node_out"], FWD_RTOL, f"{name} node (generic + fused merge)")
+    for opt in ALL[:-1]:
+        h.set_option(opt, 1)
+    oa, on = net(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
+    assert_close(oa.cpu().numpy(), g["sc_adj_out"], FWD_RTOL, f"{name} adj (all fused, merge at every size)")
+    assert_close(on.cpu().numpy(), g["sc_node_out"], FWD_RTOL, f"{name} node (all fused, merge at every size)")
 
 
 @pytest.mark.parametrize("name,B", [("tiny", 1), ("tiny", 5), ("small", 3), ("nosc", 7)])
@@ -453,8 +466,9 @@ def test_vg_batch_independence_and_masking():
     assert torch.isfinite(oa).all() and torch.isfinite(on).all()
     sel = [5, 6, 63]
     oa2, on2 = net(T(adj[sel]), T(node[sel]), T(flags[sel]), T(c_noise[sel]), T(sc_adj[sel]), T(sc_node[sel]))
-    assert_close(oa2.cpu().numpy(), oa[sel].cpu().numpy(), 2e-6, "batch independence adj")
-    assert_close(on2.cpu().numpy(), on[sel].cpu().numpy(), 2e-6, "batch independence node")
+    # (2e-5, not bitwise: B = 64 takes the fused PatchMerging, B = 3 the merge_ln kernel -- same math, different summation)
+    assert_close(oa2.cpu().numpy(), oa[sel].cpu().numpy(), 2e-5, "batch independence adj")
+    assert_close(on2.cpu().numpy(), on[sel].cpu().numpy(), 2e-5, "batch independence node")
     f = torch.from_numpy(flags).cuda()
     assert torch.all(on[~f] == 0)
     assert torch.all(oa.permute(0, 2, 3, 1)[~f] == 0) and torch.all(oa.permute(0, 3, 2, 1)[~f] == 0)
@@ -582,7 +596,7 @@ def test_vg_full_batch_kernel_paths_agree_everywhere():
             h.set_option(opt, fused)
         h.set_option("fused_rowstats", rowstats)
         h.set_option("fused_qkv_attn", rowstats)
-        h.set_option("fused_merge", rowstats)
+        h.set_option("fused_merge", 2 * rowstats)   # 2: also at the sizes where it is not the default
         h.set_option("gemm_split", split)
         return [t.clone() for t in net(*args)]
 
@@ -798,8 +812,8 @@ def test_coco_batch512_properties():
     assert torch.all(on[~f] == 0) and torch.all(oa.permute(0, 2, 3, 1)[~f] == 0) and torch.all(oa.permute(0, 3, 2, 1)[~f] == 0)
     sel = [3, 200, 511]
     oa2, on2 = net(T(adj[sel]), T(node[sel]), T(flags[sel]), T(c_noise[sel]), T(sc_adj[sel]), T(sc_node[sel]))
-    assert_close(oa2.cpu().numpy(), oa[sel].cpu().numpy(), 2e-6, "coco B=512 batch independence adj")
-    assert_close(on2.cpu().numpy(), on[sel].cpu().numpy(), 2e-6, "coco B=512 batch independence node")
+    assert_close(oa2.cpu().numpy(), oa[sel].cpu().numpy(), 2e-5, "coco B=512 batch independence adj")
+    assert_close(on2.cpu().numpy(), on[sel].cpu().numpy(), 2e-5, "coco B=512 batch independence node")
     net._ensure_handle().set_option("gemm_bf16", 1)
     ba, bn = net(*args)
     sa_, sn_ = float(oa.abs().max()), float(on.abs().max())
