@@ -181,17 +181,30 @@ def worker(args):
         if not selftest:
             torch.cuda.synchronize(dev)
 
+    def progress(msg):   # stderr only: stdout carries exactly one JSON line
+        if rank == 0:
+            sys.stderr.write(f"[bench] {msg}\n")
+            sys.stderr.flush()
+
     for k in range(args.warmup):
         one_step(-1 - k, smp_warm)
     fence()
+    progress(f"{args.warmup} warm-up sample(s) done; timing {args.steps} step(s) of T={T}, B={B} per GPU, {world} GPU(s)")
     t0 = time.perf_counter()
     nfe = 0
     out = None
+    t_last = t0
     for k in range(args.steps):
         out, st = one_step(k, smp)
         nfe += st["net_forwards"]
+        # a progress line about once a minute (dsg_sample synchronises once at its start, so the host loop follows the GPU
+        # by at most one step); no extra synchronisation is added to the timed region for it
+        if time.perf_counter() - t_last > 45.0:
+            progress(f"step {k + 1}/{args.steps} enqueued after {time.perf_counter() - t0:.0f} s")
+            t_last = time.perf_counter()
     fence()
     elapsed = time.perf_counter() - t0
+    progress(f"timed region: {elapsed:.1f} s")
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -273,6 +286,7 @@ def worker(args):
         roofline["whole_path_frac"] = roofline["whole_path_tflops"] / PEAK_F32_MFMA_TFLOPS
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
+            progress(f"cpu_baseline: timing the oracle on the host cores for up to {args.cpu_budget_s:.0f} s")
             cpu = cpu_baseline(cfg, sd, T, valid, args.cpu_budget_s)
         # BASELINE.json's metric string for the configuration it is quoted on (VG shape: 30 valid nodes, T=1000); any other
         # workload is labelled plainly and described in config.workload
