@@ -12,6 +12,7 @@ from util import FWD_RTOL, assert_close, load, rel_err
 pytestmark = pytest.mark.gpu
 
 _nets = {}
+_oracle_cache = {}
 
 
 def net_for(name):
@@ -775,8 +776,9 @@ def test_coco_short_trajectory_vs_oracle(mode):
     T_ = 6
     flags, ia, inn, na, nn, cv = Y.sampler_case(cfg, T_, 2, [20, 40], 53, "coco/smp6")
     coins = (cv < 0.5).astype(np.uint8)
-    orc = Oracle(cfg, W.synth_state_dict(cfg, 0))
-    ra, rn = orc.sample(flags, ia, inn, na, nn, coins, num_steps=T_)
+    if "coco6" not in _oracle_cache:   # the fp32 oracle trajectory is the reference for both modes: compute it once (~100 s of CPU)
+        _oracle_cache["coco6"] = Oracle(cfg, W.synth_state_dict(cfg, 0)).sample(flags, ia, inn, na, nn, coins, num_steps=T_)
+    ra, rn = _oracle_cache["coco6"]
     net = net_for("coco") if mode == "f32" else build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")
     if mode == "bf16":
         net.model._ensure_handle().set_option("gemm_bf16", 1)
