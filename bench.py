@@ -50,6 +50,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="wall-clock bound of the cpu_baseline leg")
     ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="with --gpus 1: create the RCCL process group anyway (world size 1) so that the barrier, the float64 "
+                         "max-over-ranks all-reduce and both all-gathers (fp32 raw, int16-as-bytes decoded) run through RCCL on one GPU")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU rehearsal of the multi-rank plumbing (launcher, rank env, gloo process group, barrier, max-over-ranks "
                          "timing, packed all-gather) with a stand-in step; no GPU, no product kernels, the value is meaningless")
@@ -126,16 +129,23 @@ def worker(args):
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     selftest = args.selftest_launcher
+    use_pg = world > 1 or args.rehearse_collectives
+    if args.rehearse_collectives:
+        os.environ["DSG_FORCE_COLLECTIVE"] = "1"   # diffusesg_amd.dist.gather_results: run the all-gather even at world size 1
+    if use_pg and "MASTER_ADDR" not in os.environ:   # single-rank rehearsal started without torchrun
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     if selftest:
         dev = torch.device("cpu")
-        if world > 1:
+        if use_pg:
             dist.init_process_group(backend="gloo")
     else:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        if world > 1:
+        if use_pg:
             dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
-    world_seen = dist.get_world_size() if world > 1 else 1
+    world_seen = dist.get_world_size() if use_pg else 1
 
     cfg = synth.CONFIGS[args.config]()
     n = cfg.max_node_num
@@ -176,7 +186,7 @@ def worker(args):
             return dsg_dist.gather_results(packed), dict(sampler.last_stats)
 
     def fence():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         if not selftest:
             torch.cuda.synchronize(dev)
@@ -205,7 +215,7 @@ def worker(args):
     fence()
     elapsed = time.perf_counter() - t0
     progress(f"timed region: {elapsed:.1f} s")
-    if world > 1:
+    if use_pg:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -309,7 +319,7 @@ def worker(args):
                        "warmup_num_steps": max(1, min(T, args.warmup_num_steps)),
                        "net_forwards_per_step": nfe / args.steps, "gflop_per_forward_per_graph": f_fwd / 1e9,
                        "hip_graph": not args.no_graph, "precision_mode": mode,
-                       "parallelism": f"batch-sharded x{world}, one all-gather"},
+                       "parallelism": f"batch-sharded x{world}, one all-gather", "process_group": "nccl (RCCL)" if use_pg else None},
             "roofline": roofline, "cpu_baseline": cpu,
             "tail": {"what": "on-GPU decode of the bits samples + packed int16 all-gather + D2H of the decoded graphs (once per step)",
                      "ms": 1e3 * tail, "value_with_tail": graphs / (elapsed + args.steps * tail)},
@@ -317,7 +327,7 @@ def worker(args):
     if line is not None:
         sys.stdout.write(json.dumps(line) + "\n")
         sys.stdout.flush()           # the line is out before any teardown
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

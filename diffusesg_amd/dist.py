@@ -9,6 +9,7 @@ CPU tests) of a packed per-rank buffer.
 """
 from __future__ import annotations
 
+import os
 from typing import Tuple
 
 import torch
@@ -40,9 +41,17 @@ def unpack_results(packed: torch.Tensor, c_adj: int, n: int, c_node: int) -> Tup
 
 def gather_results(packed: torch.Tensor) -> torch.Tensor:
     """All ranks get [world*B, D] in rank order.  One collective; identity when not distributed."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return packed
+    if dist.get_world_size() == 1 and not os.environ.get("DSG_FORCE_COLLECTIVE"):   # (bench.py --rehearse-collectives sets it)
         return packed
     world = dist.get_world_size()
+    if packed.dtype in (torch.int16, torch.uint16):
+        # RCCL/NCCL have no 16-bit integer type (ncclDataType: 8/32/64-bit integers and floats only): move the same bytes as uint8
+        flat = packed.contiguous().view(torch.uint8)
+        out = torch.empty((world * flat.shape[0],) + tuple(flat.shape[1:]), dtype=torch.uint8, device=flat.device)
+        dist.all_gather_into_tensor(out, flat)
+        return out.view(packed.dtype)
     out = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(out, packed)
     return out

@@ -68,6 +68,16 @@ def _worker(rank, world, port, q):
         g = torch.Generator().manual_seed(ddist.rank_seed(1234, rank))
         adj, node = torch.randn(B, 3, 4, 4, generator=g), torch.randn(B, 4, 5, generator=g)
         out = ddist.gather_results(ddist.pack_results(adj, node))
+        # the decoded hand-off is int16, which RCCL cannot carry: gather_results moves it as bytes
+        from diffusesg_amd import io as dio
+        qa = torch.randint(0, 51, (B, 4, 4), generator=g, dtype=torch.int32)
+        qn = torch.randint(0, 150, (B, 4), generator=g, dtype=torch.int32)
+        fl = torch.ones(B, 4, dtype=torch.bool)
+        bb = torch.rand(B, 4, 4, generator=g)
+        dec = ddist.gather_results(dio.pack_decoded(qa, qn, bb, fl))
+        assert dec.dtype == torch.int16 and dec.shape[0] == world * B
+        a2, n2, f2, b2 = dio.unpack_decoded(dec[rank * B:(rank + 1) * B], 4, True)
+        assert torch.equal(a2, qa) and torch.equal(n2, qn) and torch.equal(b2, bb)
         q.put((rank, out.numpy(), adj.numpy(), node.numpy()))
     finally:
         dist.destroy_process_group()
