@@ -48,7 +48,7 @@ def parse_args(argv=None):
     ap.add_argument("--solver", default="heun", choices=["heun", "euler"], help="configs[2] variant 3b: --solver euler --s-churn 0")
     ap.add_argument("--s-churn", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0, help="wall-clock bound of the cpu_baseline leg")
+    ap.add_argument("--cpu-budget-s", type=float, default=40.0, help="wall-clock bound of the cpu_baseline leg")
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="with --gpus 1: create the RCCL process group anyway (world size 1) so that the barrier, the float64 "
