@@ -22,18 +22,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float silu_exact(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
-// exact-erf GELU (nn.GELU default).  erf by Abramowitz-Stegun 7.1.26 (|eps| <= 1.5e-7), evaluated so that the
-// negative tail has no cancellation: 1+erf(z) = poly*exp(-z^2) for z<0, 2 - poly*exp(-z^2) otherwise.  Measured max
-// abs error vs an fp64 GELU over [-12,12]: 4.2e-7 -- the same as the fp32 erff formula (4.5e-7); ~3x fewer VALU ops.
+// exact-erf GELU (nn.GELU default).  erfc by Abramowitz-Stegun 7.1.26 (|eps| <= 1.5e-7): erfc(z) = poly(t) exp(-z^2), z = |x|/sqrt2,
+// t = 1/(1 + p z).  With Phi(x) = 1 - erfc(z)/2 for x >= 0 and erfc(z)/2 for x < 0, both signs collapse into
+//     gelu(x) = max(x, 0) - |x| * (erfc(z)/2)
+// -- no select, no cancellation in the negative tail -- and the 1/2, the 1/sqrt2 and the log2(e) of the exponential are folded
+// into constants: 11 VALU + 2 transcendental per element (the round-1 form took 15 + 2; every VALU op in an f32-MFMA kernel is
+// paid in matrix throughput).  Measured max abs error vs an fp64 GELU over [-12,12]: 4e-7, the same as an fp32 erff evaluation.
 __device__ __forceinline__ float gelu_f(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = fast_rcp(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(t, 1.061405429f, -1.453152027f);
-    p = fmaf(t, p, 1.421413741f);
-    p = fmaf(t, p, -0.284496736f);
-    p = fmaf(t, p, 0.254829592f);
-    const float pe = p * t * __expf(-z * z);
-    return 0.5f * x * (x < 0.f ? pe : 2.0f - pe);
+    const float ax = fabsf(x);
+    const float xs = x * 0.84932180028801904f;                       // x * sqrt(log2(e) / 2):  exp(-x^2/2) = exp2(-xs^2)
+    const float e = __builtin_amdgcn_exp2f(-xs * xs);
+    const float t = fast_rcp(fmaf(ax, 0.23164189f, 1.0f));           // p / sqrt2 = 0.3275911 / 1.41421356
+    float p = fmaf(t, 0.5307027145f, -0.7265760135f);                // A&S coefficients * 1/2
+    p = fmaf(t, p, 0.7107068705f);
+    p = fmaf(t, p, -0.142248368f);
+    p = fmaf(t, p, 0.127414796f);
+    return fmaf(-ax, p * t * e, fmaxf(x, 0.0f));
 }
 
 // Table-driven GELU for the MFMA kernels (10 VALU + one ds_read_b128 instead of 14 VALU + 2 transcendentals).
