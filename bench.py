@@ -266,6 +266,7 @@ def worker(args):
         gemm_avg_ms = ms[0] / cnt[0]
         gemm_avg_ms_inkernel = gemm_ms.value / cnt[0]
         achieved = (fl[0] / cnt[0]) / (gemm_avg_ms * 1e-3) / 1e12
+        clock_ghz = float(h.L.dsg_profile_clock_ghz(h.raw))   # shader clock held during those GEMM launches (in-kernel stamps)
         kinds = ["gemm", "window_attn", "row", "elementwise", "fused_blocks"]
         breakdown = {kinds[i]: {"ms_per_forward": ms[i] / iters, "launches_per_forward": cnt[i] // iters,
                                 "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12) if fl[i] > 0 and ms[i] > 0 else None} for i in range(5)}
@@ -290,6 +291,8 @@ def worker(args):
                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": gemm_avg_ms, "avg_launch_ms_inkernel": gemm_avg_ms_inkernel,
                     "flops_per_launch": fl[0] / cnt[0], "launches_per_forward": cnt[0] // iters,
+                    "held_clock_ghz": clock_ghz if mode == "f32" else None,
+                    "clock_limited_peak": (clock_ghz * 1024 * 64 / 1e3) if (mode == "f32" and clock_ghz > 0) else None,
                     "forward_breakdown": breakdown}
         # whole-path achieved rate: graphs/s/GPU x forwards per graph x FLOPs per forward
         roofline["whole_path_tflops"] = nfe * B * f_fwd / elapsed / 1e12

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -141,6 +142,7 @@ struct dsg_handle_s {
     // in-kernel stamps of the dominant kernel (GEMM): one {start,end} pair per launch
     unsigned long long *prof_gemm = nullptr;
     int prof_gemm_cap = 0, prof_gemm_used = 0;
+    double prof_clock_ghz = 0.0;   // median over the GEMM launches of the last dsg_profile_forward: shader clock held by block 0
 };
 
 namespace {
@@ -835,7 +837,7 @@ void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStre
 // "gemm_split" (fp32-accurate split-bf16 products) applies to every GEMM and takes precedence over "gemm_bf16".
 #define P_GEMM_LP(g) do { (g).Ws3 = split_of(h, (g).W); (g).Wb = (g).Ws3 ? nullptr : bf16_of(h, (g).W); P_GEMM_(g); } while (0)
 #define P_GEMM(g) do { (g).Ws3 = split_of(h, (g).W); (g).Wb = nullptr; P_GEMM_(g); } while (0)
-#define P_GEMM_(g) do { char tg_[96]; if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) (g).prof = h->prof_gemm + 2 * (h->prof_gemm_used++); else (g).prof = nullptr; \
+#define P_GEMM_(g) do { char tg_[96]; if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) (g).prof = h->prof_gemm + 4 * (h->prof_gemm_used++); else (g).prof = nullptr; \
     if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm M=%d N=%d K=%d ln=%d act=%d res=%d", (g).M, (g).N, (g).K, ((g).ln_stats != nullptr) + 2 * ((g).ln_part != nullptr) + 4 * ((g).stats_out != nullptr) + 8 * ((g).mod_aff != nullptr), (g).act, (g).res != nullptr); \
     ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)(g).M * (double)(g).N * (double)(g).K, tg_); launch_gemm((g), s); } while (0)
 #define P_KERN(kind, flops, call) do { ProfScope ps_(h, s, (kind), (flops), #call); call; } while (0)
@@ -885,7 +887,7 @@ BlockOut run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, 
             // LN1 -> QKV -> softmax(q k^T + bias) v in one kernel: q, k, v of (two windows, one head) stay in LDS
             g.attn_bias = b.biasT; g.wg = wg; g.attn_batch = B; g.C = w->att; g.ldc = C;
             char tg_[96];
-            if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) g.prof = h->prof_gemm + 2 * (h->prof_gemm_used++);
+            if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) g.prof = h->prof_gemm + 4 * (h->prof_gemm_used++);
             if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm+attn M=%d N=%d K=%d ln=%d heads=%d", g.M, g.N, g.K, g.ln_part ? 2 : 1, b.heads);
             ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)M * 3.0 * C * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, tg_);
             attn_done = launch_gemm_qkv_attn(g, s);
@@ -1523,13 +1525,14 @@ int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_
     for (int k = 0; k < PK_COUNT; k++) { ms_by_kind[k] = 0.0; launches_by_kind[k] = 0; flops_by_kind[k] = 0.0; }
     if (!h->prof_gemm) {
         h->prof_gemm_cap = 512;
-        HIP_TRY(h, hipMalloc((void **)&h->prof_gemm, sizeof(unsigned long long) * 2 * h->prof_gemm_cap));
+        HIP_TRY(h, hipMalloc((void **)&h->prof_gemm, sizeof(unsigned long long) * 4 * h->prof_gemm_cap));
     }
-    std::vector<unsigned long long> stamps(2 * h->prof_gemm_cap);
+    std::vector<unsigned long long> stamps(4 * h->prof_gemm_cap);   // per launch: {min start, max end, block-0 shader cycles, block-0 ticks}
+    std::vector<double> clocks;
     double gemm_inkernel_ms = 0.0;
     // pass A: in-kernel stamps only -- the launches run back to back exactly as in the sampler loop
     for (int iter = 0; iter < n_iters; iter++) {
-        for (int i = 0; i < h->prof_gemm_cap; i++) { stamps[2 * i] = ~0ull; stamps[2 * i + 1] = 0ull; }
+        for (int i = 0; i < h->prof_gemm_cap; i++) { stamps[4 * i] = ~0ull; stamps[4 * i + 1] = 0ull; stamps[4 * i + 2] = 0ull; stamps[4 * i + 3] = 0ull; }
         HIP_TRY(h, hipMemcpyAsync(h->prof_gemm, stamps.data(), sizeof(unsigned long long) * stamps.size(), hipMemcpyHostToDevice, s));
         h->prof_gemm_used = 0;
         h->prof_stamps = true;
@@ -1537,9 +1540,13 @@ int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_
         h->prof_stamps = false;
         HIP_TRY(h, hipStreamSynchronize(s));
         HIP_TRY(h, hipMemcpy(stamps.data(), h->prof_gemm, sizeof(unsigned long long) * stamps.size(), hipMemcpyDeviceToHost));
-        for (int i = 0; i < h->prof_gemm_used; i++)
-            if (stamps[2 * i + 1] > stamps[2 * i]) gemm_inkernel_ms += (double)(stamps[2 * i + 1] - stamps[2 * i]) * 1e-5;  // 100 MHz ticks
+        for (int i = 0; i < h->prof_gemm_used; i++) {
+            if (stamps[4 * i + 1] > stamps[4 * i]) gemm_inkernel_ms += (double)(stamps[4 * i + 1] - stamps[4 * i]) * 1e-5;  // 100 MHz ticks
+            if (stamps[4 * i + 3] > 200) clocks.push_back((double)stamps[4 * i + 2] / (double)stamps[4 * i + 3] * 0.1);   // GHz, blocks > 2 us
+        }
     }
+    std::sort(clocks.begin(), clocks.end());
+    h->prof_clock_ghz = clocks.empty() ? 0.0 : clocks[clocks.size() / 2];
     // pass B: HIP-event brackets around every launch (per-class breakdown; each bracket includes dispatch latency)
     for (int iter = 0; iter < n_iters; iter++) {
         h->prof_on = true; h->prof_used = 0; h->prof_kind.clear(); h->prof_flops.clear(); h->prof_tag.clear();
@@ -1604,6 +1611,8 @@ int dsg_rainbow_loss(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const 
                         node_loss_weight, iou_loss_weight, out_loss_adj, out_loss_node, Dims{B, N, c_adj, c_node}, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? DSG_OK : DSG_ERR_HIP;
 }
+
+double dsg_profile_clock_ghz(dsg_handle h) { return h ? h->prof_clock_ghz : 0.0; }
 
 int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, int32_t n_adj_type,
                     int32_t n_node_type, int32_t node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, void *stream) {

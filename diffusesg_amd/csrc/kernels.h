@@ -124,18 +124,9 @@ void launch_precond_in(CStatePtrs x, const float *sigmas, StatePtrs in, float *c
 // D = mask(c_skip*x + c_out*F); optionally stored to a second destination
 void launch_precond_out(CStatePtrs x, CStatePtrs F, const float *sigmas, const uint8_t *flags, StatePtrs D, StatePtrs D2,
                         Dims d, hipStream_t s);
-// x_hat = mask(x + coef*eps); eps from `noise` (if non-null) or Philox(seed, step)
-void launch_churn(CStatePtrs x, CStatePtrs noise, float coef, uint64_t seed, uint32_t step, const uint8_t *flags,
-                  StatePtrs xhat, Dims d, hipStream_t s);
 // x0 = mask(eps) * scale (gen_init_sample + initial scaling); eps from `init` or Philox(seed, stream): stream 0 is the
 // initial sample, stream i+1 the churn noise of step i (launch_churn)
 void launch_init(CStatePtrs init, float scale, uint64_t seed, uint32_t stream, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s);
-// Euler: x = mask(xhat + h*mask(inv*xhat - inv*D))
-void launch_euler(CStatePtrs xhat, CStatePtrs D, float inv_t, float h, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s);
-// Heun: d=mask(inv*xhat-inv*D1); xp=xhat+h*d; dp=invp*xp-invp*D2; x=mask(xhat+h*(0.5d+0.5dp))
-void launch_heun(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, float inv_t, float inv_tp, float h, const uint8_t *flags,
-                 StatePtrs x, Dims d, hipStream_t s);
-void launch_fill_f32(float *p, float v, int64_t n, hipStream_t s);
 
 // ---- reverse-loop kernels driven by a DEVICE step counter, so that one captured step body can be replayed for every step ----
 // Per-step scalars, computed on the host up front exactly as before (dsg_sigma_schedule) and uploaded once per sample() call.

@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     const int c4 = tid & 7, r0 = tid >> 3;
     const int rows_m = min(GBM, g.M - m0), rows_n = min(GBN, g.N - n0);
     // measurement mode (dsg_profile_forward): first-block-start / last-block-end on the 100 MHz constant clock
-    unsigned long long prof_t0 = 0;
-    if (g.prof && tid == 0) prof_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long prof_t0 = 0, prof_c0 = 0;   // 100 MHz constant clock / shader clock (block 0 only: the held clock)
+    if (g.prof && tid == 0) { prof_t0 = __builtin_amdgcn_s_memrealtime(); if (bid == 0) prof_c0 = __builtin_amdgcn_s_memtime(); }
 
     // EPI == 4: tile row r -> token row of the activation: window WPT*tm + r/Wp, position r%Wp inside the (shifted) window
     constexpr int A_WT = WS * WS, A_WP = (A_WT + 31) / 32 * 32, A_KT = A_WP / 32, A_WPT = GBM / A_WP;   // 64/64/2/2 or 100/128/4/1
@@ -365,8 +365,10 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
         }
         if (g.prof && tid == 0) {
             __builtin_amdgcn_s_waitcnt(0);
+            const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
             atomicMin(g.prof, prof_t0);
-            atomicMax(g.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+            atomicMax(g.prof + 1, t1);
+            if (bid == 0) { g.prof[2] = __builtin_amdgcn_s_memtime() - prof_c0; g.prof[3] = t1 - prof_t0; }
         }
         return;
     }
@@ -457,8 +459,11 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
 #endif
     if (g.prof && tid == 0) {
         __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have been issued and acknowledged
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
         atomicMin(g.prof, prof_t0);
-        atomicMax(g.prof + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
+        atomicMax(g.prof + 1, t1);
+        // block 0's lifetime on both clocks: shader cycles / 100 MHz ticks = the clock the chip holds under this load
+        if (bid == 0) { g.prof[2] = __builtin_amdgcn_s_memtime() - prof_c0; g.prof[3] = t1 - prof_t0; }
     }
 }
 static float *g_gelu_tab_dev = nullptr;
@@ -1724,24 +1729,6 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint32_t stream, u
     return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
-__global__ void churn_kernel(CStatePtrs x, CStatePtrs noise, float coef, uint64_t seed, uint32_t step, const uint8_t *flags,
-                             StatePtrs xhat, Dims d) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total_elems(d)) return;
-    const ElemIdx e = elem_index(idx, d, flags);
-    const float xv = e.is_adj ? x.adj[e.off] : x.node[e.off];
-    float eps;
-    if (noise.adj) eps = e.is_adj ? noise.adj[e.off] : noise.node[e.off];
-    else eps = (coef != 0.f && e.valid) ? philox_normal(seed, step + 1u, idx) : 0.f;
-    const float v = e.valid ? FADD(xv, FMUL(coef, eps)) : 0.f;  // edm.py:361-366
-    if (e.is_adj) xhat.adj[e.off] = v; else xhat.node[e.off] = v;
-}
-void launch_churn(CStatePtrs x, CStatePtrs noise, float coef, uint64_t seed, uint32_t step, const uint8_t *flags,
-                  StatePtrs xhat, Dims d, hipStream_t s) {
-    const size_t n = total_elems(d);
-    hipLaunchKernelGGL(churn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, noise, coef, seed, step, flags, xhat, d);
-}
-
 __global__ void init_kernel(CStatePtrs init, float scale, uint64_t seed, uint32_t stream, const uint8_t *flags, StatePtrs x, Dims d) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total_elems(d)) return;
@@ -1757,43 +1744,7 @@ void launch_init(CStatePtrs init, float scale, uint64_t seed, uint32_t stream, c
     hipLaunchKernelGGL(init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, init, scale, seed, stream, flags, x, d);
 }
 
-__global__ void euler_kernel(CStatePtrs xhat, CStatePtrs D, float inv_t, float h, const uint8_t *flags, StatePtrs x, Dims d) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total_elems(d)) return;
-    const ElemIdx e = elem_index(idx, d, flags);
-    const float xh = e.is_adj ? xhat.adj[e.off] : xhat.node[e.off];
-    const float dn = e.is_adj ? D.adj[e.off] : D.node[e.off];
-    const float dc = FSUB(FMUL(inv_t, xh), FMUL(inv_t, dn));     // edm.py:384-385
-    const float v = e.valid ? FADD(xh, FMUL(h, dc)) : 0.f;       // edm.py:395-396, :421-422
-    if (e.is_adj) x.adj[e.off] = v; else x.node[e.off] = v;
-}
-void launch_euler(CStatePtrs xhat, CStatePtrs D, float inv_t, float h, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s) {
-    const size_t n = total_elems(d);
-    hipLaunchKernelGGL(euler_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xhat, D, inv_t, h, flags, x, d);
-}
-
-__global__ void heun_kernel(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, float inv_t, float inv_tp, float h,
-                            const uint8_t *flags, StatePtrs x, Dims d) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total_elems(d)) return;
-    const ElemIdx e = elem_index(idx, d, flags);
-    const float xh = e.is_adj ? xhat.adj[e.off] : xhat.node[e.off];
-    const float d1 = e.is_adj ? D1.adj[e.off] : D1.node[e.off];
-    const float d2 = e.is_adj ? D2.adj[e.off] : D2.node[e.off];
-    const float dc = FSUB(FMUL(inv_t, xh), FMUL(inv_t, d1));            // edm.py:384-385
-    const float xp = FADD(xh, FMUL(h, dc));                             // edm.py:389-390 (alpha = 1)
-    const float dp = FSUB(FMUL(inv_tp, xp), FMUL(inv_tp, d2));          // edm.py:414-417
-    const float avg = FADD(FMUL(0.5f, dc), FMUL(0.5f, dp));
-    const float v = e.valid ? FADD(xh, FMUL(h, avg)) : 0.f;             // edm.py:418-422
-    if (e.is_adj) x.adj[e.off] = v; else x.node[e.off] = v;
-}
-void launch_heun(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, float inv_t, float inv_tp, float h, const uint8_t *flags,
-                 StatePtrs x, Dims d, hipStream_t s) {
-    const size_t n = total_elems(d);
-    hipLaunchKernelGGL(heun_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xhat, D1, D2, inv_t, inv_tp, h, flags, x, d);
-}
-
-// ---- table-driven variants: identical arithmetic, scalars from StepRow[ctl->step] (one captured step body serves every step) ----
+// ---- reverse-loop kernels: scalars from StepRow[ctl->step] (one captured step body serves every step; edm.py:355-427) ----
 __global__ void churn_tab_kernel(CStatePtrs x, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs xhat, Dims d) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total_elems(d)) return;
@@ -1892,14 +1843,6 @@ void launch_step_row(const float *table, int n, const RunCtl *ctl, float *dst, h
 }
 __global__ void step_advance_kernel(RunCtl *ctl) { ctl->step += 1; }
 void launch_step_advance(RunCtl *ctl, hipStream_t s) { hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, ctl); }
-
-__global__ void fill_kernel(float *p, float v, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-void launch_fill_f32(float *p, float v, int64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, v, n);
-}
 
 // Training-time objective (forward): R/runner/objectives/edm.py:160-180 (sigma ~ exp(N(P_mean, P_std)), loss weight) and
 // :239-281 / graph_utils.add_sym_normal_noise with non_symmetric=True (noisy inputs).  Op-by-op fp32 rounding like torch.

@@ -171,6 +171,11 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value);
 int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_kind, int64_t *launches_by_kind,
                         double *flops_by_kind, double *gemm_inkernel_ms, void *stream);
 
+/* The shader clock the chip held during the GEMM launches of the last dsg_profile_forward call, in GHz: median over the launches of
+ * (block 0's lifetime in s_memtime shader cycles) / (the same lifetime in 100 MHz s_memrealtime ticks).  Dense f32-MFMA streams are
+ * power-limited on MI355X: the clock-limited ceiling of a perfect kernel is this clock x 1024 SIMDs x 64 FLOP/clk, not 157.3 TFLOP/s. */
+double dsg_profile_clock_ghz(dsg_handle h);
+
 /* Debug: copy the named stage's activation (e.g. "down0.block0") of the next dsg_denoise call to
  * `dst` (device, capacity in floats).  Token-major [B, T, C]. */
 int dsg_debug_tap(dsg_handle h, const char *stage, float *dst, int64_t capacity);
