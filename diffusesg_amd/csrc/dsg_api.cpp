@@ -1543,6 +1543,9 @@ int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_
         for (int i = 0; i < h->prof_gemm_used; i++) {
             if (stamps[4 * i + 1] > stamps[4 * i]) gemm_inkernel_ms += (double)(stamps[4 * i + 1] - stamps[4 * i]) * 1e-5;  // 100 MHz ticks
             if (stamps[4 * i + 3] > 200) clocks.push_back((double)stamps[4 * i + 2] / (double)stamps[4 * i + 3] * 0.1);   // GHz, blocks > 2 us
+            if (iter == n_iters - 1 && getenv("DSG_PROFILE_VERBOSE") && stamps[4 * i + 3] > 0)
+                fprintf(stderr, "[dsg-clock] gemm launch %2d: block 0 held %.3f GHz over %.1f us\n", i,
+                        (double)stamps[4 * i + 2] / (double)stamps[4 * i + 3] * 0.1, (double)stamps[4 * i + 3] * 0.01);
         }
     }
     std::sort(clocks.begin(), clocks.end());

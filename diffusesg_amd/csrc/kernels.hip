@@ -116,49 +116,65 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     float a_rstd[4], a_nmr[4];
     int my_tok = -1;   // EPI == 4: token row of tile row `tid` (threads 0..127), for the output scatter
     if (EPI == 4 && tid < GBM) my_tok = win_row(tid);
+    int a_grow[4];   // EPI == 4: token row of staging row p; AMODE 1: its first fine row
 #pragma unroll
     for (int p = 0; p < 4; p++) {
         const int r = r0 + 32 * p;
         voffA1[p] = ((unsigned)r * g.lda + 4u * c4) * 4u;
         voffA2[p] = ((unsigned)r * g.lda2 + 4u * c4) * 4u;
-        int grow = 0;
+        a_grow[p] = 0;
         if (EPI == 4) {
-            grow = win_row(r);
-            voffA1[p] = grow >= 0 ? ((unsigned)grow * g.lda + 4u * c4) * 4u : 0x7fffffffu;
+            a_grow[p] = win_row(r);
+            voffA1[p] = a_grow[p] >= 0 ? ((unsigned)a_grow[p] * g.lda + 4u * c4) * 4u : 0x7fffffffu;
         }
         if (AMODE == 1) {
-            // coarse row -> its four fine rows (order x00, x10, x01, x11: part q has di = q&1, dj = q>>1); LayerNorm(4C)
-            // statistics = the four rows' partial (sum, sumsq) pairs added in a fixed order
+            // coarse row -> its four fine rows (order x00, x10, x01, x11: part q has di = q&1, dj = q>>1)
             const int m = min(m0 + r, g.M - 1), r2 = g.a4_res >> 1, T2 = r2 * r2;
             const int b = m / T2, t = m - b * T2, i = t / r2, j = t - i * r2;
-            float psm[4], psq[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int srow = b * g.a4_res * g.a4_res + (2 * i + (q & 1)) * g.a4_res + 2 * j + (q >> 1);
                 voffA4[q][p] = ((unsigned)srow * (unsigned)a4_C + 4u * c4) * 4u;
-                row_partials(g.ln_part + (size_t)srow * g.ln_nparts * 2, psm[q], psq[q]);
             }
-            const float sm = (psm[0] + psm[1]) + (psm[2] + psm[3]), sq = (psq[0] + psq[1]) + (psq[2] + psq[3]);
-            const float invk = 1.0f / (float)g.K;
-            const float mean = sm * invk, rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);
-            a_rstd[p] = rstd;
-            a_nmr[p] = -mean * rstd;
-        } else if (LN) {
-            const int m = (EPI == 4) ? max(grow, 0) : min(m0 + r, g.M - 1);
-            float mean, rstd;
-            if (g.ln_part) {   // partial (sum, sumsq) per 96-column tile of the producer: [M][nparts][2], added in tile order
-                float sm, sq;
-                row_partials(g.ln_part + (size_t)m * g.ln_nparts * 2, sm, sq);
-                const float invk = 1.0f / (float)g.K;
-                mean = sm * invk;
-                rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);
-            } else {
-                mean = g.ln_stats[2 * m]; rstd = g.ln_stats[2 * m + 1];
-            }
-            a_rstd[p] = rstd;
-            a_nmr[p] = -mean * rstd;
+            a_grow[p] = b * g.a4_res * g.a4_res + 2 * i * g.a4_res + 2 * j;   // fine row of part 0
         }
     }
+    // LayerNorm statistics of the staging rows.  (Issuing the first two chunks' tile loads before these loads -- one memory
+    // latency in the prologue instead of two -- measured 0.15 % slower in the in-box A/B, tools/ab_libs.sh.)
+    auto load_row_stats = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const int r = r0 + 32 * p;
+            if (AMODE == 1) {
+                // LayerNorm(4C) statistics = the four fine rows' partial (sum, sumsq) pairs added in a fixed order
+                float psm[4], psq[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int srow = a_grow[p] + (q & 1) * g.a4_res + (q >> 1);
+                    row_partials(g.ln_part + (size_t)srow * g.ln_nparts * 2, psm[q], psq[q]);
+                }
+                const float sm = (psm[0] + psm[1]) + (psm[2] + psm[3]), sq = (psq[0] + psq[1]) + (psq[2] + psq[3]);
+                const float invk = 1.0f / (float)g.K;
+                const float mean = sm * invk, rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);
+                a_rstd[p] = rstd;
+                a_nmr[p] = -mean * rstd;
+            } else if (LN) {
+                const int m = (EPI == 4) ? max(a_grow[p], 0) : min(m0 + r, g.M - 1);
+                float mean, rstd;
+                if (g.ln_part) {   // partial (sum, sumsq) per 96-column tile of the producer: [M][nparts][2], added in tile order
+                    float sm, sq;
+                    row_partials(g.ln_part + (size_t)m * g.ln_nparts * 2, sm, sq);
+                    const float invk = 1.0f / (float)g.K;
+                    mean = sm * invk;
+                    rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);
+                } else {
+                    mean = g.ln_stats[2 * m]; rstd = g.ln_stats[2 * m + 1];
+                }
+                a_rstd[p] = rstd;
+                a_nmr[p] = -mean * rstd;
+            }
+        }
+    };
 #pragma unroll
     for (int p = 0; p < 3; p++) {
         voffW[p] = ((unsigned)(r0 + 32 * p) * g.K + 4u * c4) * 4u;
@@ -263,6 +279,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
         mfma12(f1);                                                                                    \
     } while (0)
 
+    load_row_stats();
     issue(s0, 0);
     write(s0, 0);
     issue(s1, 1);
@@ -408,22 +425,37 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
 #pragma unroll
             for (int r = 0; r < 16; r++) rres[r] = buf_load1(rsR, vR, (unsigned)((r & 3) + 8 * (r >> 2)) * g.ldres * 4u);
         }
+        // phase by phase over the 16 rows of this 32-column slab, not row by row: the block-uniform `if (g.C2)` would otherwise
+        // cut the loop into 16 basic blocks, each one serial dependency chain (bias -> activation -> store) that the
+        // scheduler cannot interleave with its neighbours
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const unsigned rr = (unsigned)((r & 3) + 8 * (r >> 2));
-            float v = acc[j][r] + bias;
-            if (ACT == ACT_GELU) v = gelu_f(v);
-            else if (ACT == ACT_SILU) v = silu_exact(v);
-            if (RES) v += rres[r];
-            if (g.C2) buf_store1(v, rsC2, vC2, rr * g.ldc2 * 4u);
-            if (EPI == 3 && nok) {
-                const float *ar = g.mod_aff + (size_t)brow[r] * g.mod_ld + g.mod_off + n;
-                msc = ar[0] + 1.0f; msh = ar[g.N];
-            }
-            if (EPI >= 2) v = silu_exact(fmaf(v, msc, msh));
-            if (EPI >= 1 && nok) { st_s[r] += v; st_q[r] = fmaf(v, v, st_q[r]); }
-            buf_store1(v, rsC, vC, rr * g.ldc * 4u);
+            v[r] = acc[j][r] + bias;
+            if (ACT == ACT_GELU) v[r] = gelu_f(v[r]);
+            else if (ACT == ACT_SILU) v[r] = silu_exact(v[r]);
+            if (RES) v[r] += rres[r];
         }
+        if (g.C2) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) buf_store1(v[r], rsC2, vC2, (unsigned)((r & 3) + 8 * (r >> 2)) * g.ldc2 * 4u);
+        }
+        if (EPI >= 2) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (EPI == 3 && nok) {
+                    const float *ar = g.mod_aff + (size_t)brow[r] * g.mod_ld + g.mod_off + n;
+                    msc = ar[0] + 1.0f; msh = ar[g.N];
+                }
+                v[r] = silu_exact(fmaf(v[r], msc, msh));
+            }
+        }
+        if (EPI >= 1 && nok) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) { st_s[r] += v[r]; st_q[r] = fmaf(v[r], v[r], st_q[r]); }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) buf_store1(v[r], rsC, vC, (unsigned)((r & 3) + 8 * (r >> 2)) * g.ldc * 4u);
     }
     if (EPI >= 1) {
         // Row statistics of the stored tile.  A row's 96 values sit in the 32 lanes of a half-wave: transpose through a

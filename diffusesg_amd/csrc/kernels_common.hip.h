@@ -22,22 +22,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float silu_exact(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
-// exact-erf GELU (nn.GELU default).  erfc by Abramowitz-Stegun 7.1.26 (|eps| <= 1.5e-7): erfc(z) = poly(t) exp(-z^2), z = |x|/sqrt2,
-// t = 1/(1 + p z).  With Phi(x) = 1 - erfc(z)/2 for x >= 0 and erfc(z)/2 for x < 0, both signs collapse into
-//     gelu(x) = max(x, 0) - |x| * (erfc(z)/2)
-// -- no select, no cancellation in the negative tail -- and the 1/2, the 1/sqrt2 and the log2(e) of the exponential are folded
-// into constants: 11 VALU + 2 transcendental per element (the round-1 form took 15 + 2; every VALU op in an f32-MFMA kernel is
-// paid in matrix throughput).  Measured max abs error vs an fp64 GELU over [-12,12]: 4e-7, the same as an fp32 erff evaluation.
+// exact-erf GELU (nn.GELU default).  With Phi(x) = 1 - Phi(-|x|) for x >= 0 and Phi(-|x|) for x < 0 both signs collapse into
+//     gelu(x) = max(x, 0) - |x| * Phi(-|x|)
+// -- no select, no cancellation in the negative tail.  log2 Phi(-a) is smooth on [0, 6] (-1 at 0, ~ -a^2/2 log2e - log2(a sqrt(2 pi))
+// beyond); a degree-6 polynomial fitted to it under the weight a*Phi(-a) (the absolute error of the subtracted term; fit by
+// tools/fit_gelu.py) gives the term to 5e-8 in exact arithmetic, and above a = 6 it is < 6e-9 * a/6 whatever the exponent says, so
+// a is clamped there.  9 VALU + 1 transcendental per element (round 2's first form, A&S 7.1.26 with a reciprocal: 12 + 2 and
+// constant moves; every VALU op in an f32-MFMA kernel is paid in matrix throughput and v_exp/v_rcp issue at quarter rate).
+// Measured max abs error vs an fp64 GELU over [-12,12]: 2.8e-7 (an fp32 erff evaluation: 4e-7).
 __device__ __forceinline__ float gelu_f(float x) {
-    const float ax = fabsf(x);
-    const float xs = x * 0.84932180028801904f;                       // x * sqrt(log2(e) / 2):  exp(-x^2/2) = exp2(-xs^2)
-    const float e = __builtin_amdgcn_exp2f(-xs * xs);
-    const float t = fast_rcp(fmaf(ax, 0.23164189f, 1.0f));           // p / sqrt2 = 0.3275911 / 1.41421356
-    float p = fmaf(t, 0.5307027145f, -0.7265760135f);                // A&S coefficients * 1/2
-    p = fmaf(t, p, 0.7107068705f);
-    p = fmaf(t, p, -0.142248368f);
-    p = fmaf(t, p, 0.127414796f);
-    return fmaf(-ax, p * t * e, fmaxf(x, 0.0f));
+    const float a = fminf(fabsf(x), 6.0f);
+    float p = fmaf(a, 3.3159643839e-05f, -7.6972447974e-04f);
+    p = fmaf(a, p, 8.0821445939e-03f);
+    p = fmaf(a, p, -5.3413999628e-02f);
+    p = fmaf(a, p, -4.5876976689e-01f);
+    p = fmaf(a, p, -1.1512020345f);
+    p = fmaf(a, p, -9.9999303260e-01f);
+    return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(p), fmaxf(x, 0.0f));
 }
 
 // Table-driven GELU for the MFMA kernels (10 VALU + one ds_read_b128 instead of 14 VALU + 2 transcendentals).
