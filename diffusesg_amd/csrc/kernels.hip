@@ -52,6 +52,53 @@ __device__ unsigned long long *g_diag_buf = nullptr;
 // (diffusesg.py:28-57, :246-256), q, k, v go to LDS instead of HBM and softmax(q k^T + bias) v runs from there (same operand
 // scheme as window_attn_kernel below; padded key slots carry -1e30 in the bias table, padded rows are never stored).
 // AMODE 1: PatchMerging gather in the A path (GemmArgs::a4_res).
+// R rows' partial (sum, sumsq) pairs [nparts][2] each, added in tile order.  All R rows' loads are issued before the first
+// result is used and the switch on nparts sits outside the row loop: a row-by-row version cost the prologue one memory
+// latency per row (branches between the rows pin an s_waitcnt vmcnt(0) behind each row's loads).
+template <int R>
+__device__ __forceinline__ void row_partials_n(const float *const (&pp)[R], int nparts, float (&sm)[R], float (&sq)[R]) {
+    if (nparts == 1) {
+        float2 a[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) a[i] = *reinterpret_cast<const float2 *>(pp[i]);
+#pragma unroll
+        for (int i = 0; i < R; i++) { sm[i] = a[i].x; sq[i] = a[i].y; }
+    } else if (nparts == 2) {
+        f32x4 a[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) a[i] = *reinterpret_cast<const f32x4 *>(pp[i]);
+#pragma unroll
+        for (int i = 0; i < R; i++) { sm[i] = a[i][0] + a[i][2]; sq[i] = a[i][1] + a[i][3]; }
+    } else if (nparts == 4) {
+        f32x4 a[R], b[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) { a[i] = *reinterpret_cast<const f32x4 *>(pp[i]); b[i] = *reinterpret_cast<const f32x4 *>(pp[i] + 4); }
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            sm[i] = (a[i][0] + a[i][2]) + (b[i][0] + b[i][2]);
+            sq[i] = (a[i][1] + a[i][3]) + (b[i][1] + b[i][3]);
+        }
+    } else if (nparts == 8) {
+        f32x4 a[R], b[R], c[R], d[R];
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            a[i] = *reinterpret_cast<const f32x4 *>(pp[i]); b[i] = *reinterpret_cast<const f32x4 *>(pp[i] + 4);
+            c[i] = *reinterpret_cast<const f32x4 *>(pp[i] + 8); d[i] = *reinterpret_cast<const f32x4 *>(pp[i] + 12);
+        }
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            sm[i] = ((a[i][0] + a[i][2]) + (b[i][0] + b[i][2])) + ((c[i][0] + c[i][2]) + (d[i][0] + d[i][2]));
+            sq[i] = ((a[i][1] + a[i][3]) + (b[i][1] + b[i][3])) + ((c[i][1] + c[i][3]) + (d[i][1] + d[i][3]));
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            sm[i] = 0.f; sq[i] = 0.f;
+            for (int t = 0; t < nparts; t++) { sm[i] += pp[i][2 * t]; sq[i] += pp[i][2 * t + 1]; }
+        }
+    }
+}
+
 template <bool LN, int ACT, bool RES, int EPI, int WS = 8, int AMODE = 0>   // WS: window side of the fused attention (EPI == 4): 8 or 10
 __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (GBM + GBN) * GLD];
@@ -89,28 +136,6 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
                                        : make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
     const rsrc_t rsA2 = make_rsrc(g.A2 ? g.A2 + (size_t)m0 * g.lda2 : g.A, g.A2 ? (unsigned)rows_m * g.lda2 * 4u : 0u);
     const rsrc_t rsW = (EPI == 4) ? make_rsrc(g.W, (unsigned)(3 * g.wg.C) * g.K * 4u) : make_rsrc(g.W + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 4u);
-    // one row's partial (sum, sumsq) pairs [nparts][2], added in tile order; every load independent of the others, so a
-    // thread's rows cost one memory latency in the prologue
-    auto row_partials = [&](const float *pp, float &sm, float &sq) {
-        if (g.ln_nparts == 1) {
-            const float2 a = *reinterpret_cast<const float2 *>(pp);
-            sm = a.x; sq = a.y;
-        } else if (g.ln_nparts == 2) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(pp);
-            sm = a[0] + a[2]; sq = a[1] + a[3];
-        } else if (g.ln_nparts == 4) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(pp), b = *reinterpret_cast<const f32x4 *>(pp + 4);
-            sm = (a[0] + a[2]) + (b[0] + b[2]); sq = (a[1] + a[3]) + (b[1] + b[3]);
-        } else if (g.ln_nparts == 8) {
-            const f32x4 a = *reinterpret_cast<const f32x4 *>(pp), b = *reinterpret_cast<const f32x4 *>(pp + 4),
-                        c = *reinterpret_cast<const f32x4 *>(pp + 8), d = *reinterpret_cast<const f32x4 *>(pp + 12);
-            sm = ((a[0] + a[2]) + (b[0] + b[2])) + ((c[0] + c[2]) + (d[0] + d[2]));
-            sq = ((a[1] + a[3]) + (b[1] + b[3])) + ((c[1] + c[3]) + (d[1] + d[3]));
-        } else {
-            sm = 0.f; sq = 0.f;
-            for (int t = 0; t < g.ln_nparts; t++) { sm += pp[2 * t]; sq += pp[2 * t + 1]; }
-        }
-    };
     unsigned voffA1[4], voffA2[4], voffW[3];
     unsigned voffA4[4][4];   // AMODE 1: [part][staging row]
     float a_rstd[4], a_nmr[4];
@@ -142,36 +167,44 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     // LayerNorm statistics of the staging rows.  (Issuing the first two chunks' tile loads before these loads -- one memory
     // latency in the prologue instead of two -- measured 0.15 % slower in the in-box A/B, tools/ab_libs.sh.)
     auto load_row_stats = [&]() {
+        const float invk = 1.0f / (float)g.K;
+        auto finish = [&](int p, float sm, float sq) {
+            const float mean = sm * invk, rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);
+            a_rstd[p] = rstd;
+            a_nmr[p] = -mean * rstd;
+        };
+        if (AMODE == 1) {
+            // LayerNorm(4C) statistics = the four fine rows' partial (sum, sumsq) pairs added in a fixed order
+            const float *pp[16];
+            float psm[16], psq[16];
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const int r = r0 + 32 * p;
-            if (AMODE == 1) {
-                // LayerNorm(4C) statistics = the four fine rows' partial (sum, sumsq) pairs added in a fixed order
-                float psm[4], psq[4];
+            for (int p = 0; p < 4; p++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int srow = a_grow[p] + (q & 1) * g.a4_res + (q >> 1);
-                    row_partials(g.ln_part + (size_t)srow * g.ln_nparts * 2, psm[q], psq[q]);
-                }
-                const float sm = (psm[0] + psm[1]) + (psm[2] + psm[3]), sq = (psq[0] + psq[1]) + (psq[2] + psq[3]);
-                const float invk = 1.0f / (float)g.K;
-                const float mean = sm * invk, rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);
-                a_rstd[p] = rstd;
-                a_nmr[p] = -mean * rstd;
-            } else if (LN) {
-                const int m = (EPI == 4) ? max(a_grow[p], 0) : min(m0 + r, g.M - 1);
-                float mean, rstd;
-                if (g.ln_part) {   // partial (sum, sumsq) per 96-column tile of the producer: [M][nparts][2], added in tile order
-                    float sm, sq;
-                    row_partials(g.ln_part + (size_t)m * g.ln_nparts * 2, sm, sq);
-                    const float invk = 1.0f / (float)g.K;
-                    mean = sm * invk;
-                    rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invk), 0.f) + LN_EPS);
-                } else {
-                    mean = g.ln_stats[2 * m]; rstd = g.ln_stats[2 * m + 1];
-                }
-                a_rstd[p] = rstd;
-                a_nmr[p] = -mean * rstd;
+                for (int q = 0; q < 4; q++)
+                    pp[4 * p + q] = g.ln_part + (size_t)(a_grow[p] + (q & 1) * g.a4_res + (q >> 1)) * g.ln_nparts * 2;
+            row_partials_n<16>(pp, g.ln_nparts, psm, psq);
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                finish(p, (psm[4 * p] + psm[4 * p + 1]) + (psm[4 * p + 2] + psm[4 * p + 3]),
+                       (psq[4 * p] + psq[4 * p + 1]) + (psq[4 * p + 2] + psq[4 * p + 3]));
+        } else if (LN) {
+            int m[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) m[p] = (EPI == 4) ? max(a_grow[p], 0) : min(m0 + r0 + 32 * p, g.M - 1);
+            if (g.ln_part) {   // partial (sum, sumsq) per 96-column tile of the producer: [M][nparts][2], added in tile order
+                const float *pp[4];
+                float sm[4], sq[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) pp[p] = g.ln_part + (size_t)m[p] * g.ln_nparts * 2;
+                row_partials_n<4>(pp, g.ln_nparts, sm, sq);
+#pragma unroll
+                for (int p = 0; p < 4; p++) finish(p, sm[p], sq[p]);
+            } else {
+                float2 st[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) st[p] = *reinterpret_cast<const float2 *>(g.ln_stats + 2 * m[p]);
+#pragma unroll
+                for (int p = 0; p < 4; p++) { a_rstd[p] = st[p].y; a_nmr[p] = -st[p].x * st[p].y; }
             }
         }
     };
