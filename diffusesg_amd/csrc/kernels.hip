@@ -219,6 +219,11 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     struct Stage { f32x4 a[4], w[3]; };
     auto issue = [&](Stage &st, int kc) {
         kc = kc < nk ? kc : nk - 1;  // the tail iterations re-load a valid chunk they never use
+#if defined(DSG_EXP) && DSG_EXP >= 2
+        if (kc > 1) return;          // power experiment (tools/gemm_bench, wrong results): no global loads in the K loop
+#elif defined(DSG_EXP) && DSG_EXP == 1
+        kc = kc & 1;                 // power experiment: every chunk re-reads chunk 0/1 (cache hits, nothing streams)
+#endif
         const bool second = kc >= nk1;
         const unsigned soffA = (unsigned)(second ? kc - nk1 : kc) * (GBK * 4u), soffW = (unsigned)kc * (GBK * 4u);
         if (AMODE == 1) {
@@ -247,8 +252,13 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
 #pragma unroll
         for (int p = 0; p < 3; p++) st.w[p] = buf_load4(rsW, voffW[p], soffW);
     };
+    bool exp_skip_write = false;
+    (void)exp_skip_write;
     auto write = [&](const Stage &st, int buf) {
         float *As = lds + buf * BUF, *Ws = As + GBM * GLD;
+#if defined(DSG_EXP) && DSG_EXP >= 3
+        if (exp_skip_write) return;  // power experiment: no tile staging stores in the K loop
+#endif
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             f32x4 v = st.a[p];
@@ -321,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     if (tid == 0) ph1 = __builtin_amdgcn_s_memrealtime();
 #endif
     fread(f0, 0, 0);
+    exp_skip_write = true;
     int kc = 0;
     for (; kc + 1 < nk; kc += 2) {
         GEMM4_CHUNK(0, s1, s0, kc);

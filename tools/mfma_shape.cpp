@@ -45,9 +45,12 @@ __global__ __launch_bounds__(256, 2) void k(const float *__restrict__ rnd, float
 // What pulls the clock down in the real GEMM?  The same 32x32x2 loop with the GEMM's memory-side activity added step by step, all on
 // random data: MODE 1 = fragments re-read from LDS (4 ds_read_b128 per 12 MFMA, as gemm4_f32_kernel), MODE 2 = + the tile staging
 // stores (7 ds_write_b128 per 48 MFMA and thread), MODE 3 = + the global loads that feed them (7 buffer-sized 16-B loads per 48 MFMA
-// and thread from an L2-resident array).
+// and thread from an L2-resident array), MODE 4 = two of those seven loads stream a 2 GB buffer instead (unique addresses per block
+// and iteration: ~1.3 TB/s of real HBM reads, the GEMM class's measured average), MODE 5 = + one 16-B store per thread and
+// iteration to a 1 GB buffer (~0.65 TB/s of HBM writes).
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void kg(const float *__restrict__ rnd, float *out, unsigned long long *cyc, int iters) {
+__global__ __launch_bounds__(256, 2) void kg(const float *__restrict__ rnd, float *out, unsigned long long *cyc, int iters,
+                                             const f32x4 *__restrict__ big = nullptr, f32x4 *__restrict__ sink = nullptr) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 224 * 36];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 2 * 224 * 36; i += 256) lds[i] = rnd[(blockIdx.x * 4096 + i) & 0xfffff];
@@ -65,6 +68,12 @@ __global__ __launch_bounds__(256, 2) void kg(const float *__restrict__ rnd, floa
 #pragma unroll
             for (int p = 0; p < 7; p++) st[p] = g4[((it * 1792 + tid + 256 * p) & 0x3ffff)];   // 4 MB window: L2 resident
         }
+        if (MODE >= 4) {
+            const size_t base = ((size_t)it * gridDim.x + blockIdx.x) * 512;   // 8 KB per block and iteration, never re-read
+#pragma unroll
+            for (int p = 0; p < 2; p++) st[p] = big[(base + tid + 256 * p) & 0x7ffffff];   // 2 GB of f32x4
+        }
+        if (MODE >= 5) sink[(((size_t)it * gridDim.x + blockIdx.x) * 256 + tid) & 0x3ffffff] = st[6];   // 1 GB
 #pragma unroll
         for (int s4 = 0; s4 < 4; s4++) {
             const f32x4 a = *reinterpret_cast<const f32x4 *>(lds + buf + a_off + 8 * s4);
@@ -91,16 +100,16 @@ __global__ __launch_bounds__(256, 2) void kg(const float *__restrict__ rnd, floa
 }
 
 template <int MODE>
-int rung(const char *name, const float *rnd, int iters) {
+int rung(const char *name, const float *rnd, int iters, const f32x4 *big = nullptr, f32x4 *sink = nullptr) {
     const int blocks = 512;
     float *out; unsigned long long *cyc;
     CK(hipMalloc(&out, (size_t)blocks * 256 * 4)); CK(hipMalloc(&cyc, (size_t)blocks * 16));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int w = 0; w < 60; w++) hipLaunchKernelGGL(kg<MODE>, dim3(blocks), dim3(256), 0, 0, rnd, out, cyc, iters);
+    for (int w = 0; w < 60; w++) hipLaunchKernelGGL(kg<MODE>, dim3(blocks), dim3(256), 0, 0, rnd, out, cyc, iters, big, sink);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     const int reps = 10;
-    for (int w = 0; w < reps; w++) hipLaunchKernelGGL(kg<MODE>, dim3(blocks), dim3(256), 0, 0, rnd, out, cyc, iters);
+    for (int w = 0; w < reps; w++) hipLaunchKernelGGL(kg<MODE>, dim3(blocks), dim3(256), 0, 0, rnd, out, cyc, iters, big, sink);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     std::vector<unsigned long long> h(2 * blocks);
@@ -152,5 +161,10 @@ int main() {
     if (rung<1>("32x32x2 + fragment reads from LDS", rnd, 3000)) return 1;
     if (rung<2>("  + tile staging stores + barrier", rnd, 3000)) return 1;
     if (rung<3>("  + global (L2) loads for the staging", rnd, 3000)) return 1;
+    f32x4 *big, *sink;
+    CK(hipMalloc(&big, (size_t)2 << 30)); CK(hipMalloc(&sink, (size_t)1 << 30));
+    CK(hipMemset(big, 0x3c, (size_t)2 << 30)); CK(hipMemset(sink, 0, (size_t)1 << 30));
+    if (rung<4>("  + 2 of 7 loads streaming HBM (~1.3 TB/s)", rnd, 3000, big, sink)) return 1;
+    if (rung<5>("  + HBM stores (~0.65 TB/s)", rnd, 3000, big, sink)) return 1;
     return 0;
 }
