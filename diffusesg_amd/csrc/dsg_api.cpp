@@ -1615,6 +1615,19 @@ int dsg_rainbow_loss(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const 
     return hipGetLastError() == hipSuccess ? DSG_OK : DSG_ERR_HIP;
 }
 
+int dsg_rainbow_loss_backward(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *pred_adj, const float *pred_node,
+                              const float *target_adj, const float *target_node, const uint8_t *flags, const float *loss_weight,
+                              float edge_loss_weight, float node_loss_weight, float iou_loss_weight, const float *sigmas,
+                              float *out_grad_adj, float *out_grad_node, float *out_grad_F_adj, float *out_grad_F_node, void *stream) {
+    if (B < 1 || N < 1 || c_adj < 1 || c_node < 1 || !pred_adj || !pred_node || !target_adj || !target_node || !flags || !out_grad_adj ||
+        !out_grad_node || (iou_loss_weight != 0.f && c_node < 4) || ((out_grad_F_adj || out_grad_F_node) && !sigmas))
+        return DSG_ERR_INVALID;
+    launch_rainbow_loss_backward(CStatePtrs{pred_adj, pred_node}, CStatePtrs{target_adj, target_node}, flags, loss_weight,
+                                 edge_loss_weight, node_loss_weight, iou_loss_weight, sigmas, StatePtrs{out_grad_adj, out_grad_node},
+                                 StatePtrs{out_grad_F_adj, out_grad_F_node}, Dims{B, N, c_adj, c_node}, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? DSG_OK : DSG_ERR_HIP;
+}
+
 double dsg_profile_clock_ghz(dsg_handle h) { return h ? h->prof_clock_ghz : 0.0; }
 
 int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, int32_t n_adj_type,

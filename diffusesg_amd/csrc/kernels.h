@@ -156,6 +156,8 @@ void launch_train_inputs(CStatePtrs clean, const float *rnd, CStatePtrs eps, uin
 // trainer_node_adj.py:130-159); one block per sample, fixed-order reduction
 void launch_rainbow_loss(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w,
                          float *loss_adj, float *loss_node, Dims d, hipStream_t s);
+void launch_rainbow_loss_backward(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w,
+                                  float iou_w, const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d, hipStream_t s);
 void launch_decode_bits(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,
                         int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d, hipStream_t s);
 

@@ -2010,6 +2010,81 @@ void launch_rainbow_loss(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, 
     hipLaunchKernelGGL(rainbow_loss_kernel, dim3(d.B), dim3(256), 0, s, pred, tgt, flags, w, edge_w, node_w, iou_w, loss_adj, loss_node, d);
 }
 
+// Backward of  loss = mean_b(loss_adj) + mean_b(loss_node)  (trainer_node_adj.py:163) with respect to the preconditioned
+// outputs D, and with respect to the raw network outputs F:  D = mask(c_skip x + c_out F)  (precond.py:101-104)  =>
+// dL/dF = c_out(sigma_b) dL/dD.  The IoU term follows autograd through (x+1)/2 -> cxcywh->xyxy -> clamp[0,1] -> box_iou:
+// clamp passes the gradient inside [0,1] inclusive, max/min to the selected argument, the overlap's clamp(min=0) where >= 0.
+// One block per sample; the first stage of the training backward, checked against the reference's autograd.
+__global__ __launch_bounds__(256) void rainbow_loss_backward_kernel(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w,
+                                                                    float edge_w, float node_w, float iou_w, const float *sigmas,
+                                                                    StatePtrs grad, StatePtrs gradF, Dims d) {
+    __shared__ int cnt[2];
+    const int b = blockIdx.x, tid = threadIdx.x, N = d.N, Ca = d.Ca, Cn = d.Cn;
+    const uint8_t *f = flags + (size_t)b * N;
+    if (tid == 0) {
+        int n = 0, nt = 0;
+        for (int i = 0; i < N; i++) n += f[i] ? 1 : 0;
+        for (int k = 0; k < d.B * N; k++) nt += flags[k] ? 1 : 0;
+        cnt[0] = n; cnt[1] = nt;
+    }
+    __syncthreads();
+    const double n = (double)cnt[0], wb = w ? (double)w[b] : 1.0, invB = 1.0 / (double)d.B;
+    const double ka = (double)edge_w * 2.0 * wb / (n * n * (double)Ca) * invB;
+    const double kn = (double)node_w * 2.0 * wb / (n * (double)Cn) * invB;
+    const double ki = (double)iou_w * wb / (double)cnt[1] * invB;
+    float c_out = 1.0f;
+    if (sigmas) { const float sg = sigmas[b], sd = 0.5f; c_out = __fdiv_rn(FMUL(sg, sd), __fsqrt_rn(FADD(FMUL(sg, sg), FMUL(sd, sd)))); }
+    const size_t na = (size_t)Ca * N * N;
+    for (size_t k = tid; k < na; k += 256) {
+        const int j = k % N, i = (k / N) % N;
+        const float g = (f[i] && f[j]) ? (float)(ka * (double)FSUB(pred.adj[(size_t)b * na + k], tgt.adj[(size_t)b * na + k])) : 0.0f;
+        grad.adj[(size_t)b * na + k] = g;
+        if (gradF.adj) gradF.adj[(size_t)b * na + k] = FMUL(c_out, g);
+    }
+    for (int i = tid; i < N; i += 256) {
+        double gb[4] = {0.0, 0.0, 0.0, 0.0};
+        const size_t row = ((size_t)b * N + i) * Cn;
+        if (f[i] && iou_w != 0.f) {
+            float bx[2][4], raw[4];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const float *src = (q ? tgt.node : pred.node) + row + (Cn - 4);
+                const float cx = __fdiv_rn(FADD(src[0], 1.0f), 2.0f), cy = __fdiv_rn(FADD(src[1], 1.0f), 2.0f);
+                const float bw = __fdiv_rn(FADD(src[2], 1.0f), 2.0f), bh = __fdiv_rn(FADD(src[3], 1.0f), 2.0f);
+                const float v[4] = {FSUB(cx, FMUL(0.5f, bw)), FSUB(cy, FMUL(0.5f, bh)), FADD(cx, FMUL(0.5f, bw)), FADD(cy, FMUL(0.5f, bh))};
+#pragma unroll
+                for (int t = 0; t < 4; t++) { bx[q][t] = fminf(fmaxf(v[t], 0.0f), 1.0f); if (!q) raw[t] = v[t]; }
+            }
+            const double aw = FSUB(bx[0][2], bx[0][0]), ah = FSUB(bx[0][3], bx[0][1]);
+            const double a0 = aw * ah, a1 = (double)FSUB(bx[1][2], bx[1][0]) * (double)FSUB(bx[1][3], bx[1][1]);
+            const double dw = FSUB(fminf(bx[0][2], bx[1][2]), fmaxf(bx[0][0], bx[1][0])), dh = FSUB(fminf(bx[0][3], bx[1][3]), fmaxf(bx[0][1], bx[1][1]));
+            const double iw = dw > 0 ? dw : 0, ih = dh > 0 ? dh : 0;
+            const double inter = iw * ih, uni = a0 + a1 - inter, iou = inter / uni;
+            const double g_iou = ki * (-2.0 * iou), g_inter = g_iou * (uni + inter) / (uni * uni), g_area = g_iou * (-inter) / (uni * uni);
+            double gc[4];
+            gc[0] = g_inter * ((dw >= 0 && bx[0][0] > bx[1][0]) ? -ih : 0.0) + g_area * (-ah);
+            gc[1] = g_inter * ((dh >= 0 && bx[0][1] > bx[1][1]) ? -iw : 0.0) + g_area * (-aw);
+            gc[2] = g_inter * ((dw >= 0 && bx[0][2] < bx[1][2]) ? ih : 0.0) + g_area * ah;
+            gc[3] = g_inter * ((dh >= 0 && bx[0][3] < bx[1][3]) ? iw : 0.0) + g_area * aw;
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (!(raw[t] >= 0.0f && raw[t] <= 1.0f)) gc[t] = 0.0;
+            gb[0] = 0.5 * (gc[0] + gc[2]); gb[1] = 0.5 * (gc[1] + gc[3]);
+            gb[2] = 0.25 * (gc[2] - gc[0]); gb[3] = 0.25 * (gc[3] - gc[1]);
+        }
+        for (int c = 0; c < Cn; c++) {
+            double g = f[i] ? kn * (double)FSUB(pred.node[row + c], tgt.node[row + c]) : 0.0;
+            if (f[i] && c >= Cn - 4) g += gb[c - (Cn - 4)];
+            grad.node[row + c] = (float)g;
+            if (gradF.node) gradF.node[row + c] = FMUL(c_out, (float)g);
+        }
+    }
+}
+void launch_rainbow_loss_backward(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w,
+                                  float iou_w, const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d, hipStream_t s) {
+    hipLaunchKernelGGL(rainbow_loss_backward_kernel, dim3(d.B), dim3(256), 0, s, pred, tgt, flags, w, edge_w, node_w, iou_w, sigmas, grad,
+                       gradF, d);
+}
+
 // Post-decode of 'bits' samples (sampler_node_adj.py:222-285, attribute_code.py:319-328):
 // value > 0 -> bit 1, channel 0 is the MSB; clamp to [0, n_type-1]; masked; adjacency diagonal zeroed;
 // bbox = node[..., -4:]*0.5+0.5 masked (sampler_node_adj.py:201-209)

@@ -5,8 +5,10 @@
   eval_loss_step                  <-> node_adj_move_forward_one_epoch(mode='test') body     (R/runner/trainer/trainer_node_adj.py:96-167)
 
 Same constructor kwargs, call signatures and return conventions as the reference classes; the arithmetic runs in libdsg.so
-(`dsg_train_inputs`, `dsg_rainbow_loss`, and the preconditioned network through `NodeAdjPrecondHip`).  Backward, the optimiser,
-EMA and DDP are NOT built: `mode='train'` raises.
+(`dsg_train_inputs`, `dsg_rainbow_loss`, and the preconditioned network through `NodeAdjPrecondHip`).  Of the backward only the
+first stage exists (`NodeAdjRainbowLossHip.backward` -> `dsg_rainbow_loss_backward`: loss -> preconditioned outputs -> raw network
+outputs, checked against the reference's autograd); the network's backward, the optimiser, EMA and DDP are NOT built: `mode='train'`
+raises.
 """
 from __future__ import annotations
 
@@ -123,6 +125,38 @@ class NodeAdjRainbowLossHip(torch.nn.Module):
         tot_a = (la * cnt ** 2 * pa.shape[1]).sum()          # undo the per-sample normalisation: plain masked weighted sums
         tot_x = (ln * cnt * px.shape[2]).sum()
         return tot_a / cnt ** 2 * self.edge_loss_weight, tot_x / cnt * self.edge_loss_weight
+
+
+    @torch.no_grad()
+    def backward(self, net_pred_a, net_pred_x, net_target_a, net_target_x, node_flags, loss_weight=None, sigmas=None,
+                 iou_loss_weight=0.0):
+        """First stage of `loss.backward()` of a training step (trainer_node_adj.py:163-170), loss = loss_adj.mean() + loss_node.mean()
+        with reduction='none' terms: -> (dL/d net_pred_a, dL/d net_pred_x, dL/dF_a | None, dL/dF_x | None); the last two (with `sigmas`)
+        are the gradients at the raw network outputs, c_out(sigma) * the first two (precond.py:101-104).  The network's own backward is
+        not built."""
+        if node_flags.dim() != 2:
+            raise NotImplementedError("node-only ablation ([B,N,N] node_flags) is out of scope")
+        L = _lib.load()
+        dev = net_pred_a.device
+        B, n = node_flags.shape
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32)
+        a4 = lambda t: (f32(t).unsqueeze(1) if t.dim() == 3 else f32(t)).contiguous()
+        x3 = lambda t: (f32(t).unsqueeze(-1) if t.dim() == 2 else f32(t)).contiguous()
+        pa, ta, px, tx = a4(net_pred_a), a4(net_target_a), x3(net_pred_x), x3(net_target_x)
+        fl = node_flags.to(device=dev).to(torch.uint8).contiguous()
+        w = None if loss_weight is None else f32(loss_weight).reshape(-1).contiguous()
+        sg = None if sigmas is None else f32(sigmas).reshape(-1).contiguous()
+        ga, gx = torch.empty_like(pa), torch.empty_like(px)
+        fa, fx = (torch.empty_like(pa), torch.empty_like(px)) if sg is not None else (None, None)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        rc = L.dsg_rainbow_loss_backward(B, n, pa.shape[1], px.shape[2], _p(pa), _p(px), _p(ta), _p(tx), _p(fl), _p(w),
+                                         float(self.edge_loss_weight), float(self.node_loss_weight), float(iou_loss_weight), _p(sg),
+                                         _p(ga), _p(gx), _p(fa), _p(fx), C.c_void_p(st))
+        if rc != 0:
+            raise _lib.DsgError(f"dsg_rainbow_loss_backward: status {rc}")
+        sq_a = (lambda t: None if t is None else (t[:, 0] if net_pred_a.dim() == 3 else t))
+        sq_x = (lambda t: None if t is None else (t[..., 0] if net_pred_x.dim() == 2 else t))
+        return sq_a(ga), sq_x(gx), sq_a(fa), sq_x(fx)
 
 
 def eval_loss_step(model, train_obj_gen, loss_func, adjs_gt, nodes_gt, node_flags, mode="test", iou_loss_type="iou",

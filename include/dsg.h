@@ -214,6 +214,15 @@ int dsg_rainbow_loss(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const 
                      const float *target_adj, const float *target_node, const uint8_t *flags, const float *loss_weight,
                      float edge_loss_weight, float node_loss_weight, float iou_loss_weight, float *out_loss_adj, float *out_loss_node,
                      void *stream);
+/* dsg_rainbow_loss_backward: first stage of loss.backward() of a training step   R/runner/trainer/trainer_node_adj.py:163-170
+ *   loss = mean_b(loss_adj) + mean_b(loss_node) with the terms of dsg_rainbow_loss (IoU term through autograd's clamp / max / min
+ *   rules).  out_grad_* = dL/d(preconditioned outputs), layouts of pred_*.  With sigmas [B] (may be NULL) also
+ *   out_grad_F_* = dL/d(raw network outputs F) = c_out(sigma_b) * out_grad_*   (D = mask(c_skip x + c_out F), precond.py:101-104).
+ *   The backward of the network itself is not built; tests/golden/train_backward.npz holds its target gradients. */
+int dsg_rainbow_loss_backward(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *pred_adj, const float *pred_node,
+                              const float *target_adj, const float *target_node, const uint8_t *flags, const float *loss_weight,
+                              float edge_loss_weight, float node_loss_weight, float iou_loss_weight, const float *sigmas,
+                              float *out_grad_adj, float *out_grad_node, float *out_grad_F_adj, float *out_grad_F_node, void *stream);
 
 #ifdef __cplusplus
 }

@@ -834,3 +834,84 @@ int dsgref_rainbow_loss(dsgref *h, int B, const float *pred_adj, const float *pr
     }
     return 0;
 }
+
+/* Backward of  loss = mean_b(loss_adj[b]) + mean_b(loss_node[b])  (trainer_node_adj.py:163, loss terms as in dsgref_rainbow_loss)
+ * with respect to the preconditioned outputs D (grad_adj, grad_node), and -- when sigmas is given -- with respect to the raw
+ * network outputs:  D = mask(c_skip x + c_out F)  (model/precond/precond.py:101-104)  =>  dL/dF = c_out(sigma_b) * dL/dD on valid
+ * entries, 0 elsewhere;  c_out = sigma sigma_data / sqrt(sigma^2 + sigma_data^2)  (runner/objectives/edm.py:122-126).
+ *   d loss_adj[b] / d D_adj  = edge_w * 2 w_b (D - target) / (n_b^2 C_adj)          on f_i f_j
+ *   d loss_node[b] / d D_node = node_w * 2 w_b (D - target) / (n_b C_node)          on f_i
+ *   IoU term  iou_w w_b sum_i f_i (-(iou_i)^2) / n_total:  autograd through  (x+1)/2 -> cxcywh->xyxy -> clamp[0,1] -> box_iou
+ *   (clamp passes the gradient inside [0,1] inclusive; max/min to the selected argument; clamp(min=0) of the overlap where >= 0).
+ * Everything carries the 1/B of the batch mean. */
+int dsgref_rainbow_loss_backward(dsgref *h, int B, const float *pred_adj, const float *pred_node, const float *tgt_adj,
+                                 const float *tgt_node, const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w,
+                                 const float *sigmas, float *grad_adj, float *grad_node, float *grad_F_adj, float *grad_F_node) {
+    const int N = h->N, Ca = h->c_adj, Cn = h->c_node;
+    long n_total = 0;
+    for (size_t k = 0; k < (size_t)B * N; k++) n_total += flags[k] ? 1 : 0;
+    for (int b = 0; b < B; b++) {
+        const uint8_t *f = flags + (size_t)b * N;
+        int n = 0;
+        for (int i = 0; i < N; i++) n += f[i] ? 1 : 0;
+        const float wb = w ? w[b] : 1.0f;
+        const double ka = (double)edge_w * 2.0 * (double)wb / ((double)n * (double)n * (double)Ca) / (double)B;
+        const double kn = (double)node_w * 2.0 * (double)wb / ((double)n * (double)Cn) / (double)B;
+        const double ki = (double)iou_w * (double)wb / (double)n_total / (double)B;
+        float c_out = 1.0f;
+        if (sigmas) { const float sg = sigmas[b], sd = 0.5f; c_out = sg * sd / sqrtf(sg * sg + sd * sd); }
+        for (int c = 0; c < Ca; c++)
+            for (int i = 0; i < N; i++)
+                for (int j = 0; j < N; j++) {
+                    const size_t k = (((size_t)b * Ca + c) * N + i) * N + j;
+                    const float g = (f[i] && f[j]) ? (float)(ka * (double)(pred_adj[k] - tgt_adj[k])) : 0.0f;
+                    grad_adj[k] = g;
+                    if (grad_F_adj) grad_F_adj[k] = c_out * g;
+                }
+        for (int i = 0; i < N; i++) {
+            double gb[4] = {0, 0, 0, 0};
+            if (f[i] && iou_w != 0.0f) {
+                float bx[2][4], raw[4];
+                for (int q = 0; q < 2; q++) {
+                    const float *src = (q ? tgt_node : pred_node) + ((size_t)b * N + i) * Cn + (Cn - 4);
+                    const float cx = (src[0] + 1.0f) / 2.0f, cy = (src[1] + 1.0f) / 2.0f, bw = (src[2] + 1.0f) / 2.0f, bh = (src[3] + 1.0f) / 2.0f;
+                    const float v[4] = {cx - 0.5f * bw, cy - 0.5f * bh, cx + 0.5f * bw, cy + 0.5f * bh};
+                    for (int t = 0; t < 4; t++) { bx[q][t] = fminf(fmaxf(v[t], 0.0f), 1.0f); if (!q) raw[t] = v[t]; }
+                }
+                const double aw = bx[0][2] - bx[0][0], ah = bx[0][3] - bx[0][1];
+                const double a0 = aw * ah, a1 = (double)(bx[1][2] - bx[1][0]) * (double)(bx[1][3] - bx[1][1]);
+                const double dw = fminf(bx[0][2], bx[1][2]) - fmaxf(bx[0][0], bx[1][0]), dh = fminf(bx[0][3], bx[1][3]) - fmaxf(bx[0][1], bx[1][1]);
+                const double iw = dw > 0 ? dw : 0, ih = dh > 0 ? dh : 0;
+                const double inter = iw * ih, uni = a0 + a1 - inter, iou = inter / uni;
+                const double g_iou = ki * (-2.0 * iou);                       /* d/d iou of  ki * (-(iou^2)) */
+                const double g_inter = g_iou * (uni + inter) / (uni * uni);    /* iou = I/U, dU/dI = -1 */
+                const double g_area = g_iou * (-inter) / (uni * uni);
+                /* d inter / d corner (only where the prediction's corner is the selected one and the overlap is open) */
+                double gc[4];
+                gc[0] = (dw >= 0 && bx[0][0] > bx[1][0]) ? -ih : 0.0;
+                gc[1] = (dh >= 0 && bx[0][1] > bx[1][1]) ? -iw : 0.0;
+                gc[2] = (dw >= 0 && bx[0][2] < bx[1][2]) ? ih : 0.0;
+                gc[3] = (dh >= 0 && bx[0][3] < bx[1][3]) ? iw : 0.0;
+                double gcorner[4];
+                gcorner[0] = g_inter * gc[0] + g_area * (-ah);
+                gcorner[1] = g_inter * gc[1] + g_area * (-aw);
+                gcorner[2] = g_inter * gc[2] + g_area * ah;
+                gcorner[3] = g_inter * gc[3] + g_area * aw;
+                for (int t = 0; t < 4; t++) if (!(raw[t] >= 0.0f && raw[t] <= 1.0f)) gcorner[t] = 0.0;   /* clamp */
+                /* corners = (cx - w/2, cy - h/2, cx + w/2, cy + h/2), (cx,cy,w,h) = (x+1)/2 */
+                gb[0] = 0.5 * (gcorner[0] + gcorner[2]);
+                gb[1] = 0.5 * (gcorner[1] + gcorner[3]);
+                gb[2] = 0.5 * 0.5 * (gcorner[2] - gcorner[0]);
+                gb[3] = 0.5 * 0.5 * (gcorner[3] - gcorner[1]);
+            }
+            for (int c = 0; c < Cn; c++) {
+                const size_t k = ((size_t)b * N + i) * Cn + c;
+                double g = f[i] ? kn * (double)(pred_node[k] - tgt_node[k]) : 0.0;
+                if (f[i] && c >= Cn - 4) g += gb[c - (Cn - 4)];
+                grad_node[k] = (float)g;
+                if (grad_F_node) grad_F_node[k] = c_out * (float)g;
+            }
+        }
+    }
+    return 0;
+}

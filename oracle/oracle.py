@@ -50,6 +50,7 @@ def lib():
         L.dsgref_sigma_steps.argtypes = [C.c_void_p, C.c_void_p]
         L.dsgref_train_inputs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 10
         L.dsgref_rainbow_loss.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_void_p] * 2
+        L.dsgref_rainbow_loss_backward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_void_p] * 5
         L.dsgref_decode_bits.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 3
         _lib = L
     return _lib
@@ -179,6 +180,21 @@ class Oracle:
         na, nn = np.empty(sa, np.float32), np.empty(sn, np.float32)
         lib().dsgref_train_inputs(self._h, B, _p(ca), _p(cn), _p(fl), _p(rn), _p(ea), _p(en), _p(sig), _p(wts), _p(na), _p(nn))
         return sig, wts, na, nn
+
+    def rainbow_loss_backward(self, pred_adj, pred_node, tgt_adj, tgt_node, flags, loss_weight=None, edge_w=1.0, node_w=1.0, iou_w=0.0,
+                              sigmas=None):
+        """d(loss_adj.mean() + loss_node.mean()) / d(preconditioned outputs) and, with sigmas, / d(raw network outputs)
+        -> (grad_adj, grad_node, grad_F_adj | None, grad_F_node | None)"""
+        B = flags.shape[0]
+        sa, sn = self._shapes(B)
+        pa, pn, ta, tn = (_f32(x).reshape(s) for x, s in ((pred_adj, sa), (pred_node, sn), (tgt_adj, sa), (tgt_node, sn)))
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        w, sg = _f32(loss_weight), _f32(sigmas)
+        ga, gn = np.empty(sa, np.float32), np.empty(sn, np.float32)
+        fa, fn = (np.empty(sa, np.float32), np.empty(sn, np.float32)) if sg is not None else (None, None)
+        lib().dsgref_rainbow_loss_backward(self._h, B, _p(pa), _p(pn), _p(ta), _p(tn), _p(fl), _p(w), edge_w, node_w, iou_w, _p(sg),
+                                           _p(ga), _p(gn), _p(fa), _p(fn))
+        return ga, gn, fa, fn
 
     def rainbow_loss(self, pred_adj, pred_node, tgt_adj, tgt_node, flags, loss_weight=None, edge_w=1.0, node_w=1.0, iou_w=0.0):
         """loss/rainbow_loss.py:37-101 (reduction='none') + the trainer's IoU term -> (loss_adj [B], loss_node [B])"""

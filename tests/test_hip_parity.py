@@ -899,6 +899,36 @@ def test_train_forward_vs_reference_fixture():
         eval_loss_step(net_for("tiny"), gen, loss_func, T(clean_adj), T(clean_node), T(flags), mode="train")
 
 
+def test_train_backward_head_vs_reference_autograd():
+    """tests/golden/train_backward.npz (the reference's own autograd over one training step): dL/d(preconditioned outputs) incl.
+    the IoU term's clamp / max / min branches, and dL/d(raw network outputs) = c_out(sigma) * that -- the first stage of the
+    backward; plus the same kernel against the oracle at the VG shape with ragged flags (1 .. 64 valid nodes)"""
+    from oracle.oracle import Oracle
+    from diffusesg_amd.train import NodeAdjRainbowLossHip
+    g = load("train_backward.npz")
+    cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case("tiny")
+    loss_func = NodeAdjRainbowLossHip(edge_loss_weight=1.0, node_loss_weight=1.0, flag_reweight=False, objective="edm")
+    ga, gx, fa, fx = loss_func.backward(T(g["tiny_pred_adj"]), T(g["tiny_pred_node"]), T(clean_adj), T(clean_node), T(flags),
+                                        loss_weight=T(g["tiny_weights"]), sigmas=T(g["tiny_sigmas"]), iou_loss_weight=1.0)
+    for mine, key in ((ga, "grad_pred_adj"), (gx, "grad_pred_node"), (fa, "grad_F_adj"), (fx, "grad_F_node")):
+        assert_close(mine.cpu().numpy(), g["tiny_" + key].reshape(tuple(mine.shape)), 1e-5, key)
+    f = torch.from_numpy(flags).cuda()
+    assert torch.all(ga.permute(0, 2, 3, 1)[~f] == 0) and torch.all(gx[~f] == 0)
+    # VG shape, B = 64 with ragged flags, vs the oracle
+    vg = Y.CONFIGS["vg"]()
+    B, n = 64, vg.max_node_num
+    fl = W.synth_flags(B, n, [30, 1, 64, 17] * 16)
+    pa, ta = W.normal(5, "bwd/pa", (B, vg.c_adj, n, n)), np.sign(W.normal(5, "bwd/ta", (B, vg.c_adj, n, n))).astype(np.float32)
+    px, tx = W.normal(5, "bwd/px", (B, n, vg.c_node)) * 0.7, np.sign(W.normal(5, "bwd/tx", (B, n, vg.c_node))).astype(np.float32) * 0.6
+    wts, sig = np.exp(W.normal(5, "bwd/w", (B,))).astype(np.float32), np.exp(W.normal(5, "bwd/s", (B,)) * 1.2 - 1.2).astype(np.float32)
+    orc = Oracle(vg, W.synth_state_dict(vg, 0))
+    ref = orc.rainbow_loss_backward(pa, px, ta, tx, fl, wts, edge_w=2.0, node_w=0.5, iou_w=1.0, sigmas=sig)
+    lf = NodeAdjRainbowLossHip(edge_loss_weight=2.0, node_loss_weight=0.5, flag_reweight=False, objective="edm")
+    got = lf.backward(T(pa), T(px), T(ta), T(tx), T(fl), loss_weight=T(wts), sigmas=T(sig), iou_loss_weight=1.0)
+    for mine, r, what in zip(got, ref, ("dD adj", "dD node", "dF adj", "dF node")):
+        assert_close(mine.cpu().numpy(), r.reshape(tuple(mine.shape)), 2e-6, what)
+
+
 def test_train_objective_device_draws_and_loss_vs_oracle():
     """library-drawn training noise: log sigma ~ N(-1.2, 1.2^2), added noise has std sigma_b on valid entries and is exactly
     masked, one seed = one draw; and the loss kernel against the oracle at the VG shape (B = 64)"""

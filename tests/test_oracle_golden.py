@@ -147,3 +147,23 @@ def test_train_forward_matches_reference():
     # end to end through the oracle's own model output: loss = adj.mean() + node.mean() (trainer_node_adj.py:167)
     la, ln = orc.rainbow_loss(pa, pn, clean_adj, clean_node, flags, wts, iou_w=1.0)
     assert abs(float(la.mean() + ln.mean()) - float(g["tiny_loss"])) <= 1e-3 * abs(float(g["tiny_loss"]))
+
+
+def test_train_backward_head_matches_reference_autograd():
+    """first stage of the backward of a training step against tests/golden/train_backward.npz (the reference's own autograd,
+    trainer_node_adj.py:96-170 in 'train' mode): dL/d(preconditioned outputs) -- sigma-weighted masked MSE terms plus the IoU term
+    through clamp / max / min -- and dL/d(raw network outputs) = c_out(sigma) * that.  The fixture also holds the parameter
+    gradients of the whole network (norm + strided sample per tensor): the target of the network backward, which is not built."""
+    g = load("train_backward.npz")
+    cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case("tiny")
+    orc = make_oracle(cfg)
+    ga, gn, fa, fn = orc.rainbow_loss_backward(g["tiny_pred_adj"], g["tiny_pred_node"], clean_adj, clean_node, flags, g["tiny_weights"],
+                                               iou_w=1.0, sigmas=g["tiny_sigmas"])
+    assert_close(ga, g["tiny_grad_pred_adj"].reshape(ga.shape), 1e-5, "dL/dD adj")
+    assert_close(gn, g["tiny_grad_pred_node"].reshape(gn.shape), 1e-5, "dL/dD node")
+    assert_close(fa, g["tiny_grad_F_adj"].reshape(fa.shape), 1e-5, "dL/dF adj")
+    assert_close(fn, g["tiny_grad_F_node"].reshape(fn.shape), 1e-5, "dL/dF node")
+    assert np.abs(g["tiny_grad_pred_node"][..., -4:]).max() > 0    # the IoU term contributes
+    # the fixture is internally consistent: the recorded total norm is the norm of the recorded per-tensor norms
+    assert abs(float(np.sqrt((g["tiny_gparam_norms"] ** 2).sum())) - float(g["tiny_total_grad_norm"])) < 1e-3 * float(g["tiny_total_grad_norm"])
+    assert len(g["tiny_gparam_names"]) == len([k for k in g.files if k.startswith("tiny_gparam/")])
