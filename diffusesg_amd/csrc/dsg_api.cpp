@@ -120,6 +120,7 @@ struct dsg_handle_s {
     bool opt_fused_qkv_attn = true;   // QKV projection + 64-token window attention in one kernel (q, k, v never reach HBM)
     bool opt_fused_rowstats = true;   // modulate+SiLU and LayerNorm statistics in the producing GEMM's epilogue (fp32 kernel)
     bool opt_gemm_bf16 = false;                                   // bf16-MFMA GEMMs (fp32 accumulate), opt-in precision mode
+    bool opt_bf16_act = true;                                     // in that mode: hidden / attention-output tensors stored as bf16
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
     bool opt_gemm_split = false;                                  // split-bf16 GEMMs (3 planes, 6 products): fp32-accurate, opt-in
@@ -867,6 +868,11 @@ BlockOut run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, 
     const std::string &p = b.prefix;
     const bool fuse = rowstats_on(h);
     const bool mlp_fused = h->opt_fused_mlp && b.w1p && C <= h->opt_fused_mlp_maxc;
+    // bf16 mode: a tensor whose only consumer is the bf16 GEMM (which rounds its A operand to bf16 on the way into LDS) is stored as
+    // bf16 by its producer -- same values bit for bit, half the bytes, no conversion in the consumer (kernels_lp.hip ABF / CBF)
+    auto bf16_tensor_ok = [&](const float *W, int K) {
+        return h->opt_gemm_bf16 && !h->opt_gemm_split && h->opt_bf16_act && K % 64 == 0 && h->taps.empty() && bf16_of(h, W) != nullptr;
+    };
     GemmArgs g;
     if (h->opt_fused_attn && b.wqp) {
         // modulate+SiLU, LN1, QKV, window attention, proj and the residual in one register-resident kernel
@@ -882,7 +888,7 @@ BlockOut run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, 
         else g.ln_stats = w->stats;   // gamma/beta of norm1 are folded into qkv_wf / qkv_bf
         g.W = b.qkv_wf; g.bias = b.qkv_bf; g.N = 3 * C;
         WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
-        bool attn_done = false;
+        bool attn_done = false, att_bf16 = false;
         if (h->opt_fused_qkv_attn && (b.ws == 8 || b.ws == 10) && !h->opt_gemm_bf16 && !h->opt_gemm_split) {
             // LN1 -> QKV -> softmax(q k^T + bias) v in one kernel: q, k, v of (two windows, one head) stay in LDS
             g.attn_bias = b.biasT; g.wg = wg; g.attn_batch = B; g.C = w->att; g.ldc = C;
@@ -896,10 +902,13 @@ BlockOut run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, 
             g.attn_bias = nullptr; g.prof = nullptr;
             g.C = w->qkv; g.ldc = 3 * C;
             P_GEMM_LP(g);
-            P_KERN(PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s));
+            att_bf16 = bf16_tensor_ok(WT(h, p + ".attn.proj.weight"), C);
+            P_KERN(PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C,
+                   launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s, att_bf16));
         }
         g = GemmArgs();
         g.A = w->att; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = C;
+        g.a_bf16 = att_bf16;
         g.W = WT(h, p + ".attn.proj.weight"); g.bias = WT(h, p + ".attn.proj.bias");
         g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
         if (fuse && !mlp_fused) g.stats_out = w->stats;   // LN2 partials of x + proj(...)
@@ -921,9 +930,12 @@ BlockOut run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, 
     else g.ln_stats = w->stats;   // gamma/beta of norm2 are folded into fc1_wf / fc1_bf
     g.W = b.fc1_wf; g.bias = b.fc1_bf; g.act = ACT_GELU;
     g.C = w->hid; g.ldc = Hd;
+    const bool hid_bf16 = bf16_tensor_ok(WT(h, p + ".mlp.fc2.weight"), Hd) && bf16_of(h, b.fc1_wf) != nullptr;
+    g.c_bf16 = hid_bf16;
     P_GEMM_LP(g);
     g = GemmArgs();
     g.A = w->hid; g.lda = Hd; g.K1 = Hd; g.K = Hd; g.M = M; g.N = C;
+    g.a_bf16 = hid_bf16;
     g.W = WT(h, p + ".mlp.fc2.weight"); g.bias = WT(h, p + ".mlp.fc2.bias");
     g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
     attach_premod(h, w, g, next);
@@ -1293,6 +1305,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "fused_rowstats") h->opt_fused_rowstats = value != 0;
     else if (n == "fused_qkv_attn") h->opt_fused_qkv_attn = value != 0;
     else if (n == "loop_graph") h->opt_loop_graph = value != 0;
+    else if (n == "bf16_act") h->opt_bf16_act = value != 0;
     else if (n == "fused_merge") { h->opt_fused_merge = value != 0; h->opt_fused_merge_small = value > 1; }   // 2: at every size
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
@@ -1318,6 +1331,7 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "fused_rowstats") *value = h->opt_fused_rowstats;
     else if (n == "fused_qkv_attn") *value = h->opt_fused_qkv_attn;
     else if (n == "loop_graph") *value = h->opt_loop_graph;
+    else if (n == "bf16_act") *value = h->opt_bf16_act && h->opt_gemm_bf16 && !h->opt_gemm_split;   // only acts in bf16 mode
     else if (n == "fused_merge") *value = h->opt_fused_merge ? (h->opt_fused_merge_small ? 2 : 1) : 0;
     else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
     else if (n == "gemm_split") *value = h->opt_gemm_split;

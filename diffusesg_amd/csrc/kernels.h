@@ -51,6 +51,7 @@ struct GemmArgs {
     const float *attn_bias = nullptr;            // [nWt][heads][64][64] key-major, log2(e)-scaled (build_bias_table)
     WinGeom wg{0, 0, 0, 0, 0};
     int attn_batch = 0;
+    int a_bf16 = 0, c_bf16 = 0;                  // bf16 mode only: A / C are bf16 tensors (lda / ldc in elements); see kernels_lp.hip
     const float *gelu_tab = nullptr;             // filled in by launch_gemm (table-driven GELU of the split kernel)
     unsigned long long *prof = nullptr;          // measurement mode: {min block start, max block end} in 100 MHz ticks
 };
@@ -84,7 +85,7 @@ void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, co
                          const float *bqkv, const float *biasT, const float *Wpp, const float *bproj, int B, const WinGeom &g,
                          bool premod, hipStream_t s);   // premod: x is already modulated by the producing kernel
 // qkv [B*T, 3C] token order -> out [B*T, C] token order; biasT [nWt][heads][Wp][Wp] (key-major)
-void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s);
+void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s, bool out_bf16 = false);
 
 // x <- silu(shift + x*(1+scale)), (scale,shift) = aff[b][off .. off+2C); stats of the new rows
 void launch_mod_stats(float *x, const float *aff, int aff_ld, int aff_off, float *stats, int B, int T, int C, hipStream_t s);

@@ -562,6 +562,7 @@ const float *gelu_table() {
 
 void launch_gemm(const GemmArgs &g, hipStream_t s) {
     if ((g.Ws3 || g.Wb) && launch_gemm_lp(g, s)) return;   // opt-in bf16-MFMA modes (kernels_lp.hip)
+    if (g.a_bf16 || g.c_bf16) { fprintf(stderr, "dsg: launch_gemm: bf16 tensors need the bf16 GEMM kernel\n"); abort(); }
     const int tiles_m = (g.M + GBM - 1) / GBM, tiles_n = (g.N + GBN - 1) / GBN;
     const dim3 grid(((tiles_m + 7) / 8) * 8 * tiles_n), block(256);
     const bool ln = g.ln_stats != nullptr || g.ln_part != nullptr, res = g.res != nullptr;
@@ -1227,7 +1228,8 @@ bool launch_fused_patch_embed96(const float *adj, const float *node, const float
 // Relative-position bias and the shifted-window mask (-100) come pre-combined and transposed
 // (key-major) from a dense table built at weight-load time; padded key slots hold -1e30.
 // =================================================================================================
-template <int KT, int WS>  // KT 32-token tiles per window (Wp = 32*KT >= WS*WS); WS compile-time: cheap index math
+template <int KT, int WS, bool OBF = false>  // KT 32-token tiles per window (Wp = 32*KT >= WS*WS); WS compile-time: cheap index math;
+                                             // OBF: the output is stored as bf16 (bf16 mode: the proj GEMM rounds it to bf16 anyway)
 __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ biasT,
                                                           float *__restrict__ out, int B, WinGeom g, int n_units) {
     constexpr int Wp = 32 * KT, Wt = WS * WS, VLD = 36;
@@ -1264,7 +1266,8 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
     // descriptors: the sample's qkv rows / the (window-type, head) bias tile / the sample's output rows
     const rsrc_t rsQ = make_rsrc(qkv + (size_t)b * T * 3 * C, (unsigned)T * 3u * C * 4u);
     const rsrc_t rsB = make_rsrc(biasT + ((size_t)(g.shift > 0 ? w : 0) * heads + head) * Wp * Wp, (unsigned)(Wp * Wp) * 4u);
-    const rsrc_t rsO = make_rsrc(out + (size_t)b * T * C, active ? (unsigned)T * C * 4u : 0u);
+    const rsrc_t rsO = OBF ? make_rsrc(reinterpret_cast<unsigned short *>(out) + (size_t)b * T * C, active ? (unsigned)T * C * 2u : 0u)
+                           : make_rsrc(out + (size_t)b * T * C, active ? (unsigned)T * C * 4u : 0u);
     const unsigned hoff = (unsigned)head * 128u;
 
     // K fragments (lane = key), V rows -> LDS (for the transposed read lane = head dim)
@@ -1336,17 +1339,22 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
             const int q0 = (r & 3) + 8 * (r >> 2);
             const int ta = __builtin_amdgcn_readlane(tokr[qt], q0), tb = __builtin_amdgcn_readlane(tokr[qt], q0 + 4);
             const int q = 32 * qt + q0 + 4 * lhalf;
-            const unsigned voff = (q < Wt) ? ((unsigned)(lhalf ? tb : ta) * (unsigned)C + (unsigned)lrow) * 4u : 0x7fffffffu;
-            buf_store1(oacc[r], rsO, voff, hoff);
+            const unsigned eoff = (unsigned)(lhalf ? tb : ta) * (unsigned)C + (unsigned)lrow;
+            if (OBF) buf_store_bf16(oacc[r], rsO, (q < Wt) ? eoff * 2u : 0x7fffffffu, hoff >> 1);
+            else buf_store1(oacc[r], rsO, (q < Wt) ? eoff * 4u : 0x7fffffffu, hoff);
         }
     }
 }
 
-void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s) {
+void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s, bool out_bf16) {
     const int nW = (g.res / g.ws) * (g.res / g.ws);
     const int n_units = B * nW * g.heads;
     const dim3 grid((n_units + 3) / 4), block(256);
-#define WA(KT_, WS_) hipLaunchKernelGGL((window_attn_kernel<KT_, WS_>), grid, block, 0, s, qkv, biasT, out, B, g, n_units)
+#define WA(KT_, WS_)                                                                                                          \
+    do {                                                                                                                      \
+        if (out_bf16) hipLaunchKernelGGL((window_attn_kernel<KT_, WS_, true>), grid, block, 0, s, qkv, biasT, out, B, g, n_units); \
+        else hipLaunchKernelGGL((window_attn_kernel<KT_, WS_, false>), grid, block, 0, s, qkv, biasT, out, B, g, n_units);         \
+    } while (0)
     switch (g.ws) {
         case 2: WA(1, 2); break;
         case 4: WA(1, 4); break;

@@ -83,6 +83,16 @@ __device__ __forceinline__ float buf_load1(rsrc_t r, unsigned voff, unsigned sof
 __device__ __forceinline__ void buf_store1(float v, rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
+// fp32 -> bf16, round to nearest even, on the integer pipe: bits [31:16] of the result are the bf16 value.  The one rounding the
+// bf16 mode uses everywhere (A operands on their way into LDS, weights at pack time, bf16-stored activations), so that storing an
+// activation as bf16 gives the consumer bit for bit what it would have rounded itself.
+__device__ __forceinline__ unsigned bf16_rne_hi(float x) {
+    const unsigned u = __float_as_uint(x);
+    return u + 0x7fffu + ((u >> 16) & 1u);
+}
+__device__ __forceinline__ void buf_store_bf16(float v, rsrc_t r, unsigned voff, unsigned soff) {   // offsets in bytes (2 per element)
+    __builtin_amdgcn_raw_buffer_store_b16((short)(bf16_rne_hi(v) >> 16), r, voff, soff, 0);
+}
 
 
 // implemented in kernels_lp.hip: the bf16-MFMA GEMMs (g.Ws3: split-bf16, fp32-accurate; g.Wb: plain bf16 operands).

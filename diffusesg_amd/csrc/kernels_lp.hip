@@ -24,10 +24,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // fp32 -> bf16 on the integer pipe.  The gfx950 v_cvt_pk_bf16_f32 instruction is deliberately not used: in these kernels
 // (conversion results feeding ds_write while bf16 MFMAs of the same wave are in flight) it produced rare wrong values in
 // lanes 48..63 (about one 16-lane group in 1e5; found with tools/gemm_bench's full-matrix diff, gone with this code).
-__device__ __forceinline__ unsigned bf16_rne_hi(float x) {   // bits [31:16] = round-to-nearest-even bf16 of x
-    const unsigned u = __float_as_uint(x);
-    return u + 0x7fffu + ((u >> 16) & 1u);
-}
+// (bf16_rne_hi lives in kernels_common.hip.h)
 __device__ __forceinline__ unsigned pack_hi16(unsigned lo, unsigned hi) {   // (hi & 0xffff0000) | (lo >> 16)
     return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
 }
@@ -42,8 +39,12 @@ constexpr int HBK = 64, HLD = 72;  // k per chunk, LDS row stride in bf16 elemen
 
 // EPI: the same epilogue extensions as gemm4_f32_kernel (kernels.hip): 1 row-statistics partials, 2 / 3 the next block's
 // modulate+SiLU (batch-uniform / per-sample) + partials; LN statistics may come from a producer's partials (g.ln_part).
-template <bool LN, int ACT, bool RES, int EPI = 0>
+// ABF / CBF ("bf16 activations between kernels"): the A tensor is already bf16 (staged into LDS as is: no conversion, half the
+// bytes) / the result is stored as bf16.  Used where the consumer is this kernel and would round the fp32 value to bf16 on its way
+// into LDS anyway (fc1 -> fc2's hidden tensor, attention output -> proj): results are bit-identical to the fp32-tensor path.
+template <bool LN, int ACT, bool RES, int EPI = 0, bool ABF = false, bool CBF = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    static_assert(!(ABF && LN), "a bf16 A tensor carries no LayerNorm");
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (GBM + GBN) * HLD];
     constexpr int BUF = (GBM + GBN) * HLD;
     const int bid = blockIdx.x;
@@ -53,7 +54,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
     const int m0 = tm * GBM, n0 = tn * GBN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rows_m = min(GBM, g.M - m0), rows_n = min(GBN, g.N - n0);
-    const rsrc_t rsA1 = make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
+    const rsrc_t rsA1 = ABF ? make_rsrc(reinterpret_cast<const __bf16 *>(g.A) + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 2u)
+                            : make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
     const rsrc_t rsA2 = make_rsrc(g.A2 ? g.A2 + (size_t)m0 * g.lda2 : g.A, g.A2 ? (unsigned)rows_m * g.lda2 * 4u : 0u);
     const rsrc_t rsW = make_rsrc(static_cast<const __bf16 *>(g.Wb) + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 2u);
     // A staging: 16 threads per row (float4 each = 64 k), rows ra + 16p; W staging: 8 threads per row (8 bf16 each)
@@ -91,17 +93,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
     }
 #pragma unroll
     for (int p = 0; p < 3; p++) voffW[p] = ((unsigned)(rw + 32 * p) * g.K + 8u * cw) * 2u;
+    unsigned voffAb[4];   // ABF: 8 threads per row (8 bf16 each), rows rw + 32p
+#pragma unroll
+    for (int p = 0; p < 4; p++) voffAb[p] = ((unsigned)(rw + 32 * p) * g.lda + 8u * cw) * 2u;
     // K may be a multiple of 32 only (e.g. 96): the last chunk is then half valid; the descriptor zero-fills the rest of
     // the row only at the buffer end, so clamp explicitly
     const int nk = (g.K + HBK - 1) / HBK;
     const int K1 = g.A2 ? g.K1 : g.K;
 
     f32x4 sa[8];
-    bf16x8 sw[3];
+    bf16x8 sw[3], sab[4];
     auto issue = [&](int kc) {
         const int k0 = kc * HBK, k = k0 + 4 * ca;
+        if (ABF) {
 #pragma unroll
-        for (int p = 0; p < 8; p++) {
+            for (int p = 0; p < 4; p++) {
+                bf16x8 v = {};
+                if (k0 + 8 * cw < g.K) v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsA1, voffAb[p], (unsigned)k0 * 2u, 0));
+                sab[p] = v;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < (ABF ? 0 : 8); p++) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (k < g.K) v = (k >= K1) ? buf_load4(rsA2, voffA2[p], (unsigned)(k0 - K1) * 4u) : buf_load4(rsA1, voffA1[p], (unsigned)k0 * 4u);
             sa[p] = v;
@@ -116,8 +129,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
     auto write = [&](int buf, int kc) {
         __bf16 *As = lds + buf * BUF, *Ws = As + GBM * HLD;
         const bool kvalid = kc * HBK + 4 * ca < g.K;
+        if (ABF) {
 #pragma unroll
-        for (int p = 0; p < 8; p++) {
+            for (int p = 0; p < 4; p++) *reinterpret_cast<bf16x8 *>(As + (rw + 32 * p) * HLD + 8 * cw) = sab[p];
+        }
+#pragma unroll
+        for (int p = 0; p < (ABF ? 0 : 8); p++) {
             f32x4 v = sa[p];
             if (LN && kvalid) {
 #pragma unroll
@@ -156,7 +173,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
         if (kc + 1 < nk) write(1 - cur, kc + 1);
         __syncthreads();
     }
-    const rsrc_t rsC = make_rsrc(g.C + (size_t)m0 * g.ldc, (unsigned)rows_m * g.ldc * 4u);
+    const rsrc_t rsC = CBF ? make_rsrc(reinterpret_cast<unsigned short *>(g.C) + (size_t)m0 * g.ldc, (unsigned)rows_m * g.ldc * 2u)
+                           : make_rsrc(g.C + (size_t)m0 * g.ldc, (unsigned)rows_m * g.ldc * 4u);
     const rsrc_t rsC2 = make_rsrc(g.C2 ? g.C2 + (size_t)m0 * g.ldc2 : g.C, g.C2 ? (unsigned)rows_m * g.ldc2 * 4u : 0u);
     const rsrc_t rsR = make_rsrc(RES ? g.res + (size_t)m0 * g.ldres : g.C, RES ? (unsigned)rows_m * g.ldres * 4u : 0u);
     const unsigned rowl = (unsigned)(wave * 32 + 4 * lhalf);
@@ -199,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
             }
             if (EPI >= 2) v = silu_exact(fmaf(v, msc, msh));
             if (EPI >= 1 && nok) { st_s[r] += v; st_q[r] = fmaf(v, v, st_q[r]); }
-            buf_store1(v, rsC, vC, rr * g.ldc * 4u);
+            if (CBF) buf_store_bf16(v, rsC, nok ? vC >> 1 : OOB, rr * g.ldc * 2u);
+            else buf_store1(v, rsC, vC, rr * g.ldc * 4u);
         }
     }
     if (EPI >= 1) {   // row statistics of the stored tile: per-wave LDS transpose, fixed-order sums (see gemm4_f32_kernel)
@@ -479,6 +498,17 @@ bool launch_gemm_lp(const GemmArgs &g_in, hipStream_t s) {
     const dim3 grid(round_up8(tiles_m) * tiles_n), block(256);
     const bool ln = g.ln_stats != nullptr || g.ln_part != nullptr, res = g.res != nullptr;
     if (g.a4_res > 0 || g.attn_bias) return false;               // fp32-kernel-only features
+    if (g.a_bf16 || g.c_bf16) {   // bf16 tensors between kernels: only the shapes the forward uses; anything else is a caller bug
+        const bool a_ok = g.a_bf16 && !g.c_bf16 && !split && !ln && g.act == ACT_NONE && res && !g.A2 && g.K % HBK == 0;
+        const bool c_ok = g.c_bf16 && !g.a_bf16 && !split && ln && g.act == ACT_GELU && !res && !g.stats_out && !g.C2;
+        if (!a_ok && !c_ok) { fprintf(stderr, "dsg: launch_gemm_lp: unsupported bf16-tensor GEMM\n"); abort(); }
+        if (c_ok) { hipLaunchKernelGGL((gemm_bf16_kernel<true, ACT_GELU, false, 0, false, true>), grid, block, 0, s, g, tiles_m, tiles_n); return true; }
+        const int epi = !g.stats_out ? 0 : !g.mod_aff ? 1 : (g.mod_ld == 0 ? 2 : 3);
+#define LP_ABF(E) hipLaunchKernelGGL((gemm_bf16_kernel<false, ACT_NONE, true, E, true, false>), grid, block, 0, s, g, tiles_m, tiles_n)
+        if (epi == 0) LP_ABF(0); else if (epi == 1) LP_ABF(1); else if (epi == 2) LP_ABF(2); else LP_ABF(3);
+#undef LP_ABF
+        return true;
+    }
     if (split && (g.stats_out || g.ln_part)) return false;       // the split kernel has no epilogue extensions
     if (g.stats_out) {
         if (ln || g.act != ACT_NONE) return false;

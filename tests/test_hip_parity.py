@@ -825,6 +825,31 @@ def test_coco_batch512_properties():
     assert torch.all(bn[~f] == 0)
 
 
+@pytest.mark.parametrize("name", ["small", "vg", "coco"])
+def test_bf16_stored_activations_are_bit_identical(name):
+    """bf16 mode, option "bf16_act" (default on): the MLP's hidden tensor and the attention output are stored as bf16 by their
+    producers because their only consumer, the bf16 GEMM, rounds its A operand to bf16 (RNE) on the way into LDS anyway -- so the
+    forward must equal the fp32-tensor path BIT FOR BIT, in the generic and the fused kernel selections, graphs on"""
+    from diffusesg_amd.model import build_network
+    cfg, flags, adj, node, sc_adj, sc_node = Y.fwd_case(name)
+    net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda").model
+    h = net._ensure_handle()
+    h.set_option("gemm_bf16", 1)
+    args = (T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
+    for fused in (1, 0):
+        for opt in ("fused_attn", "fused_mlp", "fused_qkv_attn"):
+            h.set_option(opt, fused)
+        h.set_option("bf16_act", 1)
+        assert h.get_option("bf16_act") == 1
+        a1, n1 = [t.clone() for t in net(*args)]
+        h.set_option("bf16_act", 0)
+        assert h.get_option("bf16_act") == 0
+        a0, n0 = [t.clone() for t in net(*args)]
+        assert torch.equal(a1, a0) and torch.equal(n1, n0), f"{name} fused={fused}"
+    h.set_option("gemm_bf16", 0)
+    assert h.get_option("bf16_act") == 0   # reports what acts: nothing outside bf16 mode
+
+
 def test_step_graphs_reused_across_runs_match_eager():
     """The captured step bodies of the reverse loop are cached per (self-cond slot, update, coins) combination and replayed
     back to back with nothing in between (no snapshots); runs with different coin sequences reuse each other's graphs and
