@@ -120,7 +120,7 @@ struct dsg_handle_s {
     bool opt_fused_qkv_attn = true;   // QKV projection + 64-token window attention in one kernel (q, k, v never reach HBM)
     bool opt_fused_rowstats = true;   // modulate+SiLU and LayerNorm statistics in the producing GEMM's epilogue (fp32 kernel)
     bool opt_gemm_bf16 = false;                                   // bf16-MFMA GEMMs (fp32 accumulate), opt-in precision mode
-    bool opt_bf16_act = true;                                     // in that mode: hidden / attention-output tensors stored as bf16
+    int opt_bf16_act = 2;                                         // in that mode: 1 hidden / attention-output tensors stored as bf16 (bit-identical), 2 also qkv
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
     bool opt_gemm_split = false;                                  // split-bf16 GEMMs (3 planes, 6 products): fp32-accurate, opt-in
@@ -901,10 +901,14 @@ BlockOut run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, 
         if (!attn_done) {
             g.attn_bias = nullptr; g.prof = nullptr;
             g.C = w->qkv; g.ldc = 3 * C;
-            P_GEMM_LP(g);
             att_bf16 = bf16_tensor_ok(WT(h, p + ".attn.proj.weight"), C);
+            // level 2: q, k, v leave the QKV GEMM as bf16 too (the attention math stays fp32 on the widened values; this one
+            // changes results -- within the bf16 mode's stated bar -- because the fp32 attention kernel is the consumer)
+            const bool qkv_bf16 = att_bf16 && h->opt_bf16_act >= 2 && bf16_of(h, b.qkv_wf) != nullptr;
+            g.c_bf16 = qkv_bf16;
+            P_GEMM_LP(g);
             P_KERN(PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C,
-                   launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s, att_bf16));
+                   launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s, att_bf16, qkv_bf16));
         }
         g = GemmArgs();
         g.A = w->att; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = C;
@@ -1305,7 +1309,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "fused_rowstats") h->opt_fused_rowstats = value != 0;
     else if (n == "fused_qkv_attn") h->opt_fused_qkv_attn = value != 0;
     else if (n == "loop_graph") h->opt_loop_graph = value != 0;
-    else if (n == "bf16_act") h->opt_bf16_act = value != 0;
+    else if (n == "bf16_act") h->opt_bf16_act = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "fused_merge") { h->opt_fused_merge = value != 0; h->opt_fused_merge_small = value > 1; }   // 2: at every size
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
@@ -1331,7 +1335,7 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "fused_rowstats") *value = h->opt_fused_rowstats;
     else if (n == "fused_qkv_attn") *value = h->opt_fused_qkv_attn;
     else if (n == "loop_graph") *value = h->opt_loop_graph;
-    else if (n == "bf16_act") *value = h->opt_bf16_act && h->opt_gemm_bf16 && !h->opt_gemm_split;   // only acts in bf16 mode
+    else if (n == "bf16_act") *value = (h->opt_gemm_bf16 && !h->opt_gemm_split) ? h->opt_bf16_act : 0;   // only acts in bf16 mode
     else if (n == "fused_merge") *value = h->opt_fused_merge ? (h->opt_fused_merge_small ? 2 : 1) : 0;
     else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
     else if (n == "gemm_split") *value = h->opt_gemm_split;

@@ -85,7 +85,7 @@ void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, co
                          const float *bqkv, const float *biasT, const float *Wpp, const float *bproj, int B, const WinGeom &g,
                          bool premod, hipStream_t s);   // premod: x is already modulated by the producing kernel
 // qkv [B*T, 3C] token order -> out [B*T, C] token order; biasT [nWt][heads][Wp][Wp] (key-major)
-void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s, bool out_bf16 = false);
+void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s, bool out_bf16 = false, bool in_bf16 = false);
 
 // x <- silu(shift + x*(1+scale)), (scale,shift) = aff[b][off .. off+2C); stats of the new rows
 void launch_mod_stats(float *x, const float *aff, int aff_ld, int aff_off, float *stats, int B, int T, int C, hipStream_t s);

@@ -1228,8 +1228,9 @@ bool launch_fused_patch_embed96(const float *adj, const float *node, const float
 // Relative-position bias and the shifted-window mask (-100) come pre-combined and transposed
 // (key-major) from a dense table built at weight-load time; padded key slots hold -1e30.
 // =================================================================================================
-template <int KT, int WS, bool OBF = false>  // KT 32-token tiles per window (Wp = 32*KT >= WS*WS); WS compile-time: cheap index math;
-                                             // OBF: the output is stored as bf16 (bf16 mode: the proj GEMM rounds it to bf16 anyway)
+template <int KT, int WS, bool OBF = false, bool IBF = false>  // KT 32-token tiles per window (Wp = 32*KT >= WS*WS); WS compile-time:
+                                             // cheap index math; OBF: the output is stored as bf16 (bf16 mode: the proj GEMM rounds it
+                                             // to bf16 anyway); IBF: qkv is a bf16 tensor (widened to fp32 on load, math unchanged)
 __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restrict__ qkv, const float *__restrict__ biasT,
                                                           float *__restrict__ out, int B, WinGeom g, int n_units) {
     constexpr int Wp = 32 * KT, Wt = WS * WS, VLD = 36;
@@ -1261,10 +1262,16 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
             t = ti * res + tj;
         }
         tokr[kt] = t;
-        rowoff[kt] = (unsigned)t * (unsigned)(3 * C) * 4u + 16u * lhalf;
+        rowoff[kt] = IBF ? (unsigned)t * (unsigned)(3 * C) * 2u + 8u * lhalf : (unsigned)t * (unsigned)(3 * C) * 4u + 16u * lhalf;
     }
     // descriptors: the sample's qkv rows / the (window-type, head) bias tile / the sample's output rows
-    const rsrc_t rsQ = make_rsrc(qkv + (size_t)b * T * 3 * C, (unsigned)T * 3u * C * 4u);
+    const rsrc_t rsQ = IBF ? make_rsrc(reinterpret_cast<const unsigned short *>(qkv) + (size_t)b * T * 3 * C, (unsigned)T * 3u * C * 2u)
+                           : make_rsrc(qkv + (size_t)b * T * 3 * C, (unsigned)T * 3u * C * 4u);
+    // q | k | v fragment of this lane: 4 consecutive head dims at 8s + 4*half of head `head`, part 0 / 1 / 2
+    auto qkv_frag = [&](unsigned roff, int part, int s4) -> f32x4 {
+        return IBF ? buf_load4_bf16(rsQ, roff, (unsigned)(part * C) * 2u + (unsigned)head * 64u + 16u * s4)
+                   : buf_load4(rsQ, roff, (unsigned)(part * C) * 4u + (unsigned)head * 128u + 32u * s4);
+    };
     const rsrc_t rsB = make_rsrc(biasT + ((size_t)(g.shift > 0 ? w : 0) * heads + head) * Wp * Wp, (unsigned)(Wp * Wp) * 4u);
     const rsrc_t rsO = OBF ? make_rsrc(reinterpret_cast<unsigned short *>(out) + (size_t)b * T * C, active ? (unsigned)T * C * 2u : 0u)
                            : make_rsrc(out + (size_t)b * T * C, active ? (unsigned)T * C * 4u : 0u);
@@ -1276,10 +1283,10 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) {
 #pragma unroll
-        for (int s = 0; s < 4; s++) kf[kt][s] = buf_load4(rsQ, rowoff[kt], (unsigned)C * 4u + hoff + 32u * s);
+        for (int s = 0; s < 4; s++) kf[kt][s] = qkv_frag(rowoff[kt], 1, s);
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            const f32x4 v = buf_load4(rsQ, rowoff[kt], (unsigned)C * 8u + hoff + 32u * s);
+            const f32x4 v = qkv_frag(rowoff[kt], 2, s);
             *reinterpret_cast<f32x4 *>(vl + (32 * kt + lrow) * VLD + 8 * s + 4 * lhalf) = v;
         }
     }
@@ -1297,7 +1304,7 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
         if (32 * qt >= Wt) break;
         f32x4 qf[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) qf[s] = buf_load4(rsQ, rowoff[qt], hoff + 32u * s);  // pre-scaled by 32^-0.5 * log2(e)
+        for (int s = 0; s < 4; s++) qf[s] = qkv_frag(rowoff[qt], 0, s);  // pre-scaled by 32^-0.5 * log2(e)
         f32x16 sacc[KT];
         float mx = -3.0e38f;
 #pragma unroll
@@ -1346,14 +1353,16 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
     }
 }
 
-void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s, bool out_bf16) {
+void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s, bool out_bf16, bool in_bf16) {
     const int nW = (g.res / g.ws) * (g.res / g.ws);
     const int n_units = B * nW * g.heads;
     const dim3 grid((n_units + 3) / 4), block(256);
-#define WA(KT_, WS_)                                                                                                          \
-    do {                                                                                                                      \
-        if (out_bf16) hipLaunchKernelGGL((window_attn_kernel<KT_, WS_, true>), grid, block, 0, s, qkv, biasT, out, B, g, n_units); \
-        else hipLaunchKernelGGL((window_attn_kernel<KT_, WS_, false>), grid, block, 0, s, qkv, biasT, out, B, g, n_units);         \
+    if (in_bf16 && !out_bf16) { fprintf(stderr, "dsg: launch_window_attn: bf16 qkv is only built with a bf16 output\n"); abort(); }
+#define WA(KT_, WS_)                                                                                                                \
+    do {                                                                                                                            \
+        if (in_bf16) hipLaunchKernelGGL((window_attn_kernel<KT_, WS_, true, true>), grid, block, 0, s, qkv, biasT, out, B, g, n_units);  \
+        else if (out_bf16) hipLaunchKernelGGL((window_attn_kernel<KT_, WS_, true>), grid, block, 0, s, qkv, biasT, out, B, g, n_units);  \
+        else hipLaunchKernelGGL((window_attn_kernel<KT_, WS_, false>), grid, block, 0, s, qkv, biasT, out, B, g, n_units);               \
     } while (0)
     switch (g.ws) {
         case 2: WA(1, 2); break;

@@ -90,6 +90,14 @@ __device__ __forceinline__ unsigned bf16_rne_hi(float x) {
     const unsigned u = __float_as_uint(x);
     return u + 0x7fffu + ((u >> 16) & 1u);
 }
+__device__ __forceinline__ f32x4 buf_load4_bf16(rsrc_t r, unsigned voff, unsigned soff) {   // four consecutive bf16 -> fp32 (exact)
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t u = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    f32x4 v;
+    v[0] = __uint_as_float(u[0] << 16); v[1] = __uint_as_float(u[0] & 0xffff0000u);
+    v[2] = __uint_as_float(u[1] << 16); v[3] = __uint_as_float(u[1] & 0xffff0000u);
+    return v;
+}
 __device__ __forceinline__ void buf_store_bf16(float v, rsrc_t r, unsigned voff, unsigned soff) {   // offsets in bytes (2 per element)
     __builtin_amdgcn_raw_buffer_store_b16((short)(bf16_rne_hi(v) >> 16), r, voff, soff, 0);
 }

@@ -500,9 +500,13 @@ bool launch_gemm_lp(const GemmArgs &g_in, hipStream_t s) {
     if (g.a4_res > 0 || g.attn_bias) return false;               // fp32-kernel-only features
     if (g.a_bf16 || g.c_bf16) {   // bf16 tensors between kernels: only the shapes the forward uses; anything else is a caller bug
         const bool a_ok = g.a_bf16 && !g.c_bf16 && !split && !ln && g.act == ACT_NONE && res && !g.A2 && g.K % HBK == 0;
-        const bool c_ok = g.c_bf16 && !g.a_bf16 && !split && ln && g.act == ACT_GELU && !res && !g.stats_out && !g.C2;
+        const bool c_ok = g.c_bf16 && !g.a_bf16 && !split && ln && (g.act == ACT_GELU || g.act == ACT_NONE) && !res && !g.stats_out && !g.C2;
         if (!a_ok && !c_ok) { fprintf(stderr, "dsg: launch_gemm_lp: unsupported bf16-tensor GEMM\n"); abort(); }
-        if (c_ok) { hipLaunchKernelGGL((gemm_bf16_kernel<true, ACT_GELU, false, 0, false, true>), grid, block, 0, s, g, tiles_m, tiles_n); return true; }
+        if (c_ok) {
+            if (g.act == ACT_GELU) hipLaunchKernelGGL((gemm_bf16_kernel<true, ACT_GELU, false, 0, false, true>), grid, block, 0, s, g, tiles_m, tiles_n);
+            else hipLaunchKernelGGL((gemm_bf16_kernel<true, ACT_NONE, false, 0, false, true>), grid, block, 0, s, g, tiles_m, tiles_n);
+            return true;
+        }
         const int epi = !g.stats_out ? 0 : !g.mod_aff ? 1 : (g.mod_ld == 0 ? 2 : 3);
 #define LP_ABF(E) hipLaunchKernelGGL((gemm_bf16_kernel<false, ACT_NONE, true, E, true, false>), grid, block, 0, s, g, tiles_m, tiles_n)
         if (epi == 0) LP_ABF(0); else if (epi == 1) LP_ABF(1); else if (epi == 2) LP_ABF(2); else LP_ABF(3);

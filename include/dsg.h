@@ -155,9 +155,10 @@ int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t
  *   "gemm_bf16" = 1: the block/merge/breakup GEMMs on bf16 MFMA with operands rounded to bf16 (activations, LayerNorm,
  *       softmax and the sampler stay fp32) -- BASELINE config 5; parity against the fp32 oracle then holds to 1.5e-2 RMS /
  *       5e-2 max-abs of the output scale, not 1e-4.  "gemm_split" takes precedence if both are set.
- *   "bf16_act" (default 1; acts only with "gemm_bf16"): tensors whose only consumer is the bf16 GEMM -- the MLP's hidden
- *       activations, the attention output -- are stored as bf16 by their producer.  The consumer rounds its A operand to bf16
- *       anyway, so results are bit-identical to "bf16_act" = 0; half the bytes, no conversion in the consumer. */
+ *   "bf16_act" (0 / 1 / 2, default 2; acts only with "gemm_bf16"): 1 -- tensors whose only consumer is the bf16 GEMM (the MLP's
+ *       hidden activations, the attention output) are stored as bf16 by their producer; the consumer rounds its A operand to bf16
+ *       anyway, so results are bit-identical to 0, with half the bytes and no conversion in the consumer.  2 -- q, k, v are
+ *       stored as bf16 as well; the attention arithmetic stays fp32 on the widened values, results move within the mode's bar. */
 int dsg_set_option(dsg_handle h, const char *name, int32_t value);
 /* The value an option currently has on this handle (what the next forward will run with), whichever way it was set
  * (dsg_set_option or a DSG_* environment default): measurement code reports the precision mode from here. */
