@@ -19,3 +19,11 @@ bash $R/tools/pmc_mfma.sh > $OUT/pmc_mfma_summary.txt 2>&1
 cp $R/gpurun_out/pmc_mfma_util.json $OUT/ 2>/dev/null
 echo "mfma done"
 DSG_PROFILE_VERBOSE=1 python3 $R/bench.py --steps 1 --warmup 1 --num-steps 50 --no-cpu-baseline > /dev/null 2> $OUT/forward_per_launch_B64.txt
+echo "per-launch done"
+# 4. configs[4]'s per-GPU share in the opt-in bf16 mode (COCO-bits, B=512, T=20): kernel stats and HBM traffic of gemm_bf16_kernel
+rm -rf /tmp/kt5
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt5 -- python3 $R/bench.py --config coco --batch 512 --num-steps 20 --precision bf16 --no-cpu-baseline --no-graph --warmup 0 --steps 1 > $OUT/coco_bf16_under_rocprof.json 2> /dev/null
+cp $(ls /tmp/kt5/*/*kernel_stats.csv | head -1) $OUT/coco_B512_T20_bf16_kernel_stats.csv
+PMC_BENCH_ARGS="--config coco --batch 512 --precision bf16" PMC_RAW=pmc_traffic_raw_coco_bf16.json bash $R/tools/pmc_traffic.sh > $OUT/pmc_traffic_coco_bf16_summary.txt 2>&1
+cp $R/gpurun_out/pmc_traffic_raw_coco_bf16.json $OUT/ 2>/dev/null
+echo "coco bf16 done"
