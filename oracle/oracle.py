@@ -33,9 +33,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        path = os.environ.get("DSGREF_LIB", _LIB_PATH)   # tests/test_oracle_asan.py points this at the AddressSanitizer build
+        if path == _LIB_PATH and not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(path)
         L.dsgref_create.restype = C.c_void_p
         L.dsgref_create.argtypes = [C.c_void_p]
         L.dsgref_destroy.argtypes = [C.c_void_p]
