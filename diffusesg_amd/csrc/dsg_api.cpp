@@ -1590,6 +1590,27 @@ int dsg_profile_forward(dsg_handle h, int32_t B, int32_t n_iters, double *ms_by_
     return DSG_OK;
 }
 
+int32_t dsg_affine_width(dsg_handle h) { return (h && h->finalized) ? h->aff_n : 0; }
+
+int dsg_noise_embed(dsg_handle h, int32_t rows, const float *c_noise, float *out_pe, float *out_emb, float *out_aff, void *stream) {
+    if (!h || !h->finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
+    if (rows < 1 || !c_noise) return fail(h, DSG_ERR_INVALID, "rows / c_noise");
+    hipStream_t s = (hipStream_t)stream;
+    float *tmp = nullptr;   // pe | emb0 | emb | aff
+    const size_t n_pe = (size_t)rows * h->E, n_e = (size_t)rows * NOISE_EMB, n_a = (size_t)rows * h->aff_n;
+    HIP_TRY(h, hipMalloc((void **)&tmp, sizeof(float) * (n_pe + 2 * n_e + n_a)));
+    float *pe = tmp, *emb0 = pe + n_pe, *emb = emb0 + n_e, *aff = emb + n_e;
+    embed_rows(h, c_noise, rows, pe, emb0, emb, aff, s);
+    hipError_t e = hipSuccess;
+    if (out_pe) e = hipMemcpyAsync(out_pe, pe, sizeof(float) * n_pe, hipMemcpyDeviceToDevice, s);
+    if (out_emb && e == hipSuccess) e = hipMemcpyAsync(out_emb, emb, sizeof(float) * n_e, hipMemcpyDeviceToDevice, s);
+    if (out_aff && e == hipSuccess) e = hipMemcpyAsync(out_aff, aff, sizeof(float) * n_a, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    HIP_TRY(h, e);
+    return DSG_OK;
+}
+
 int dsg_debug_gemm(int32_t M, int32_t N, int32_t K, const float *A, const float *W, const float *bias, const float *ln_stats,
                    const float *res, int32_t act, int32_t mode, float *C, void *stream) {
     if (M < 1 || N < 1 || K < 32 || K % 32 != 0 || !A || !W || !C || act < 0 || act > 2 || mode < 0 || mode > 2) return DSG_ERR_INVALID;

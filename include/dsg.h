@@ -199,6 +199,14 @@ int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node
 int dsg_debug_gemm(int32_t M, int32_t N, int32_t K, const float *A, const float *W, const float *bias, const float *ln_stats,
                    const float *res, int32_t act, int32_t mode, float *C, void *stream);
 
+/* The noise-conditioning path on its own (test / inspection hook for SURVEY fixture G1): PositionalEmbedding -> map_layer0/1 with
+ * SiLU (R/model/diffusesg/diffusesg.py:507-513, :768-771) -> every `affine` linear (:238, :574) for `rows` noise labels c_noise
+ * (device, [rows]).  out_pe [rows, embed_dim], out_emb [rows, 512], out_aff [rows, dsg_affine_width(h)] (any may be NULL):
+ * (scale | shift) of patch_embed, then of down_layers[l].blocks[j], then of up_layers[i].blocks[j] -- the table dsg_sample builds
+ * once per call for all its steps. */
+int dsg_noise_embed(dsg_handle h, int32_t rows, const float *c_noise, float *out_pe, float *out_emb, float *out_aff, void *stream);
+int32_t dsg_affine_width(dsg_handle h);
+
 /* ---- training-time forward (first half: what a test-loss / training step computes before backward) ----
  * No handle: these only need the tensor dimensions.  Return DSG_OK / DSG_ERR_INVALID / DSG_ERR_HIP.
  *

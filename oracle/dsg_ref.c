@@ -352,7 +352,7 @@ static float *patch_breakup(dsgref *h, const char *prefix, const float *x, int r
 }
 
 /* PositionalEmbedding + map_layer0/1 (diffusesg.py:507-513, 768-771) */
-static void noise_embedding(dsgref *h, float c_noise, float *emb /*[512]*/) {
+static void noise_embedding_pe(dsgref *h, float c_noise, float *emb /*[512]*/, float *pe_out /*[E] or NULL*/) {
     const int E = h->E, half = E / 2;
     float *pe = (float *)malloc(sizeof(float) * E);
     for (int k = 0; k < half; k++) {
@@ -366,7 +366,14 @@ static void noise_embedding(dsgref *h, float c_noise, float *emb /*[512]*/) {
     for (int i = 0; i < NOISE_EMB; i++) t0[i] = silu_f(t0[i]);
     linear(W(h, "%s", "map_layer1.weight"), W(h, "%s", "map_layer1.bias")->data, t0, emb, 1, NOISE_EMB, NOISE_EMB);
     for (int i = 0; i < NOISE_EMB; i++) emb[i] = silu_f(emb[i]);
+    if (pe_out) memcpy(pe_out, pe, sizeof(float) * E);
     free(pe); free(t0);
+}
+static void noise_embedding(dsgref *h, float c_noise, float *emb) { noise_embedding_pe(h, c_noise, emb, NULL); }
+/* stand-alone: PositionalEmbedding rows [rows, E] and the mapped embedding [rows, 512] (test hook for survey fixture G1) */
+int dsgref_noise_embed(dsgref *h, int rows, const float *c_noise, float *pe, float *emb) {
+    for (int r = 0; r < rows; r++) noise_embedding_pe(h, c_noise[r], emb + (size_t)r * NOISE_EMB, pe + (size_t)r * h->E);
+    return 0;
 }
 
 /* DiffuseSG.forward for ONE sample (diffusesg.py:765-830 with forward_features :739-763) */

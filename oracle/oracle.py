@@ -52,6 +52,7 @@ def lib():
         L.dsgref_train_inputs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 10
         L.dsgref_rainbow_loss.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_void_p] * 2
         L.dsgref_rainbow_loss_backward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_void_p] * 5
+        L.dsgref_noise_embed.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
         L.dsgref_decode_bits.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 3
         _lib = L
     return _lib
@@ -181,6 +182,13 @@ class Oracle:
         na, nn = np.empty(sa, np.float32), np.empty(sn, np.float32)
         lib().dsgref_train_inputs(self._h, B, _p(ca), _p(cn), _p(fl), _p(rn), _p(ea), _p(en), _p(sig), _p(wts), _p(na), _p(nn))
         return sig, wts, na, nn
+
+    def noise_embed(self, c_noise):
+        """PositionalEmbedding + map_layer0/1 (diffusesg.py:507-513, :768-771) -> (pe [rows,E], emb [rows,512])"""
+        c = _f32(c_noise).reshape(-1)
+        pe, emb = np.empty((c.size, self.cfg.embed_dim), np.float32), np.empty((c.size, 512), np.float32)
+        lib().dsgref_noise_embed(self._h, c.size, _p(c), _p(pe), _p(emb))
+        return pe, emb
 
     def rainbow_loss_backward(self, pred_adj, pred_node, tgt_adj, tgt_node, flags, loss_weight=None, edge_w=1.0, node_w=1.0, iou_w=0.0,
                               sigmas=None):

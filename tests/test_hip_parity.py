@@ -929,6 +929,27 @@ def test_train_forward_vs_reference_fixture():
         eval_loss_step(net_for("tiny"), gen, loss_func, T(clean_adj), T(clean_node), T(flags), mode="train")
 
 
+@pytest.mark.parametrize("name", ["tiny", "vg", "coco"])
+def test_noise_embedding_standalone_vs_reference(name):
+    """survey fixture G1 (tests/golden/noise_embed.npz): PositionalEmbedding, map_layer0/1 + SiLU and every affine linear's
+    (scale | shift) row -- the table dsg_sample builds once per call -- through dsg_noise_embed, against the reference modules"""
+    import ctypes as C
+    from diffusesg_amd.model import build_network
+    g = load("noise_embed.npz")
+    cfg = Y.CONFIGS[name]()
+    h = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda").model._ensure_handle()
+    rows, width = len(g["c_noise"]), h.L.dsg_affine_width(h._h)
+    pe, emb, aff = torch.empty(rows, cfg.embed_dim, device="cuda"), torch.empty(rows, 512, device="cuda"), torch.empty(rows, width, device="cuda")
+    c = T(g["c_noise"])
+    h.check(h.L.dsg_noise_embed(h._h, rows, C.c_void_p(c.data_ptr()), C.c_void_p(pe.data_ptr()), C.c_void_p(emb.data_ptr()),
+                                C.c_void_p(aff.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "dsg_noise_embed")
+    assert_close(pe.cpu().numpy(), g[f"{name}_pe"], 2e-6, "positional embedding")
+    assert_close(emb.cpu().numpy(), g[f"{name}_emb"], 1e-5, "mapped noise embedding")
+    if f"{name}_aff" in g.files:
+        assert width == g[f"{name}_aff"].shape[1]
+        assert_close(aff.cpu().numpy(), g[f"{name}_aff"], 1e-5, "affine (scale | shift) table")
+
+
 def test_train_backward_head_vs_reference_autograd():
     """tests/golden/train_backward.npz (the reference's own autograd over one training step): dL/d(preconditioned outputs) incl.
     the IoU term's clamp / max / min branches, and dL/d(raw network outputs) = c_out(sigma) * that -- the first stage of the

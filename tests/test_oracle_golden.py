@@ -167,3 +167,14 @@ def test_train_backward_head_matches_reference_autograd():
     # the fixture is internally consistent: the recorded total norm is the norm of the recorded per-tensor norms
     assert abs(float(np.sqrt((g["tiny_gparam_norms"] ** 2).sum())) - float(g["tiny_total_grad_norm"])) < 1e-3 * float(g["tiny_total_grad_norm"])
     assert len(g["tiny_gparam_names"]) == len([k for k in g.files if k.startswith("tiny_gparam/")])
+
+
+@pytest.mark.parametrize("name", ["tiny", "vg", "coco"])
+def test_noise_embedding_standalone_matches_reference(name):
+    """survey fixture G1: PositionalEmbedding and the map MLP on their own (diffusesg.py:507-513, :768-771) against
+    tests/golden/noise_embed.npz, over c_noise = ln(sigma)/4 for sigma from 1e-4 to 80"""
+    g = load("noise_embed.npz")
+    cfg = Y.CONFIGS[name]()
+    pe, emb = make_oracle(cfg).noise_embed(g["c_noise"])
+    assert_close(pe, g[f"{name}_pe"], 2e-6, "positional embedding")
+    assert_close(emb, g[f"{name}_emb"], 1e-5, "mapped noise embedding")

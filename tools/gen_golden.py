@@ -478,6 +478,32 @@ def gen_train_backward(DiffuseSG, NodeAdjPrecond, out):
     np.savez_compressed(os.path.join(out, "train_backward.npz"), **res)
 
 
+def gen_noise_embed(DiffuseSG, out):
+    """G1 (stand-alone): the noise-conditioning path on its own -- PositionalEmbedding (`map_noise`), map_layer0/1 with SiLU
+    (diffusesg.py:768-771) and every `affine` linear applied to the embedding (PatchEmbed :574, the Swin blocks :238), concatenated
+    in module order: patch_embed, down_layers[l].blocks[j], up_layers[i].blocks[j]."""
+    from torch.nn.functional import silu
+    res = {}
+    c_noise = np.array([-2.3, -0.35, 0.4, 1.0955], np.float32)   # ln(sigma)/4 for sigma in [1e-4, 80]
+    res["c_noise"] = c_noise
+    for name in ("tiny", "vg", "coco"):
+        cfg = CONFIGS[name]()
+        net = build_ref_net(DiffuseSG, cfg)
+        with torch.no_grad():
+            pe = net.map_noise(t(c_noise))
+            emb = silu(net.map_layer1(silu(net.map_layer0(pe))))
+            aff = [net.patch_embed.affine(emb)]
+            for l in net.down_layers:
+                aff += [b.affine(emb) for b in l.blocks]
+            for l in net.up_layers:
+                aff += [b.affine(emb) for b in l.blocks]
+        res[f"{name}_pe"], res[f"{name}_emb"] = pe.numpy(), emb.numpy()
+        if name != "coco":   # (kept small: COCO's 11328 affine outputs add nothing the VG table does not exercise)
+            res[f"{name}_aff"] = torch.cat(aff, dim=1).numpy()
+        print(f"noise embed {name}: pe {tuple(pe.shape)} emb {tuple(emb.shape)} affine outputs {sum(a.shape[1] for a in aff)}")
+    np.savez_compressed(os.path.join(out, "noise_embed.npz"), **res)
+
+
 def check_channel_table():
     """diffusesg_amd.spec.sg_channels (data restated from sg_utils.py:348-409) against the imported reference function."""
     from utils.sg_utils import get_node_adj_num_type
@@ -508,6 +534,8 @@ def main():
         gen_train_forward(DiffuseSG, NodeAdjPrecond, args.out)
     if args.only in ("", "train", "train_bwd"):
         gen_train_backward(DiffuseSG, NodeAdjPrecond, args.out)
+    if args.only in ("", "noise"):
+        gen_noise_embed(DiffuseSG, args.out)
     if args.only in ("", "fwd"):
         gen_forward(DiffuseSG, args.out)
     if args.only in ("", "precond"):
