@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """profiles/rN/pmc_traffic.json from the raw per-kernel counter sums tools/pmc_traffic.sh leaves in pmc_traffic_raw.json.
 Units and corrections as MI355X_MICROARCH.md §HBM prescribes: counter values are KiB; on gfx950 FETCH_SIZE reports half
-of the bytes of wide coalesced reads, so it is doubled; WRITE_SIZE is taken as read (exact for 16-B/lane stores and float
-atomics, uncalibrated for the 4-B/lane stores of the GEMM epilogue)."""
+of the bytes of wide coalesced reads, so it is doubled; WRITE_SIZE is taken as read: exact for 16-B/lane stores and, by
+tools/pmc_write_cal.sh (profiles/r2/write_size_cal.txt), also for 4-B/lane row stores and the GEMM epilogue's two-row store shape."""
 import collections
 import json
 import sys
@@ -23,7 +23,7 @@ for tag, key in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
 out = {"source": f"tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --no-graph --num-steps 3 "
                  f"--warmup 0 --no-cpu-baseline`, MI355X, round {rnd[1:]}",
        "units": "bytes; counter values are KiB; FETCH_SIZE doubled (gfx950 reports 1/2 of 16-B/lane coalesced reads, MI355X_MICROARCH.md §HBM); "
-                "WRITE_SIZE as read (4-B/lane stores: uncalibrated width)",
+                "WRITE_SIZE as read (calibrated 1.0000 for 4-B/lane and 16-B/lane stores: profiles/r2/write_size_cal.txt)",
        "kernels": {}, "instantiations": {}}
 for f, v in sorted(fam.items(), key=lambda kv: -(kv[1]["fetch"] + kv[1]["write"])):
     if v["launches"] == 0:
