@@ -74,6 +74,12 @@ class DiffuseSGHip(nn.Module):
         if self._handle is None:
             if not torch.cuda.is_available():
                 raise _lib.DsgError("DiffuseSGHip needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
+            # one process per GPU: the library allocates and launches on the CURRENT HIP device; a model placed on another one
+            # would mix devices silently, so insist (torchrun ranks call torch.cuda.set_device(LOCAL_RANK) first, as bench.py does)
+            idx = self._dev.index if self._dev.index is not None else torch.cuda.current_device()
+            if idx != torch.cuda.current_device():
+                raise _lib.DsgError(f"model is on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}: "
+                                    f"call torch.cuda.set_device({idx}) before the first forward (one process per GPU)")
             self._handle = _lib.Handle(self.config)
         ver = self._weights_version()
         if ver != self._synced_version:
