@@ -1667,6 +1667,58 @@ int dsg_rainbow_loss_backward(int32_t B, int32_t N, int32_t c_adj, int32_t c_nod
     return hipGetLastError() == hipSuccess ? DSG_OK : DSG_ERR_HIP;
 }
 
+int dsg_block_train(dsg_handle h, const char *block, int32_t B, const float *x_in, const float *emb, const float *grad_out, float *x_out,
+                    float *grad_in, float *grad_emb, int32_t n_params, const char *const *names, float *const *grad_params, void *stream) {
+    if (!h || !h->finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
+    if (!block || B < 1 || !x_in || !emb || !x_out) return fail(h, DSG_ERR_INVALID, "null argument");
+    const BlockPlan *bp = nullptr;
+    for (int l = 0; l < h->L; l++)
+        for (auto *vec : {&h->down[l], &h->up[l]})
+            for (auto &b : *vec) if (b.prefix == block) bp = &b;
+    if (!bp) return fail(h, DSG_ERR_INVALID, "no block '%s'", block);
+    static const char *kNames[15] = {"affine.weight", "affine.bias", "norm1.weight", "norm1.bias", "attn.relative_position_bias_table",
+                                     "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "norm2.weight",
+                                     "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"};
+    TrainBlockArgs a{};
+    float **Wp[15] = {&a.W.aff_w, &a.W.aff_b, &a.W.n1_w, &a.W.n1_b, &a.W.rpb, &a.W.qkv_w, &a.W.qkv_b, &a.W.proj_w, &a.W.proj_b,
+                      &a.W.n2_w, &a.W.n2_b, &a.W.fc1_w, &a.W.fc1_b, &a.W.fc2_w, &a.W.fc2_b};
+    float **Gp[15] = {&a.G.aff_w, &a.G.aff_b, &a.G.n1_w, &a.G.n1_b, &a.G.rpb, &a.G.qkv_w, &a.G.qkv_b, &a.G.proj_w, &a.G.proj_b,
+                      &a.G.n2_w, &a.G.n2_b, &a.G.fc1_w, &a.G.fc1_b, &a.G.fc2_w, &a.G.fc2_b};
+    for (int i = 0; i < 15; i++) {
+        auto it = h->w.find(bp->prefix + "." + kNames[i]);
+        if (it == h->w.end()) return fail(h, DSG_ERR_STATE, "weight '%s.%s' is not loaded", block, kNames[i]);
+        *Wp[i] = it->second.p;
+    }
+    if (grad_out) {
+        if (!grad_in || !grad_emb || !names || !grad_params) return fail(h, DSG_ERR_INVALID, "backward needs grad_in, grad_emb and the parameter gradient buffers");
+        for (int i = 0; i < 15; i++) {
+            float *dst = nullptr;
+            for (int k = 0; k < n_params; k++) if (names[k] && !strcmp(names[k], kNames[i])) dst = grad_params[k];
+            if (!dst) return fail(h, DSG_ERR_INVALID, "no gradient buffer for '%s'", kNames[i]);
+            *Gp[i] = dst;
+        }
+    }
+    a.B = B; a.res = bp->res; a.ws = bp->ws; a.shift = bp->shift; a.heads = bp->heads; a.C = bp->C; a.hidden = h->cfg.mlp_ratio * bp->C;
+    a.x_in = x_in; a.emb = emb; a.grad_out = grad_out; a.x_out = x_out; a.grad_in = grad_in; a.grad_emb = grad_emb;
+    const size_t M = (size_t)B * a.res * a.res, C = a.C, H = a.hidden;
+    const size_t sizes[17] = {(size_t)B * 2 * C, (size_t)B * 2 * C, M * C, M * C, M * C, M * C, M * C, M * C, M * C, M * C, M * 2, M * 2,
+                              M * 3 * C, M * 3 * C, M * H, M * H, M * H};
+    float **slots[17] = {&a.aff, &a.d_aff, &a.x_mod, &a.xn1, &a.att, &a.x1, &a.xn2, &a.d_x1, &a.t_mc, &a.t_mc2, &a.stats1, &a.stats2,
+                         &a.qkv, &a.t_m3c, &a.pre, &a.hid, &a.t_mh};
+    size_t total = 0;
+    for (size_t v : sizes) total += (v + 63) / 64 * 64;
+    float *scratch = nullptr;
+    HIP_TRY(h, hipMalloc((void **)&scratch, sizeof(float) * total));
+    size_t off = 0;
+    for (int i = 0; i < 17; i++) { *slots[i] = scratch + off; off += (sizes[i] + 63) / 64 * 64; }
+    const bool ok = train_block(a, (hipStream_t)stream);
+    const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(scratch);
+    HIP_TRY(h, e);
+    if (!ok) return fail(h, DSG_ERR_HIP, "train_block failed (window larger than 128 tokens or a launch error)");
+    return DSG_OK;
+}
+
 double dsg_profile_clock_ghz(dsg_handle h) { return h ? h->prof_clock_ghz : 0.0; }
 
 int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, int32_t n_adj_type,

@@ -157,6 +157,21 @@ void launch_train_inputs(CStatePtrs clean, const float *rnd, CStatePtrs eps, uin
 // trainer_node_adj.py:130-159); one block per sample, fixed-order reduction
 void launch_rainbow_loss(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w,
                          float *loss_adj, float *loss_node, Dims d, hipStream_t s);
+// ---- training-time block (train_kernels.hip; correctness-first kernels, not on the sampling path) ----
+struct TrainBlockParams {   // the 15 parameter tensors of a SwinTransformerBlock, reference layouts ([out, in] linears)
+    float *aff_w, *aff_b, *n1_w, *n1_b, *rpb, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2_w, *n2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+};
+struct TrainBlockArgs {
+    int B, res, ws, shift, heads, C, hidden;
+    TrainBlockParams W, G;                 // weights (read) and their gradients (written)
+    const float *x_in, *emb, *grad_out;    // [B*T, C], [B, 512], [B*T, C] or null (forward only)
+    float *x_out, *grad_in, *grad_emb;     // [B*T, C], [B*T, C], [B, 512]
+    // saved forward tensors and scratch (caller-allocated): aff / d_aff [B, 2C]; x_mod, xn1, att, x1, xn2, d_x1, t_mc, t_mc2 [M, C];
+    // stats1, stats2 [M, 2]; qkv, t_m3c [M, 3C]; pre, hid, t_mh [M, hidden]
+    float *aff, *d_aff, *x_mod, *xn1, *att, *x1, *xn2, *d_x1, *t_mc, *t_mc2, *stats1, *stats2, *qkv, *t_m3c, *pre, *hid, *t_mh;
+};
+bool train_block(const TrainBlockArgs &a, hipStream_t s);
+
 void launch_rainbow_loss_backward(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w,
                                   float iou_w, const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d, hipStream_t s);
 void launch_decode_bits(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,

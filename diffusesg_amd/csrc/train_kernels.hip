@@ -1,0 +1,344 @@
+// train_kernels.hip -- training-time kernels of one SwinTransformerBlock (second half, first piece): the block's
+// forward in the form that keeps what the backward needs, and its backward.  R = DiffuseSG/ of the reference.
+//
+//   forward   R/model/diffusesg/diffusesg.py:232-277 (block), :108-139 (WindowAttention), :19-25 (Mlp)
+//   backward  what torch.autograd derives for those lines; checked against the reference's own autograd
+//             (tests/golden/block_backward.npz, tools/gen_golden.py::gen_block_backward)
+//
+// CORRECTNESS FIRST: these are straightforward fp32 kernels (an LDS-tiled FMA GEMM, one thread per element / row / window row),
+// NOT the MFMA kernels of the sampling path -- they exist so that every gradient formula is pinned to the reference before the
+// fast versions are written.  Nothing on the sampling path calls into this file.
+#include "kernels_common.hip.h"
+
+#include <stdio.h>
+
+namespace dsg {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C[M,N] (+)= op(A) op(B) (+ bias[n]);  op(A)(m,k) = TA ? A[k*lda+m] : A[m*lda+k];  op(B)(k,n) = TB ? B[n*ldb+k] : B[k*ldb+n]
+// 32x32 tile per 256-thread block, 4 outputs per thread, k in chunks of 32, fixed summation order (deterministic).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void t_gemm_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                     const float *__restrict__ bias, float *__restrict__ C, int ldc, int M, int N, int K,
+                                                     int accumulate) {
+    __shared__ float As[32][33], Bs[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // ty 0..7
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int r = ty + 8 * i;   // tile row
+            {   // As[r][tx] = op(A)(m0 + r, k0 + tx)
+                const int m = m0 + r, k = k0 + tx;
+                float v = 0.f;
+                if (TA) { const int mm = m0 + tx, kk = k0 + r; v = (mm < M && kk < K) ? A[(size_t)kk * lda + mm] : 0.f; As[tx][r] = v; }
+                else { v = (m < M && k < K) ? A[(size_t)m * lda + k] : 0.f; As[r][tx] = v; }
+            }
+            {   // Bs[r][tx] = op(B)(k0 + r, n0 + tx)
+                float v = 0.f;
+                if (TB) { const int nn = n0 + r, kk = k0 + tx; v = (nn < N && kk < K) ? B[(size_t)nn * ldb + kk] : 0.f; Bs[tx][r] = v; }
+                else { const int kk = k0 + r, nn = n0 + tx; v = (kk < K && nn < N) ? B[(size_t)kk * ldb + nn] : 0.f; Bs[r][tx] = v; }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 32; kk++) {
+            const float b = Bs[kk][tx];
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[i] = fmaf(As[ty + 8 * i][kk], b, acc[i]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int m = m0 + ty + 8 * i, n = n0 + tx;
+        if (m < M && n < N) {
+            float v = acc[i] + (bias ? bias[n] : 0.f);
+            if (accumulate) v += C[(size_t)m * ldc + n];
+            C[(size_t)m * ldc + n] = v;
+        }
+    }
+}
+void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K,
+            bool accumulate, hipStream_t s) {
+    const dim3 grid((N + 31) / 32, (M + 31) / 32), block(256);
+    if (!ta && !tb) hipLaunchKernelGGL((t_gemm_kernel<false, false>), grid, block, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, (int)accumulate);
+    else if (!ta && tb) hipLaunchKernelGGL((t_gemm_kernel<false, true>), grid, block, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, (int)accumulate);
+    else if (ta && !tb) hipLaunchKernelGGL((t_gemm_kernel<true, false>), grid, block, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, (int)accumulate);
+    else hipLaunchKernelGGL((t_gemm_kernel<true, true>), grid, block, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, (int)accumulate);
+}
+
+// out[n] = sum_m X[m*ld + n] (double accumulation, fixed order: one thread per column)
+__global__ void t_colsum_kernel(const float *X, int ld, float *out, int M, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s = 0.0;
+    for (int m = 0; m < M; m++) s += (double)X[(size_t)m * ld + n];
+    out[n] = (float)s;
+}
+void t_colsum(const float *X, int ld, float *out, int M, int N, hipStream_t s) {
+    hipLaunchKernelGGL(t_colsum_kernel, dim3((N + 63) / 64), dim3(64), 0, s, X, ld, out, M, N);
+}
+
+__device__ __forceinline__ float t_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// y = silu(shift_b + x (1 + scale_b))   (diffusesg.py:238-240); aff [B][2C] = (scale | shift)
+__global__ void t_modulate_fwd_kernel(const float *x, const float *aff, float *y, int T, int C, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = i % C;
+    const size_t b = i / ((size_t)T * C);
+    const float u = aff[b * 2 * C + C + c] + x[i] * (aff[b * 2 * C + c] + 1.0f);
+    y[i] = u * t_sigmoid(u);
+}
+// dx = du (1 + scale), du = dy silu'(u); d_aff[b] = (sum_t du x | sum_t du): one thread per (b, c), tokens in order
+__global__ void t_modulate_bwd_kernel(const float *x, const float *aff, const float *dy, float *dx, float *d_aff, int B, int T, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i % C;
+    const float sc = aff[(size_t)b * 2 * C + c] + 1.0f, sh = aff[(size_t)b * 2 * C + C + c];
+    double ds = 0.0, dh = 0.0;
+    for (int t = 0; t < T; t++) {
+        const size_t k = ((size_t)b * T + t) * C + c;
+        const float xv = x[k], u = sh + xv * sc, sg = t_sigmoid(u);
+        const float du = dy[k] * (sg * (1.0f + u * (1.0f - sg)));
+        dx[k] = du * sc;
+        ds += (double)(du * xv);
+        dh += (double)du;
+    }
+    d_aff[(size_t)b * 2 * C + c] = (float)ds;
+    d_aff[(size_t)b * 2 * C + C + c] = (float)dh;
+}
+
+// LayerNorm with affine: one thread per row (C <= 768 here; naive).  stats[m] = (mean, rstd)
+__global__ void t_ln_fwd_kernel(const float *x, const float *gam, const float *bet, float *y, float *stats, int M, int C) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float *r = x + (size_t)m * C;
+    double s = 0.0;
+    for (int c = 0; c < C; c++) s += (double)r[c];
+    const float mean = (float)(s / C);
+    double v = 0.0;
+    for (int c = 0; c < C; c++) { const float d = r[c] - mean; v += (double)(d * d); }
+    const float rstd = 1.0f / sqrtf((float)(v / C) + LN_EPS);
+    for (int c = 0; c < C; c++) y[(size_t)m * C + c] = (r[c] - mean) * rstd * gam[c] + bet[c];
+    stats[2 * (size_t)m] = mean; stats[2 * (size_t)m + 1] = rstd;
+}
+// dx (ADDED to dx_acc) = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;  xhat_dy[m][c] = dy xhat (for d_gamma = colsum)
+__global__ void t_ln_bwd_kernel(const float *x, const float *gam, const float *stats, const float *dy, float *dx_acc, float *xhat_dy, int M, int C) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float mean = stats[2 * (size_t)m], rstd = stats[2 * (size_t)m + 1];
+    const float *r = x + (size_t)m * C, *d = dy + (size_t)m * C;
+    double sg = 0.0, sgx = 0.0;
+    for (int c = 0; c < C; c++) {
+        const float xh = (r[c] - mean) * rstd, g = d[c] * gam[c];
+        sg += (double)g; sgx += (double)(g * xh);
+        xhat_dy[(size_t)m * C + c] = d[c] * xh;
+    }
+    const float mg = (float)(sg / C), mgx = (float)(sgx / C);
+    for (int c = 0; c < C; c++) {
+        const float xh = (r[c] - mean) * rstd, g = d[c] * gam[c];
+        dx_acc[(size_t)m * C + c] += rstd * (g - mg - xh * mgx);
+    }
+}
+
+// exact-erf GELU and its derivative  Phi(x) + x phi(x)
+__global__ void t_gelu_fwd_kernel(const float *x, float *y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = 0.5f * x[i] * (1.0f + erff(x[i] * 0.70710678118654752f));
+}
+__global__ void t_gelu_bwd_kernel(const float *x, const float *dy, float *dx, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i];
+    dx[i] = dy[i] * (0.5f * (1.0f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v));
+}
+__global__ void t_add_kernel(float *a, const float *b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += b[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Window attention core, forward and backward, one block per (sample, window, head); thread i owns query row i (and, in the
+// column passes of the backward, key/value row i).  qkv [B*T][3C] token-major (as the QKV linear writes it), out / d_out [B*T][C].
+//   S = scale q k^T + table[index(i,j)][h] (+ -100 where the shifted window's regions differ);  P = softmax_j S;  O = P v
+// token of (window (wi,wj), position p): rolled coordinate r = (wi ws + p / ws, wj ws + p % ws), original (r + shift) mod res.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TAttnGeom { int res, ws, shift, heads, C; };
+__device__ __forceinline__ int t_token_of(const TAttnGeom &g, int w, int p, int &ri, int &rj) {
+    const int nwr = g.res / g.ws, wi = w / nwr, wj = w % nwr;
+    ri = wi * g.ws + p / g.ws; rj = wj * g.ws + p % g.ws;
+    int ti = ri + g.shift, tj = rj + g.shift;
+    if (ti >= g.res) ti -= g.res;
+    if (tj >= g.res) tj -= g.res;
+    return ti * g.res + tj;
+}
+__device__ __forceinline__ int t_region(const TAttnGeom &g, int r) { return r < g.res - g.ws ? 0 : (r < g.res - g.shift ? 1 : 2); }
+
+template <bool BWD>
+__global__ void t_attn_kernel(const float *qkv, const float *table, float *out, const float *d_out, float *d_qkv, float *d_table,
+                              TAttnGeom g) {
+    extern __shared__ float sm[];
+    const int Wt = g.ws * g.ws, HD = g.C / g.heads, LD = HD + 1;
+    float *qs = sm, *ks = qs + Wt * LD, *vs = ks + Wt * LD, *dos = vs + Wt * LD, *Ps = dos + (BWD ? Wt * LD : 0);   // Ps [Wt][Wt+1]
+    const int nW = (g.res / g.ws) * (g.res / g.ws), T = g.res * g.res;
+    const int h = blockIdx.x % g.heads, w = (blockIdx.x / g.heads) % nW, b = blockIdx.x / (g.heads * nW);
+    const int i = threadIdx.x;
+    const float scale = 1.0f / sqrtf((float)HD);
+    int ri = 0, rj = 0, tok = 0, reg = 0;
+    if (i < Wt) {
+        tok = t_token_of(g, w, i, ri, rj);
+        reg = g.shift > 0 ? 3 * t_region(g, ri) + t_region(g, rj) : 0;
+        const float *row = qkv + ((size_t)b * T + tok) * 3 * g.C + h * HD;
+        for (int d = 0; d < HD; d++) { qs[i * LD + d] = row[d]; ks[i * LD + d] = row[g.C + d]; vs[i * LD + d] = row[2 * g.C + d]; }
+        if (BWD) { const float *dr = d_out + ((size_t)b * T + tok) * g.C + h * HD; for (int d = 0; d < HD; d++) dos[i * LD + d] = dr[d]; }
+    }
+    __shared__ int regs[128];
+    if (i < Wt) regs[i] = reg;
+    __syncthreads();
+    const int yi = i / g.ws, xi = i % g.ws;
+    if (i < Wt) {   // row i of P
+        float mx = -3.0e38f;
+        for (int j = 0; j < Wt; j++) {
+            float s = 0.f;
+            for (int d = 0; d < HD; d++) s = fmaf(qs[i * LD + d], ks[j * LD + d], s);
+            const int idx = (yi - j / g.ws + g.ws - 1) * (2 * g.ws - 1) + (xi - j % g.ws + g.ws - 1);
+            s = s * scale + table[(size_t)idx * g.heads + h];
+            if (g.shift > 0 && regs[j] != reg) s += -100.0f;
+            Ps[i * (Wt + 1) + j] = s;
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < Wt; j++) { const float e = expf(Ps[i * (Wt + 1) + j] - mx); Ps[i * (Wt + 1) + j] = e; sum += e; }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < Wt; j++) Ps[i * (Wt + 1) + j] *= inv;
+        if (!BWD) {
+            float *o = out + ((size_t)b * T + tok) * g.C + h * HD;
+            for (int d = 0; d < HD; d++) {
+                float a = 0.f;
+                for (int j = 0; j < Wt; j++) a = fmaf(Ps[i * (Wt + 1) + j], vs[j * LD + d], a);
+                o[d] = a;
+            }
+        }
+    }
+    if (!BWD) return;
+    __syncthreads();
+    float *dq = d_qkv + ((size_t)b * T + tok) * 3 * g.C + h * HD;
+    if (i < Wt) {   // column pass 1: dV[i] = sum_q P[q][i] dO[q]
+        for (int d = 0; d < HD; d++) {
+            float a = 0.f;
+            for (int q = 0; q < Wt; q++) a = fmaf(Ps[q * (Wt + 1) + i], dos[q * LD + d], a);
+            dq[2 * g.C + d] = a;
+        }
+    }
+    __syncthreads();
+    if (i < Wt) {   // row pass: dS[i][j] = P (dP - sum_j dP P), overwriting P; the bias gradient; dQ[i] = scale sum_j dS[i][j] k[j]
+        float tsum = 0.f;
+        for (int j = 0; j < Wt; j++) {
+            float dp = 0.f;
+            for (int d = 0; d < HD; d++) dp = fmaf(dos[i * LD + d], vs[j * LD + d], dp);
+            tsum = fmaf(dp, Ps[i * (Wt + 1) + j], tsum);
+        }
+        for (int j = 0; j < Wt; j++) {
+            float dp = 0.f;
+            for (int d = 0; d < HD; d++) dp = fmaf(dos[i * LD + d], vs[j * LD + d], dp);
+            const float ds = Ps[i * (Wt + 1) + j] * (dp - tsum);
+            Ps[i * (Wt + 1) + j] = ds;
+            const int idx = (yi - j / g.ws + g.ws - 1) * (2 * g.ws - 1) + (xi - j % g.ws + g.ws - 1);
+            atomicAdd(d_table + (size_t)idx * g.heads + h, ds);
+        }
+        for (int d = 0; d < HD; d++) {
+            float a = 0.f;
+            for (int j = 0; j < Wt; j++) a = fmaf(Ps[i * (Wt + 1) + j], ks[j * LD + d], a);
+            dq[d] = a * scale;
+        }
+    }
+    __syncthreads();
+    if (i < Wt) {   // column pass 2: dK[i] = scale sum_q dS[q][i] q[q]
+        for (int d = 0; d < HD; d++) {
+            float a = 0.f;
+            for (int q = 0; q < Wt; q++) a = fmaf(Ps[q * (Wt + 1) + i], qs[q * LD + d], a);
+            dq[g.C + d] = a * scale;
+        }
+    }
+}
+static bool t_attn_launch(bool bwd, const float *qkv, const float *table, float *out, const float *d_out, float *d_qkv, float *d_table,
+                          int B, TAttnGeom g, hipStream_t s) {
+    const int Wt = g.ws * g.ws, HD = g.C / g.heads, LD = HD + 1;
+    if (Wt > 128) return false;
+    const size_t lds = sizeof(float) * ((size_t)(bwd ? 4 : 3) * Wt * LD + (size_t)Wt * (Wt + 1));
+    const int nW = (g.res / g.ws) * (g.res / g.ws);
+    const dim3 grid(B * nW * g.heads), block(128);
+    if (bwd) {
+        if (hipFuncSetAttribute((const void *)t_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        hipLaunchKernelGGL((t_attn_kernel<true>), grid, block, lds, s, qkv, table, out, d_out, d_qkv, d_table, g);
+    } else {
+        if (hipFuncSetAttribute((const void *)t_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        hipLaunchKernelGGL((t_attn_kernel<false>), grid, block, lds, s, qkv, table, out, d_out, d_qkv, d_table, g);
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One block, forward (training form) + backward.  All buffers caller-provided (see dsg_block_train in dsg_api.cpp).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int NOISE_EMB = 512;   // width of the mapped noise embedding (diffusesg.py: noise_emb_channels)
+static inline unsigned t_blocks(size_t n) { return (unsigned)((n + 255) / 256); }
+
+bool train_block(const TrainBlockArgs &a, hipStream_t s) {
+    const int B = a.B, T = a.res * a.res, C = a.C, M = B * T, H = a.hidden;
+    const size_t nMC = (size_t)M * C, nMH = (size_t)M * H;
+    TAttnGeom g{a.res, a.ws, a.shift, a.heads, C};
+    // ---- forward ----
+    t_gemm(false, true, a.emb, NOISE_EMB, a.W.aff_w, NOISE_EMB, a.W.aff_b, a.aff, 2 * C, B, 2 * C, NOISE_EMB, false, s);     // params = affine(emb)
+    hipLaunchKernelGGL(t_modulate_fwd_kernel, dim3(t_blocks(nMC)), dim3(256), 0, s, a.x_in, a.aff, a.x_mod, T, C, nMC);
+    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, a.x_mod, a.W.n1_w, a.W.n1_b, a.xn1, a.stats1, M, C);
+    t_gemm(false, true, a.xn1, C, a.W.qkv_w, C, a.W.qkv_b, a.qkv, 3 * C, M, 3 * C, C, false, s);
+    if (!t_attn_launch(false, a.qkv, a.W.rpb, a.att, nullptr, nullptr, nullptr, B, g, s)) return false;
+    if (hipMemcpyAsync(a.x1, a.x_mod, sizeof(float) * nMC, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;
+    t_gemm(false, true, a.att, C, a.W.proj_w, C, a.W.proj_b, a.x1, C, M, C, C, true, s);                                      // x1 = shortcut + proj(att)
+    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, a.x1, a.W.n2_w, a.W.n2_b, a.xn2, a.stats2, M, C);
+    t_gemm(false, true, a.xn2, C, a.W.fc1_w, C, a.W.fc1_b, a.pre, H, M, H, C, false, s);
+    hipLaunchKernelGGL(t_gelu_fwd_kernel, dim3(t_blocks(nMH)), dim3(256), 0, s, a.pre, a.hid, nMH);
+    if (hipMemcpyAsync(a.x_out, a.x1, sizeof(float) * nMC, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;
+    t_gemm(false, true, a.hid, H, a.W.fc2_w, H, a.W.fc2_b, a.x_out, C, M, C, H, true, s);                                      // x_out = x1 + fc2(gelu(fc1(ln2)))
+    if (!a.grad_out) return hipGetLastError() == hipSuccess;
+    // ---- backward ----  (d_x1 accumulates in a.d_x1; scratch tensors t_mc [M,C], t_mh [M,H], t_m3c [M,3C])
+    const float *dY = a.grad_out;
+    // MLP: x_out = x1 + hid W2^T + b2
+    t_gemm(true, false, dY, C, a.hid, H, nullptr, a.G.fc2_w, H, C, H, M, false, s);            // dW2 [C,H] = dY^T hid
+    t_colsum(dY, C, a.G.fc2_b, M, C, s);
+    t_gemm(false, false, dY, C, a.W.fc2_w, H, nullptr, a.t_mh, H, M, H, C, false, s);          // d_hid = dY W2
+    hipLaunchKernelGGL(t_gelu_bwd_kernel, dim3(t_blocks(nMH)), dim3(256), 0, s, a.pre, a.t_mh, a.t_mh, nMH);   // d_pre
+    t_gemm(true, false, a.t_mh, H, a.xn2, C, nullptr, a.G.fc1_w, C, H, C, M, false, s);         // dW1 [H,C] = d_pre^T xn2
+    t_colsum(a.t_mh, H, a.G.fc1_b, M, H, s);
+    t_gemm(false, false, a.t_mh, H, a.W.fc1_w, C, nullptr, a.t_mc, C, M, C, H, false, s);       // d_xn2 = d_pre W1
+    if (hipMemcpyAsync(a.d_x1, dY, sizeof(float) * nMC, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;   // residual branch
+    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, a.x1, a.W.n2_w, a.stats2, a.t_mc, a.d_x1, a.t_mc2, M, C);
+    t_colsum(a.t_mc2, C, a.G.n2_w, M, C, s);                                                     // d_gamma2 = colsum(d_xn2 * xhat)
+    t_colsum(a.t_mc, C, a.G.n2_b, M, C, s);                                                      // d_beta2 = colsum(d_xn2)
+    // attention half: x1 = x_mod + att Wp^T + bp
+    t_gemm(true, false, a.d_x1, C, a.att, C, nullptr, a.G.proj_w, C, C, C, M, false, s);
+    t_colsum(a.d_x1, C, a.G.proj_b, M, C, s);
+    t_gemm(false, false, a.d_x1, C, a.W.proj_w, C, nullptr, a.t_mc, C, M, C, C, false, s);      // d_att
+    if (hipMemsetAsync(a.G.rpb, 0, sizeof(float) * (size_t)(2 * a.ws - 1) * (2 * a.ws - 1) * a.heads, s) != hipSuccess) return false;
+    if (!t_attn_launch(true, a.qkv, a.W.rpb, nullptr, a.t_mc, a.t_m3c, a.G.rpb, B, g, s)) return false;   // d_qkv, d_table
+    t_gemm(true, false, a.t_m3c, 3 * C, a.xn1, C, nullptr, a.G.qkv_w, C, 3 * C, C, M, false, s);
+    t_colsum(a.t_m3c, 3 * C, a.G.qkv_b, M, 3 * C, s);
+    t_gemm(false, false, a.t_m3c, 3 * C, a.W.qkv_w, C, nullptr, a.t_mc, C, M, C, 3 * C, false, s);   // d_xn1
+    // d_xmod = d_x1 (shortcut) + LN1 backward
+    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, a.x_mod, a.W.n1_w, a.stats1, a.t_mc, a.d_x1, a.t_mc2, M, C);
+    t_colsum(a.t_mc2, C, a.G.n1_w, M, C, s);
+    t_colsum(a.t_mc, C, a.G.n1_b, M, C, s);
+    // modulate: x_mod = silu(shift + x (1 + scale)); params = emb Wa^T + ba
+    hipLaunchKernelGGL(t_modulate_bwd_kernel, dim3((B * C + 63) / 64), dim3(64), 0, s, a.x_in, a.aff, a.d_x1, a.grad_in, a.d_aff, B, T, C);
+    t_gemm(true, false, a.d_aff, 2 * C, a.emb, NOISE_EMB, nullptr, a.G.aff_w, NOISE_EMB, 2 * C, NOISE_EMB, B, false, s);   // dWa = d_aff^T emb
+    t_colsum(a.d_aff, 2 * C, a.G.aff_b, B, 2 * C, s);
+    t_gemm(false, false, a.d_aff, 2 * C, a.W.aff_w, NOISE_EMB, nullptr, a.grad_emb, NOISE_EMB, B, NOISE_EMB, 2 * C, false, s);   // d_emb
+    return hipGetLastError() == hipSuccess;
+}
+
+}  // namespace dsg

@@ -128,3 +128,15 @@ def train_case(name: str = "tiny", B: int = 4, seed: int = 7):
     eps_node = W.normal(seed, f"trn/{name}/eps_node", (B, n, cfg.c_node))
     coin = float(W.coins(seed, f"trn/{name}", 1)[0])
     return cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin
+
+
+def block_case(cfg, prefix: str, B: int, seed: int = 11):
+    """inputs of one SwinTransformerBlock on its own: x [B, T, C] of the block's level, a mapped noise embedding [B, 512] of
+    realistic scale, and the upstream gradient dY [B, T, C] (tools/gen_golden.py::gen_block_backward, tests)."""
+    parts = prefix.split(".")
+    lvl = int(parts[1]) if parts[0] == "down_layers" else cfg.num_layers - 1 - int(parts[1])
+    res, C = cfg.max_node_num >> lvl, cfg.embed_dim << lvl
+    x = W.normal(seed, f"blk/{prefix}/x", (B, res * res, C))
+    emb = (0.3 * W.normal(seed, f"blk/{prefix}/emb", (B, 512))).astype(np.float32)
+    dy = W.normal(seed, f"blk/{prefix}/dy", (B, res * res, C))
+    return x, emb, dy

@@ -177,3 +177,31 @@ def eval_loss_step(model, train_obj_gen, loss_func, adjs_gt, nodes_gt, node_flag
                                             reduction="none", iou_loss_weight=iou_loss_weight)
     loss = reg_loss_adj.mean() + reg_loss_node.mean()
     return loss, reg_loss_adj, reg_loss_node, sigmas
+
+
+BLOCK_PARAM_NAMES = ("affine.weight", "affine.bias", "norm1.weight", "norm1.bias", "attn.relative_position_bias_table",
+                     "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias",
+                     "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")
+
+
+@torch.no_grad()
+def swin_block_train(net, block: str, x, emb, grad_out=None):
+    """One SwinTransformerBlock of `net` (a DiffuseSGHip) in training form: forward `block(x, emb)` (diffusesg.py:232-277) and, with
+    `grad_out`, its backward -> (x_out, grad_x, grad_emb, {parameter name: gradient}) -- the first piece of the network backward
+    (`dsg_block_train`; correctness-first kernels pinned to the reference's autograd, not the MFMA kernels of the sampling path).
+    x, grad_out: [B, T, C]; emb: [B, 512] (the mapped noise embedding); `block` e.g. "down_layers.0.blocks.1"."""
+    h = net._ensure_handle()
+    dev = net._dev
+    f32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()
+    x, emb, gy = f32(x), f32(emb), f32(grad_out)
+    B = x.shape[0]
+    sd = net.state_dict()
+    x_out = torch.empty_like(x)
+    gx, ge = (torch.empty_like(x), torch.empty_like(emb)) if gy is not None else (None, None)
+    grads = {k: torch.zeros(tuple(sd[f"{block}.{k}"].shape), device=dev, dtype=torch.float32) for k in BLOCK_PARAM_NAMES} if gy is not None else {}
+    names = (C.c_char_p * len(BLOCK_PARAM_NAMES))(*[k.encode() for k in BLOCK_PARAM_NAMES])
+    ptrs = (C.c_void_p * len(BLOCK_PARAM_NAMES))(*[grads[k].data_ptr() if grads else None for k in BLOCK_PARAM_NAMES])
+    st = torch.cuda.current_stream(dev).cuda_stream
+    h.check(h.L.dsg_block_train(h._h, block.encode(), B, _p(x), _p(emb), _p(gy), _p(x_out), _p(gx), _p(ge), len(BLOCK_PARAM_NAMES) if grads else 0,
+                                names, ptrs, C.c_void_p(st)), "dsg_block_train")
+    return x_out, gx, ge, grads

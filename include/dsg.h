@@ -236,6 +236,18 @@ int dsg_rainbow_loss_backward(int32_t B, int32_t N, int32_t c_adj, int32_t c_nod
                               float edge_loss_weight, float node_loss_weight, float iou_loss_weight, const float *sigmas,
                               float *out_grad_adj, float *out_grad_node, float *out_grad_F_adj, float *out_grad_F_node, void *stream);
 
+/* One SwinTransformerBlock in training form: forward x_out = block(x_in, emb) (R/model/diffusesg/diffusesg.py:232-277 with
+ * WindowAttention :108-139 and Mlp :19-25) and, when grad_out != NULL, its backward as torch.autograd derives it -- the first
+ * piece of the network backward (second half).  Correctness-first kernels (csrc/train_kernels.hip: LDS-tiled FMA GEMM,
+ * one thread per row / window row), pinned to the reference's autograd by tests/golden/block_backward.npz; not on the sampling path.
+ *   block: state-dict prefix of the block, e.g. "down_layers.0.blocks.1".  x_in, x_out, grad_out, grad_in: [B, T, C] token-major
+ *   (the reference's [B, L, C]); emb, grad_emb: [B, 512] (the mapped noise embedding, dsg_noise_embed).  names[i] (relative to the
+ *   prefix: "affine.weight", "affine.bias", "norm1.weight", "norm1.bias", "attn.relative_position_bias_table", "attn.qkv.weight",
+ *   "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias",
+ *   "mlp.fc2.weight", "mlp.fc2.bias") -> grad_params[i] (device, the parameter's shape); all 15 are required with grad_out. */
+int dsg_block_train(dsg_handle h, const char *block, int32_t B, const float *x_in, const float *emb, const float *grad_out, float *x_out,
+                    float *grad_in, float *grad_emb, int32_t n_params, const char *const *names, float *const *grad_params, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

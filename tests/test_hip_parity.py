@@ -950,6 +950,37 @@ def test_noise_embedding_standalone_vs_reference(name):
         assert_close(aff.cpu().numpy(), g[f"{name}_aff"], 1e-5, "affine (scale | shift) table")
 
 
+@pytest.mark.parametrize("name,prefix,B", [("small", "down_layers.0.blocks.1", 2), ("tiny", "down_layers.1.blocks.0", 3),
+                                           ("coco", "down_layers.1.blocks.1", 1)])
+def test_swin_block_forward_backward_vs_reference_autograd(name, prefix, B):
+    """tests/golden/block_backward.npz (the reference's SwinTransformerBlock under autograd): the training-form forward and the
+    backward of one block -- modulate+SiLU, LayerNorm, QKV, window attention with relative-position bias (and the -100 region mask of
+    shifted windows; 16-, 64- and 100-token windows), proj, MLP with exact GELU, and the affine linear of the noise embedding --
+    dL/dx, dL/demb and all 15 parameter gradients (norm + strided sample each)"""
+    from diffusesg_amd.model import build_network
+    from diffusesg_amd.train import swin_block_train, BLOCK_PARAM_NAMES
+    g = load("block_backward.npz")
+    cfg = Y.CONFIGS[name]()
+    net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda").model
+    x, emb, dy = Y.block_case(cfg, prefix, B)
+    x_out, gx, ge, grads = swin_block_train(net, prefix, T(x), T(emb), T(dy))
+    key = f"{name}/{prefix}"
+    rs = int(g[f"{key}/row_stride"])
+    assert_close(x_out.cpu().numpy()[:, ::rs], g[f"{key}/x_out"], 2e-5, "block output")
+    assert_close(gx.cpu().numpy()[:, ::rs], g[f"{key}/grad_in"], 1e-4, "dL/dx")
+    assert_close(ge.cpu().numpy(), g[f"{key}/grad_emb"], 1e-4, "dL/demb")
+    for k in BLOCK_PARAM_NAMES:
+        mine = grads[k].cpu().numpy().reshape(-1)
+        ref = g[f"{key}/gparam/{k}"]
+        stride = max(1, -(-mine.size // 512))
+        assert_close(mine[::stride], ref, 2e-4, f"grad {k}")
+        nrm = float(np.sqrt((mine.astype(np.float64) ** 2).sum()))
+        assert abs(nrm - float(g[f"{key}/gnorm/{k}"])) <= 2e-4 * float(g[f"{key}/gnorm/{k}"]), k
+    # forward only (no gradient buffers) gives the same output
+    x_out2, _, _, _ = swin_block_train(net, prefix, T(x), T(emb))
+    assert torch.equal(x_out2, x_out)
+
+
 def test_train_backward_head_vs_reference_autograd():
     """tests/golden/train_backward.npz (the reference's own autograd over one training step): dL/d(preconditioned outputs) incl.
     the IoU term's clamp / max / min branches, and dL/d(raw network outputs) = c_out(sigma) * that -- the first stage of the

@@ -504,6 +504,43 @@ def gen_noise_embed(DiffuseSG, out):
     np.savez_compressed(os.path.join(out, "noise_embed.npz"), **res)
 
 
+BLOCK_CASES = [("small", "down_layers.0.blocks.1", 2),    # 16x16 tokens, 4x4 windows, shift 2: the -100 region mask is active
+               ("tiny", "down_layers.1.blocks.0", 3),     # 4x4 tokens, window = whole map (no partition), C = 192, 6 heads
+               ("coco", "down_layers.1.blocks.1", 1)]     # 20x20 tokens, 10x10 windows (100 tokens), shift 5, C = 192
+
+
+def gen_block_backward(DiffuseSG, out):
+    """G9: one SwinTransformerBlock on its own (diffusesg.py:232-277), forward and the reference's autograd backward:
+    x_out, dL/dx_in, dL/demb and the gradient of each of the block's 15 parameters (L2 norm + every stride-th element, <= 512
+    values; x_out / dL/dx_in as every 4th token row except for the tiny case) for L = sum(x_out * dY) with a random dY.  Inputs from the portable generator (diffusesg_amd.synth.block_case)."""
+    res = {}
+    for name, prefix, B in BLOCK_CASES:
+        cfg = CONFIGS[name]()
+        net = build_ref_net(DiffuseSG, cfg)
+        mod = net
+        for part in prefix.split("."):
+            mod = mod[int(part)] if part.isdigit() else getattr(mod, part)
+        x, emb, dy = Y.block_case(cfg, prefix, B)
+        xt, et = t(x.copy()).requires_grad_(True), t(emb.copy()).requires_grad_(True)
+        for p_ in mod.parameters():
+            p_.grad = None
+        y = mod(xt, et)
+        (y * t(dy)).sum().backward()
+        key = f"{name}/{prefix}"
+        rs = 1 if name == "tiny" else 4   # token rows kept (every rs-th): the fixture stays small
+        res[f"{key}/row_stride"] = np.array(rs)
+        res[f"{key}/x_out"], res[f"{key}/grad_in"] = y.detach().numpy()[:, ::rs].copy(), xt.grad.numpy()[:, ::rs].copy()
+        res[f"{key}/grad_emb"] = et.grad.numpy().copy()
+        for k, p_ in mod.named_parameters():
+            g_ = p_.grad.numpy().reshape(-1)
+            stride = max(1, -(-g_.size // 512))
+            res[f"{key}/gparam/{k}"] = g_[::stride].copy()
+            res[f"{key}/gnorm/{k}"] = np.array(float(np.sqrt((g_.astype(np.float64) ** 2).sum())))
+        print(f"block backward {key}: |x_out| {float(y.abs().max()):.3f} |grad_in| {float(xt.grad.norm()):.4f} "
+              f"|d table| {float(mod.attn.relative_position_bias_table.grad.norm()):.4e}")
+    np.savez_compressed(os.path.join(out, "block_backward.npz"), **res)
+
+
 def check_channel_table():
     """diffusesg_amd.spec.sg_channels (data restated from sg_utils.py:348-409) against the imported reference function."""
     from utils.sg_utils import get_node_adj_num_type
@@ -536,6 +573,8 @@ def main():
         gen_train_backward(DiffuseSG, NodeAdjPrecond, args.out)
     if args.only in ("", "noise"):
         gen_noise_embed(DiffuseSG, args.out)
+    if args.only in ("", "block_bwd"):
+        gen_block_backward(DiffuseSG, args.out)
     if args.only in ("", "fwd"):
         gen_forward(DiffuseSG, args.out)
     if args.only in ("", "precond"):
