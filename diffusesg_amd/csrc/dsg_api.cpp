@@ -18,6 +18,8 @@
 #include <map>
 #include <memory>
 #include <random>
+#include <functional>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -1717,6 +1719,351 @@ int dsg_block_train(dsg_handle h, const char *block, int32_t B, const float *x_i
     HIP_TRY(h, e);
     if (!ok) return fail(h, DSG_ERR_HIP, "train_block failed (window larger than 128 tokens or a launch error)");
     return DSG_OK;
+}
+
+// ---- whole-network training step: forward in training form + backward to every parameter (correctness-first kernels) ----
+namespace {
+struct TArena {   // bump allocator over one hipMalloc
+    float *base = nullptr; size_t cap = 0, off = 0; bool dry = true;
+    float *get(size_t n) { n = (n + 63) / 64 * 64; float *p = dry ? nullptr : base + off; off += n; return p; }
+};
+struct TLin { const float *x; float *y; };   // nothing else: linears keep their input pointer in the stage structs below
+}  // namespace
+
+// `mid` (optional) runs between forward and backward on the same stream and fills dL/dF from the forward's outputs
+typedef std::function<int(const float *F_adj, const float *F_node, float *dF_adj, float *dF_node)> TrainMid;
+static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const float *in_node, const uint8_t *flags, const float *c_noise,
+                            const float *sc_adj, const float *sc_node, const float *grad_F_adj, const float *grad_F_node, const TrainMid *mid,
+                            float *out_F_adj, float *out_F_node, int32_t n_params, const char *const *names, float *const *grad_params,
+                            void *stream) {
+    if (!h || !h->finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
+    if (B < 1 || !in_adj || !in_node || !flags || !c_noise || !out_F_adj || !out_F_node) return fail(h, DSG_ERR_INVALID, "null argument");
+    const bool bwd = grad_F_adj != nullptr || mid != nullptr;
+    if (bwd && ((!mid && !grad_F_node) || !names || !grad_params)) return fail(h, DSG_ERR_INVALID, "backward needs both output gradients and the parameter gradient buffers");
+    if (h->cfg.self_condition && ((sc_adj == nullptr) != (sc_node == nullptr))) return fail(h, DSG_ERR_INVALID, "self-conditioning needs both tensors or none");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = h->N, E = h->E, L = h->L, Ca = h->Ca, Cn = h->Cn, Cin = h->Cin, T0 = N * N;
+    const size_t M0 = (size_t)B * T0;
+    std::unordered_map<std::string, float *> gmap;
+    if (bwd) for (int k = 0; k < n_params; k++) if (names[k] && grad_params[k]) gmap[names[k]] = grad_params[k];
+    std::string missing;
+    auto Wt = [&](const std::string &k) -> float * { auto it = h->w.find(k); if (it == h->w.end()) { if (missing.empty()) missing = k; return nullptr; } return it->second.p; };
+    auto Gd = [&](const std::string &k) -> float * { if (!bwd) return nullptr; auto it = gmap.find(k); if (it == gmap.end()) { if (missing.empty()) missing = "grad:" + k; return nullptr; } return it->second; };
+    // collect the blocks in execution order
+    struct Stage { const BlockPlan *bp; TrainBlockArgs a; float *x_in, *x_out, *d_emb; };
+    std::vector<Stage> enc[8], dec[8];
+    TArena A;
+    int has_sc_host = (h->cfg.self_condition && sc_adj) ? 1 : 0;
+    int *has_sc_dev = nullptr;
+    // everything below runs twice: a dry pass that only sizes the arena, then the real pass
+    struct Bufs {
+        float *pe, *m0, *s0, *m1, *emb, *d_emb, *tok, *pe_lin, *pe_ln, *pe_stats, *pe_aff, *pe_daff, *x0;
+        float *mcat[8], *mnrm[8], *mstats[8], *mout[8];                       // PatchMerging per level
+        float *ucat[8], *uy[8], *un[8], *ustats[8], *usc[8], *upn[8], *upstats[8], *uout[8];   // PatchBreakup per up layer
+        float *fy, *fstats, *z1, *z2, *rep, *ha_pre, *ha, *oa, *pool, *hn_pre, *hn, *on;
+        float *d_skip[8];
+    } Bf{};
+    const float *skip_ptr[8] = {};
+    int skip_res[8] = {}, skip_C[8] = {};
+    auto fill_block = [&](const BlockPlan &b, Stage &st) -> bool {
+        static const char *kNames[15] = {"affine.weight", "affine.bias", "norm1.weight", "norm1.bias", "attn.relative_position_bias_table",
+                                         "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "norm2.weight",
+                                         "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"};
+        TrainBlockArgs &a = st.a;
+        float **Wp[15] = {&a.W.aff_w, &a.W.aff_b, &a.W.n1_w, &a.W.n1_b, &a.W.rpb, &a.W.qkv_w, &a.W.qkv_b, &a.W.proj_w, &a.W.proj_b,
+                          &a.W.n2_w, &a.W.n2_b, &a.W.fc1_w, &a.W.fc1_b, &a.W.fc2_w, &a.W.fc2_b};
+        float **Gp[15] = {&a.G.aff_w, &a.G.aff_b, &a.G.n1_w, &a.G.n1_b, &a.G.rpb, &a.G.qkv_w, &a.G.qkv_b, &a.G.proj_w, &a.G.proj_b,
+                          &a.G.n2_w, &a.G.n2_b, &a.G.fc1_w, &a.G.fc1_b, &a.G.fc2_w, &a.G.fc2_b};
+        for (int i = 0; i < 15; i++) { *Wp[i] = Wt(b.prefix + "." + kNames[i]); *Gp[i] = Gd(b.prefix + "." + kNames[i]); }
+        a.B = B; a.res = b.res; a.ws = b.ws; a.shift = b.shift; a.heads = b.heads; a.C = b.C; a.hidden = h->cfg.mlp_ratio * b.C;
+        const size_t M = (size_t)B * b.res * b.res, C = b.C, H = a.hidden;
+        a.aff = A.get((size_t)B * 2 * C); a.d_aff = A.get((size_t)B * 2 * C);
+        a.x_mod = A.get(M * C); a.xn1 = A.get(M * C); a.att = A.get(M * C); a.x1 = A.get(M * C); a.xn2 = A.get(M * C);
+        a.stats1 = A.get(M * 2); a.stats2 = A.get(M * 2); a.qkv = A.get(M * 3 * C); a.pre = A.get(M * H); a.hid = A.get(M * H);
+        st.x_out = A.get(M * C); st.d_emb = A.get((size_t)B * NOISE_EMB);
+        return true;
+    };
+    for (int pass = 0; pass < 2; pass++) {
+        A.off = 0; A.dry = pass == 0;
+        for (int l = 0; l < 8; l++) { enc[l].clear(); dec[l].clear(); }
+        Bf.pe = A.get((size_t)B * E); Bf.m0 = A.get((size_t)B * NOISE_EMB); Bf.s0 = A.get((size_t)B * NOISE_EMB);
+        Bf.m1 = A.get((size_t)B * NOISE_EMB); Bf.emb = A.get((size_t)B * NOISE_EMB); Bf.d_emb = A.get((size_t)B * NOISE_EMB);
+        Bf.tok = A.get(M0 * Cin); Bf.pe_lin = A.get(M0 * E); Bf.pe_ln = A.get(M0 * E); Bf.pe_stats = A.get(M0 * 2);
+        Bf.pe_aff = A.get((size_t)B * 2 * E); Bf.pe_daff = A.get((size_t)B * 2 * E); Bf.x0 = A.get(M0 * E);
+        int res = N, C = E;
+        for (int l = 0; l < L; l++) {
+            for (auto &b : h->down[l]) { Stage st{}; st.bp = &b; fill_block(b, st); enc[l].push_back(st); }
+            if (l < L - 1) {
+                const size_t M2 = (size_t)B * (res / 2) * (res / 2);
+                Bf.mcat[l] = A.get(M2 * 4 * C); Bf.mnrm[l] = A.get(M2 * 4 * C); Bf.mstats[l] = A.get(M2 * 2); Bf.mout[l] = A.get(M2 * 2 * C);
+                res /= 2; C *= 2;
+            }
+            skip_res[l] = res; skip_C[l] = C;
+            Bf.d_skip[l] = A.get((size_t)B * res * res * C);
+        }
+        for (int i = 0; i < L; i++) {
+            const int lvl = L - 1 - i;
+            if (i > 0) {
+                const size_t Mi = (size_t)B * res * res; const int D = 2 * C, Co = D / 4;
+                Bf.ucat[i] = A.get(Mi * D); Bf.uy[i] = A.get(Mi * D); Bf.un[i] = A.get(Mi * D); Bf.ustats[i] = A.get(Mi * 2);
+                Bf.usc[i] = A.get(Mi * 4 * Co); Bf.upn[i] = A.get(Mi * 4 * Co); Bf.upstats[i] = A.get(Mi * 4 * 2); Bf.uout[i] = A.get(Mi * 4 * Co);
+                res *= 2; C /= 2;
+            }
+            for (auto &b : h->up[i]) { Stage st{}; st.bp = &b; fill_block(b, st); dec[i].push_back(st); }
+            (void)lvl;
+        }
+        Bf.fy = A.get(M0 * E); Bf.fstats = A.get(M0 * 2); Bf.z1 = A.get(M0 * E); Bf.z2 = A.get(M0 * E); Bf.rep = A.get(M0 * E);
+        Bf.ha_pre = A.get(M0 * E); Bf.ha = A.get(M0 * E); Bf.oa = A.get(M0 * Ca);
+        Bf.pool = A.get((size_t)B * N * E); Bf.hn_pre = A.get((size_t)B * N * E); Bf.hn = A.get((size_t)B * N * E); Bf.on = A.get((size_t)B * N * Cn);
+        if (pass == 0) {
+            if (!missing.empty()) return fail(h, DSG_ERR_INVALID, "missing tensor '%s'", missing.c_str());
+            // scratch for the backward: the widest [M, 4C] tensors of any stage, three of them, + block scratch
+            A.cap = A.off;
+            HIP_TRY(h, hipMalloc((void **)&A.base, sizeof(float) * A.cap + 64));
+            HIP_TRY(h, hipMalloc((void **)&has_sc_dev, sizeof(int)));
+            HIP_TRY(h, hipMemcpy(has_sc_dev, &has_sc_host, sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
+    // widest scratch tensors (backward): sized for level 0's [M0, 4E]; every level has M C constant up to the 2x of merging
+    size_t wide = M0 * (size_t)(4 * E);
+    float *scr = nullptr;
+    if (hipMalloc((void **)&scr, sizeof(float) * (wide * 3 + M0 * (size_t)E * 8 + 4096)) != hipSuccess) { (void)hipFree(A.base); (void)hipFree(has_sc_dev); return fail(h, DSG_ERR_HIP, "out of memory"); }
+    float *t_mh = scr, *t_m3c = scr + wide, *t_w = scr + 2 * wide, *t_mc = scr + 3 * wide, *t_mc2 = t_mc + M0 * E * 2, *d_x = t_mc2 + M0 * E * 2,
+          *d_y = d_x + M0 * E * 2;
+    auto lin_fwd = [&](const float *x, const float *Wm, const float *bias, float *y, size_t M, int in, int out) {
+        t_gemm(false, true, x, in, Wm, in, bias, y, out, (int)M, out, in, false, s);
+    };
+    auto lin_bwd = [&](const float *x, const float *Wm, const float *dy, float *dx, float *dW, float *db, size_t M, int in, int out) {
+        t_gemm(true, false, dy, out, x, in, nullptr, dW, in, out, in, (int)M, false, s);           // dW [out,in] = dy^T x
+        if (db) t_colsum(dy, out, db, (int)M, out, s);
+        if (dx) t_gemm(false, false, dy, out, Wm, in, nullptr, dx, in, (int)M, in, out, false, s);   // dx = dy W
+    };
+    bool ok = true;
+    // ================================ forward ================================
+    launch_noise_pe(c_noise, Bf.pe, B, E, s);
+    lin_fwd(Bf.pe, Wt("map_layer0.weight"), Wt("map_layer0.bias"), Bf.m0, B, E, NOISE_EMB);
+    t_silu(Bf.m0, nullptr, Bf.s0, (size_t)B * NOISE_EMB, false, s);
+    lin_fwd(Bf.s0, Wt("map_layer1.weight"), Wt("map_layer1.bias"), Bf.m1, B, NOISE_EMB, NOISE_EMB);
+    t_silu(Bf.m1, nullptr, Bf.emb, (size_t)B * NOISE_EMB, false, s);
+    launch_assemble(in_adj, in_node, sc_adj, sc_node, has_sc_dev, flags, Bf.tok, B, N, Ca, Cn, h->cfg.self_condition, Cin, s);
+    lin_fwd(Bf.tok, Wt("patch_embed.proj.weight"), Wt("patch_embed.proj.bias"), Bf.pe_lin, M0, Cin, E);
+    t_ln_fwd(Bf.pe_lin, Wt("patch_embed.norm.weight"), Wt("patch_embed.norm.bias"), Bf.pe_ln, Bf.pe_stats, (int)M0, E, s);
+    lin_fwd(Bf.emb, Wt("patch_embed.affine.weight"), Wt("patch_embed.affine.bias"), Bf.pe_aff, B, NOISE_EMB, 2 * E);
+    t_modulate(Bf.pe_ln, Bf.pe_aff, nullptr, Bf.x0, nullptr, B, T0, E, false, s);
+    const float *x = Bf.x0;
+    int res = N, C = E;
+    auto run_blocks_fwd = [&](std::vector<Stage> &v) {
+        for (auto &st : v) {
+            st.x_in = const_cast<float *>(x);
+            st.a.x_in = x; st.a.emb = Bf.emb; st.a.x_out = st.x_out; st.a.grad_out = nullptr;
+            ok = ok && train_block(st.a, s);
+            x = st.x_out;
+        }
+    };
+    for (int l = 0; l < L; l++) {
+        run_blocks_fwd(enc[l]);
+        if (l < L - 1) {
+            const std::string p = "down_layers." + std::to_string(l) + ".downsample";
+            const size_t M2 = (size_t)B * (res / 2) * (res / 2);
+            t_regroup(x, Bf.mcat[l], B, res, C, true, s);
+            t_ln_fwd(Bf.mcat[l], Wt(p + ".norm.weight"), Wt(p + ".norm.bias"), Bf.mnrm[l], Bf.mstats[l], (int)M2, 4 * C, s);
+            lin_fwd(Bf.mnrm[l], Wt(p + ".reduction.weight"), nullptr, Bf.mout[l], M2, 4 * C, 2 * C);
+            x = Bf.mout[l]; res /= 2; C *= 2;
+        }
+        skip_ptr[l] = x;
+    }
+    for (int i = 0; i < L; i++) {
+        const int lvl = L - 1 - i;
+        if (i > 0) {
+            const std::string p = "up_layers." + std::to_string(i) + ".upsample";
+            const size_t Mi = (size_t)B * res * res; const int D = 2 * C, Co = D / 4;
+            t_concat(x, skip_ptr[lvl], Bf.ucat[i], Mi, C, s);
+            lin_fwd(Bf.ucat[i], Wt(p + ".pre_linear.weight"), nullptr, Bf.uy[i], Mi, D, D);
+            t_ln_fwd(Bf.uy[i], Wt(p + ".norm.weight"), Wt(p + ".norm.bias"), Bf.un[i], Bf.ustats[i], (int)Mi, D, s);
+            t_regroup(Bf.un[i], Bf.usc[i], B, 2 * res, Co, false, s);   // scatter: fine [4 Mi, Co] <- coarse [Mi, 4 Co]
+            t_ln_fwd(Bf.usc[i], Wt(p + ".post_norm.weight"), Wt(p + ".post_norm.bias"), Bf.upn[i], Bf.upstats[i], (int)(4 * Mi), Co, s);
+            lin_fwd(Bf.upn[i], Wt(p + ".post_linear.weight"), nullptr, Bf.uout[i], 4 * Mi, Co, Co);
+            x = Bf.uout[i]; res *= 2; C /= 2;
+        }
+        run_blocks_fwd(dec[i]);
+    }
+    const float *xL = x;
+    t_ln_fwd(xL, Wt("norm.weight"), Wt("norm.bias"), Bf.fy, Bf.fstats, (int)M0, E, s);
+    t_gemm(false, false, Bf.fy, E, Wt("read_out.0.weight"), E, Wt("read_out.0.bias"), Bf.z1, E, (int)M0, E, E, false, s);   // ConvTranspose2d: [in, out]
+    lin_fwd(Bf.z1, Wt("read_out.1.weight"), Wt("read_out.1.bias"), Bf.z2, M0, E, E);
+    lin_fwd(Bf.z2, Wt("read_out.2.weight"), Wt("read_out.2.bias"), Bf.rep, M0, E, E);
+    lin_fwd(Bf.rep, Wt("readout_adj_mlp.fc1.weight"), Wt("readout_adj_mlp.fc1.bias"), Bf.ha_pre, M0, E, E);
+    t_gelu(Bf.ha_pre, nullptr, Bf.ha, M0 * E, false, s);
+    lin_fwd(Bf.ha, Wt("readout_adj_mlp.fc2.weight"), Wt("readout_adj_mlp.fc2.bias"), Bf.oa, M0, E, Ca);
+    t_adj_out(Bf.oa, flags, out_F_adj, nullptr, nullptr, B, N, Ca, false, s);
+    launch_pool(Bf.rep, flags, Bf.pool, B, N, E, s);
+    lin_fwd(Bf.pool, Wt("readout_node_mlp.fc1.weight"), Wt("readout_node_mlp.fc1.bias"), Bf.hn_pre, (size_t)B * N, E, E);
+    t_gelu(Bf.hn_pre, nullptr, Bf.hn, (size_t)B * N * E, false, s);
+    lin_fwd(Bf.hn, Wt("readout_node_mlp.fc2.weight"), Wt("readout_node_mlp.fc2.bias"), Bf.on, (size_t)B * N, E, Cn);
+    t_rowmask(Bf.on, flags, out_F_node, (size_t)B * N, Cn, s);
+    // ================================ backward ================================
+    float *mid_buf = nullptr;
+    if (bwd && ok && mid) {
+        const size_t na = (size_t)B * Ca * N * N, nn = (size_t)B * N * Cn;
+        if (hipMalloc((void **)&mid_buf, sizeof(float) * (na + nn)) != hipSuccess) ok = false;
+        else { ok = (*mid)(out_F_adj, out_F_node, mid_buf, mid_buf + na) == DSG_OK; grad_F_adj = mid_buf; grad_F_node = mid_buf + na; }
+    }
+    if (bwd && ok) {
+        hipError_t e0 = hipMemsetAsync(Bf.d_emb, 0, sizeof(float) * (size_t)B * NOISE_EMB, s);
+        for (int l = 0; l < L && e0 == hipSuccess; l++) e0 = hipMemsetAsync(Bf.d_skip[l], 0, sizeof(float) * (size_t)B * skip_res[l] * skip_res[l] * skip_C[l], s);
+        ok = ok && e0 == hipSuccess;
+        // heads
+        float *d_on = t_mc, *d_hn = t_mc2, *d_pool = d_x, *d_rep = d_y;
+        t_rowmask(grad_F_node, flags, d_on, (size_t)B * N, Cn, s);
+        lin_bwd(Bf.hn, Wt("readout_node_mlp.fc2.weight"), d_on, d_hn, Gd("readout_node_mlp.fc2.weight"), Gd("readout_node_mlp.fc2.bias"), (size_t)B * N, E, Cn);
+        t_gelu(Bf.hn_pre, d_hn, d_hn, (size_t)B * N * E, true, s);
+        lin_bwd(Bf.pool, Wt("readout_node_mlp.fc1.weight"), d_hn, d_pool, Gd("readout_node_mlp.fc1.weight"), Gd("readout_node_mlp.fc1.bias"), (size_t)B * N, E, E);
+        float *d_oa = t_m3c, *d_ha = t_mh;
+        t_adj_out(nullptr, flags, nullptr, grad_F_adj, d_oa, B, N, Ca, true, s);
+        lin_bwd(Bf.ha, Wt("readout_adj_mlp.fc2.weight"), d_oa, d_ha, Gd("readout_adj_mlp.fc2.weight"), Gd("readout_adj_mlp.fc2.bias"), M0, E, Ca);
+        t_gelu(Bf.ha_pre, d_ha, d_ha, M0 * E, true, s);
+        lin_bwd(Bf.rep, Wt("readout_adj_mlp.fc1.weight"), d_ha, d_rep, Gd("readout_adj_mlp.fc1.weight"), Gd("readout_adj_mlp.fc1.bias"), M0, E, E);
+        t_pool_bwd(d_pool, flags, d_rep, B, N, E, s);
+        // read_out.2, .1 (Conv2d [out,in]) and .0 (ConvTranspose2d [in,out]), final norm
+        float *d_z2 = t_mh, *d_z1 = t_m3c, *d_fy = t_w;
+        lin_bwd(Bf.z2, Wt("read_out.2.weight"), d_rep, d_z2, Gd("read_out.2.weight"), Gd("read_out.2.bias"), M0, E, E);
+        lin_bwd(Bf.z1, Wt("read_out.1.weight"), d_z2, d_z1, Gd("read_out.1.weight"), Gd("read_out.1.bias"), M0, E, E);
+        t_gemm(true, false, Bf.fy, E, d_z1, E, nullptr, Gd("read_out.0.weight"), E, E, E, (int)M0, false, s);        // dW [in,out] = y^T dz
+        t_colsum(d_z1, E, Gd("read_out.0.bias"), (int)M0, E, s);
+        t_gemm(false, true, d_z1, E, Wt("read_out.0.weight"), E, nullptr, d_fy, E, (int)M0, E, E, false, s);        // dy = dz W^T
+        float *dx = d_x;   // running gradient wrt the current activation x (size up to M0*E*2)
+        ok = ok && hipMemsetAsync(dx, 0, sizeof(float) * M0 * E, s) == hipSuccess;
+        t_ln_bwd(xL, Wt("norm.weight"), Bf.fstats, d_fy, dx, t_mc2, (int)M0, E, s);
+        t_colsum(t_mc2, E, Gd("norm.weight"), (int)M0, E, s);
+        t_colsum(d_fy, E, Gd("norm.bias"), (int)M0, E, s);
+        // blocks / up / down in reverse
+        float *dcur = dx, *dnext = d_y;   // ping-pong
+        auto run_blocks_bwd = [&](std::vector<Stage> &v) {
+            for (int k = (int)v.size() - 1; k >= 0; k--) {
+                Stage &st = v[k];
+                TrainBlockArgs &a = st.a;
+                const size_t M = (size_t)B * a.res * a.res, Cc = a.C, H = a.hidden;
+                a.grad_out = dcur; a.grad_in = dnext; a.grad_emb = st.d_emb;
+                a.d_x1 = t_w; a.t_mc = t_mc; a.t_mc2 = t_mc2; a.t_m3c = t_m3c; a.t_mh = t_mh;
+                (void)M; (void)Cc; (void)H;
+                ok = ok && train_block_backward(a, s);
+                t_add(Bf.d_emb, st.d_emb, (size_t)B * NOISE_EMB, s);
+                std::swap(dcur, dnext);
+            }
+        };
+        res = N; C = E;
+        for (int i = L - 1; i >= 0; i--) {
+            const int lvl = L - 1 - i;
+            run_blocks_bwd(dec[i]);
+            if (i > 0) {
+                // here res, C are the FINE values (after the breakup); the coarse input had res/2, 2C per source
+                const std::string p = "up_layers." + std::to_string(i) + ".upsample";
+                const int rc = res / 2, Cc = 2 * C; const size_t Mi = (size_t)B * rc * rc; const int D = 2 * Cc, Co = D / 4;
+                float *d_upn = t_mh, *d_usc = t_m3c, *d_un = t_w, *d_uy = t_mh, *d_cat = t_m3c;
+                lin_bwd(Bf.upn[i], Wt(p + ".post_linear.weight"), dcur, d_upn, Gd(p + ".post_linear.weight"), nullptr, 4 * Mi, Co, Co);
+                ok = ok && hipMemsetAsync(d_usc, 0, sizeof(float) * 4 * Mi * Co, s) == hipSuccess;
+                t_ln_bwd(Bf.usc[i], Wt(p + ".post_norm.weight"), Bf.upstats[i], d_upn, d_usc, t_mc2, (int)(4 * Mi), Co, s);
+                t_colsum(t_mc2, Co, Gd(p + ".post_norm.weight"), (int)(4 * Mi), Co, s);
+                t_colsum(d_upn, Co, Gd(p + ".post_norm.bias"), (int)(4 * Mi), Co, s);
+                t_regroup(d_usc, d_un, B, res, Co, true, s);   // transpose of the scatter = gather
+                ok = ok && hipMemsetAsync(d_uy, 0, sizeof(float) * Mi * D, s) == hipSuccess;
+                t_ln_bwd(Bf.uy[i], Wt(p + ".norm.weight"), Bf.ustats[i], d_un, d_uy, t_mc2, (int)Mi, D, s);
+                t_colsum(t_mc2, D, Gd(p + ".norm.weight"), (int)Mi, D, s);
+                t_colsum(d_un, D, Gd(p + ".norm.bias"), (int)Mi, D, s);
+                lin_bwd(Bf.ucat[i], Wt(p + ".pre_linear.weight"), d_uy, d_cat, Gd(p + ".pre_linear.weight"), nullptr, Mi, D, D);
+                t_split(d_cat, dnext, Bf.d_skip[lvl], Mi, Cc, s);
+                std::swap(dcur, dnext);
+                res = rc; C = Cc;
+            }
+        }
+        for (int l = L - 1; l >= 0; l--) {
+            // the tensor at the end of encoder level l (after its merging, if any) also fed the decoder as skip[l]
+            if (l < L - 1 || true) t_add(dcur, Bf.d_skip[l], (size_t)B * skip_res[l] * skip_res[l] * skip_C[l], s);
+            if (l < L - 1) {
+                const std::string p = "down_layers." + std::to_string(l) + ".downsample";
+                const int rf = res * 2, Cf = C / 2; const size_t M2 = (size_t)B * res * res;
+                float *d_nrm = t_mh, *d_cat = t_m3c;
+                lin_bwd(Bf.mnrm[l], Wt(p + ".reduction.weight"), dcur, d_nrm, Gd(p + ".reduction.weight"), nullptr, M2, 4 * Cf, 2 * Cf);
+                ok = ok && hipMemsetAsync(d_cat, 0, sizeof(float) * M2 * 4 * Cf, s) == hipSuccess;
+                t_ln_bwd(Bf.mcat[l], Wt(p + ".norm.weight"), Bf.mstats[l], d_nrm, d_cat, t_w, (int)M2, 4 * Cf, s);
+                t_colsum(t_w, 4 * Cf, Gd(p + ".norm.weight"), (int)M2, 4 * Cf, s);
+                t_colsum(d_nrm, 4 * Cf, Gd(p + ".norm.bias"), (int)M2, 4 * Cf, s);
+                t_regroup(d_cat, dnext, B, rf, Cf, false, s);   // transpose of the gather = scatter back to the fine grid
+                std::swap(dcur, dnext);
+                res = rf; C = Cf;
+            }
+            run_blocks_bwd(enc[l]);
+        }
+        // PatchEmbed: modulate <- LN <- 1x1 conv (the inputs are leaves)
+        float *d_pe_ln = dnext, *d_pe_lin = t_mh;
+        t_modulate(Bf.pe_ln, Bf.pe_aff, dcur, d_pe_ln, Bf.pe_daff, B, T0, E, true, s);
+        t_gemm(true, false, Bf.pe_daff, 2 * E, Bf.emb, NOISE_EMB, nullptr, Gd("patch_embed.affine.weight"), NOISE_EMB, 2 * E, NOISE_EMB, B, false, s);
+        t_colsum(Bf.pe_daff, 2 * E, Gd("patch_embed.affine.bias"), B, 2 * E, s);
+        t_gemm(false, false, Bf.pe_daff, 2 * E, Wt("patch_embed.affine.weight"), NOISE_EMB, nullptr, Bf.d_emb, NOISE_EMB, B, NOISE_EMB, 2 * E, true, s);
+        ok = ok && hipMemsetAsync(d_pe_lin, 0, sizeof(float) * M0 * E, s) == hipSuccess;
+        t_ln_bwd(Bf.pe_lin, Wt("patch_embed.norm.weight"), Bf.pe_stats, d_pe_ln, d_pe_lin, t_mc2, (int)M0, E, s);
+        t_colsum(t_mc2, E, Gd("patch_embed.norm.weight"), (int)M0, E, s);
+        t_colsum(d_pe_ln, E, Gd("patch_embed.norm.bias"), (int)M0, E, s);
+        lin_bwd(Bf.tok, Wt("patch_embed.proj.weight"), d_pe_lin, nullptr, Gd("patch_embed.proj.weight"), Gd("patch_embed.proj.bias"), M0, Cin, E);
+        // noise embedding: emb = silu(map1(silu(map0(pe))))
+        float *d_m1 = t_mc, *d_s0 = t_mc2;
+        t_silu(Bf.m1, Bf.d_emb, d_m1, (size_t)B * NOISE_EMB, true, s);
+        lin_bwd(Bf.s0, Wt("map_layer1.weight"), d_m1, d_s0, Gd("map_layer1.weight"), Gd("map_layer1.bias"), B, NOISE_EMB, NOISE_EMB);
+        t_silu(Bf.m0, d_s0, d_s0, (size_t)B * NOISE_EMB, true, s);
+        lin_bwd(Bf.pe, Wt("map_layer0.weight"), d_s0, nullptr, Gd("map_layer0.weight"), Gd("map_layer0.bias"), B, E, NOISE_EMB);
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    const hipError_t e2 = hipGetLastError();
+    (void)hipFree(scr); (void)hipFree(A.base); (void)hipFree(has_sc_dev); (void)hipFree(mid_buf);
+    HIP_TRY(h, e);
+    HIP_TRY(h, e2);
+    if (!ok) return fail(h, DSG_ERR_HIP, "a training kernel failed to launch");
+    return DSG_OK;
+}
+
+int dsg_train_grads(dsg_handle h, int32_t B, const float *in_adj, const float *in_node, const uint8_t *flags, const float *c_noise,
+                    const float *sc_adj, const float *sc_node, const float *grad_F_adj, const float *grad_F_node, float *out_F_adj,
+                    float *out_F_node, int32_t n_params, const char *const *names, float *const *grad_params, void *stream) {
+    return train_grads_core(h, B, in_adj, in_node, flags, c_noise, sc_adj, sc_node, grad_F_adj, grad_F_node, nullptr, out_F_adj, out_F_node,
+                            n_params, names, grad_params, stream);
+}
+
+int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const float *noisy_node, const uint8_t *flags, const float *sigmas,
+                         const float *sc_adj, const float *sc_node, const float *target_adj, const float *target_node,
+                         const float *loss_weight, float edge_loss_weight, float node_loss_weight, float iou_loss_weight, float *out_D_adj,
+                         float *out_D_node, float *out_loss_adj, float *out_loss_node, int32_t n_params, const char *const *names,
+                         float *const *grad_params, void *stream) {
+    if (!h || !h->finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
+    if (B < 1 || !noisy_adj || !noisy_node || !flags || !sigmas || !target_adj || !target_node || !out_D_adj || !out_D_node || !out_loss_adj ||
+        !out_loss_node)
+        return fail(h, DSG_ERR_INVALID, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const Dims d = dims_of(h, B);
+    const size_t na = (size_t)B * h->Ca * h->N * h->N, nn = (size_t)B * h->N * h->Cn;
+    float *buf = nullptr;   // in_adj | in_node | c_noise | F_adj | F_node
+    HIP_TRY(h, hipMalloc((void **)&buf, sizeof(float) * (2 * na + 2 * nn + (size_t)B + 64)));
+    float *in_a = buf, *in_n = in_a + na, *cn = in_n + nn, *F_a = cn + ((B + 63) / 64) * 64, *F_n = F_a + na;
+    launch_precond_in(CStatePtrs{noisy_adj, noisy_node}, sigmas, StatePtrs{in_a, in_n}, cn, d, s);   // c_in * x, c_noise = ln(sigma)/4
+    const TrainMid mid = [&](const float *Fa, const float *Fn, float *dFa, float *dFn) -> int {
+        // D = mask(c_skip x + c_out F) (precond.py:101-104); per-sample losses; dL/dD; dL/dF = c_out dL/dD
+        launch_precond_out(CStatePtrs{noisy_adj, noisy_node}, CStatePtrs{Fa, Fn}, sigmas, flags, StatePtrs{out_D_adj, out_D_node},
+                           StatePtrs{nullptr, nullptr}, d, s);
+        launch_rainbow_loss(CStatePtrs{out_D_adj, out_D_node}, CStatePtrs{target_adj, target_node}, flags, loss_weight, edge_loss_weight,
+                            node_loss_weight, iou_loss_weight, out_loss_adj, out_loss_node, d, s);
+        float *tmp = nullptr;
+        if (hipMalloc((void **)&tmp, sizeof(float) * (na + nn)) != hipSuccess) return DSG_ERR_HIP;
+        launch_rainbow_loss_backward(CStatePtrs{out_D_adj, out_D_node}, CStatePtrs{target_adj, target_node}, flags, loss_weight,
+                                     edge_loss_weight, node_loss_weight, iou_loss_weight, sigmas, StatePtrs{tmp, tmp + na}, StatePtrs{dFa, dFn}, d, s);
+        const hipError_t e = hipStreamSynchronize(s);
+        (void)hipFree(tmp);
+        return e == hipSuccess ? DSG_OK : DSG_ERR_HIP;
+    };
+    const bool want_grads = names && grad_params && n_params > 0;
+    int rc = train_grads_core(h, B, in_a, in_n, flags, cn, sc_adj, sc_node, nullptr, nullptr, want_grads ? &mid : nullptr, F_a, F_n, n_params, names,
+                              grad_params, stream);
+    if (rc == DSG_OK && !want_grads) rc = mid(F_a, F_n, in_a, in_n);   // forward only: still report D and the losses (gradients discarded)
+    (void)hipFree(buf);
+    return rc;
 }
 
 double dsg_profile_clock_ghz(dsg_handle h) { return h ? h->prof_clock_ghz : 0.0; }

@@ -170,7 +170,24 @@ struct TrainBlockArgs {
     // stats1, stats2 [M, 2]; qkv, t_m3c [M, 3C]; pre, hid, t_mh [M, hidden]
     float *aff, *d_aff, *x_mod, *xn1, *att, *x1, *xn2, *d_x1, *t_mc, *t_mc2, *stats1, *stats2, *qkv, *t_m3c, *pre, *hid, *t_mh;
 };
-bool train_block(const TrainBlockArgs &a, hipStream_t s);
+bool train_block(const TrainBlockArgs &a, hipStream_t s);            // forward; + backward when a.grad_out is set
+bool train_block_backward(const TrainBlockArgs &a, hipStream_t s);   // backward alone, from the tensors the forward left in `a`
+// building blocks of the whole-network training step (same file): C (+)= op(A) op(B) (+ bias), column sums, elementwise / row ops
+void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K,
+            bool accumulate, hipStream_t s);
+void t_colsum(const float *X, int ld, float *out, int M, int N, hipStream_t s);
+void t_silu(const float *x, const float *dy, float *out, size_t n, bool bwd, hipStream_t s);
+void t_gelu(const float *x, const float *dy, float *out, size_t n, bool bwd, hipStream_t s);
+void t_add(float *a, const float *b, size_t n, hipStream_t s);
+void t_ln_fwd(const float *x, const float *gam, const float *bet, float *y, float *stats, int M, int C, hipStream_t s);
+void t_ln_bwd(const float *x, const float *gam, const float *stats, const float *dy, float *dx_acc, float *xhat_dy, int M, int C, hipStream_t s);
+void t_modulate(const float *x, const float *aff, const float *dy, float *out, float *d_aff, int B, int T, int C, bool bwd, hipStream_t s);
+void t_regroup(const float *src, float *dst, int B, int res, int C, bool gather, hipStream_t s);
+void t_concat(const float *x, const float *skip, float *cat, size_t M, int C, hipStream_t s);
+void t_split(const float *dcat, float *dx, float *dskip_acc, size_t M, int C, hipStream_t s);
+void t_adj_out(const float *oa, const uint8_t *flags, float *F, const float *dF, float *d_oa, int B, int N, int Ca, bool bwd, hipStream_t s);
+void t_pool_bwd(const float *d_pool, const uint8_t *flags, float *d_rep_acc, int B, int N, int E, hipStream_t s);
+void t_rowmask(const float *x, const uint8_t *flags, float *y, size_t M, int C, hipStream_t s);
 
 void launch_rainbow_loss_backward(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w,
                                   float iou_w, const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d, hipStream_t s);

@@ -282,6 +282,71 @@ static bool t_attn_launch(bool bwd, const float *qkv, const float *table, float 
     return true;
 }
 
+// ---- small kernels of the rest of the network (training form) ----
+__global__ void t_silu_fwd_kernel(const float *x, float *y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = x[i] * t_sigmoid(x[i]);
+}
+__global__ void t_silu_bwd_kernel(const float *x, const float *dy, float *dx, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float sg = t_sigmoid(x[i]);
+    dx[i] = dy[i] * (sg * (1.0f + x[i] * (1.0f - sg)));
+}
+// PatchMerging's 2x2 regrouping (diffusesg.py:322-327) and its inverse (PatchBreakup's scatter, :389-398, is the inverse with C = D/4):
+// coarse[((b T2 + i r2 + j) 4 + q) C + c] <-> fine[(b T + (2i + (q&1)) res + 2j + (q>>1)) C + c];  gather: coarse <- fine
+__global__ void t_regroup_kernel(const float *src, float *dst, int B, int res, int C, int gather, size_t n) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int c = idx % C;
+    const size_t tok = idx / C;
+    const int T = res * res, r2 = res / 2;
+    const int b = tok / T, t = tok % T, ti = t / res, tj = t % res;
+    const int q = (ti & 1) + 2 * (tj & 1);
+    const size_t coarse = (((size_t)b * (T / 4) + (size_t)(ti / 2) * r2 + tj / 2) * 4 + q) * C + c;
+    if (gather) dst[coarse] = src[idx]; else dst[idx] = src[coarse];
+}
+// cat[m] = (x[m] | skip[m])  and the split of its gradient (d_skip accumulates: the skip tensor also feeds the encoder's next stage)
+__global__ void t_concat_kernel(const float *x, const float *skip, float *cat, int C, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t m = i / (2 * C);
+    const int c = i % (2 * C);
+    cat[i] = c < C ? x[m * C + c] : skip[m * C + c - C];
+}
+__global__ void t_split_kernel(const float *dcat, float *dx, float *dskip_acc, int C, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t m = i / (2 * C);
+    const int c = i % (2 * C);
+    if (c < C) dx[m * C + c] = dcat[i]; else dskip_acc[m * C + c - C] += dcat[i];
+}
+// adjacency head tail: F_adj[b,a,i,j] = f_i f_j oa[(b,i,j)][a] (mask_adjs, diffusesg.py:825) and its transpose
+__global__ void t_adj_out_kernel(const float *oa, const uint8_t *flags, float *F, const float *dF, float *d_oa, int B, int N, int Ca, int bwd) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * N * N * Ca) return;
+    const int a = idx % Ca;
+    const size_t t = idx / Ca;
+    const int j = t % N, i = (t / N) % N, b = t / ((size_t)N * N);
+    const bool ok = flags[(size_t)b * N + i] && flags[(size_t)b * N + j];
+    const size_t k = (((size_t)b * Ca + a) * N + i) * N + j;
+    if (bwd) d_oa[idx] = ok ? dF[k] : 0.f; else F[k] = ok ? oa[idx] : 0.f;
+}
+// node pooling backward: d_rep[(b,i,j)][e] += f_i f_j d_pool[(b,i)][e] / N   (forward: launch_pool, diffusesg.py:812-815)
+__global__ void t_pool_bwd_kernel(const float *d_pool, const uint8_t *flags, float *d_rep_acc, int B, int N, int E) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * N * N * E) return;
+    const int e = idx % E;
+    const size_t t = idx / E;
+    const int j = t % N, i = (t / N) % N, b = t / ((size_t)N * N);
+    if (flags[(size_t)b * N + i] && flags[(size_t)b * N + j]) d_rep_acc[idx] += d_pool[((size_t)b * N + i) * E + e] / (float)N;
+}
+// y[m][c] = f_m x[m][c]   (mask_nodes on [B*N, Cn]; its own transpose)
+__global__ void t_rowmask_kernel(const float *x, const uint8_t *flags, float *y, int C, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = flags[i / C] ? x[i] : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // One block, forward (training form) + backward.  All buffers caller-provided (see dsg_block_train in dsg_api.cpp).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -306,7 +371,15 @@ bool train_block(const TrainBlockArgs &a, hipStream_t s) {
     if (hipMemcpyAsync(a.x_out, a.x1, sizeof(float) * nMC, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;
     t_gemm(false, true, a.hid, H, a.W.fc2_w, H, a.W.fc2_b, a.x_out, C, M, C, H, true, s);                                      // x_out = x1 + fc2(gelu(fc1(ln2)))
     if (!a.grad_out) return hipGetLastError() == hipSuccess;
-    // ---- backward ----  (d_x1 accumulates in a.d_x1; scratch tensors t_mc [M,C], t_mh [M,H], t_m3c [M,3C])
+    return train_block_backward(a, s);
+}
+
+// backward of the block from the tensors train_block's forward left in `a` (d_x1 accumulates in a.d_x1; scratch t_mc, t_mc2 [M,C],
+// t_mh [M,H], t_m3c [M,3C]; a.grad_out is read, a.grad_in / a.grad_emb / a.G.* are written)
+bool train_block_backward(const TrainBlockArgs &a, hipStream_t s) {
+    const int B = a.B, T = a.res * a.res, C = a.C, M = B * T, H = a.hidden;
+    const size_t nMC = (size_t)M * C, nMH = (size_t)M * H;
+    TAttnGeom g{a.res, a.ws, a.shift, a.heads, C};
     const float *dY = a.grad_out;
     // MLP: x_out = x1 + hid W2^T + b2
     t_gemm(true, false, dY, C, a.hid, H, nullptr, a.G.fc2_w, H, C, H, M, false, s);            // dW2 [C,H] = dY^T hid
@@ -339,6 +412,46 @@ bool train_block(const TrainBlockArgs &a, hipStream_t s) {
     t_colsum(a.d_aff, 2 * C, a.G.aff_b, B, 2 * C, s);
     t_gemm(false, false, a.d_aff, 2 * C, a.W.aff_w, NOISE_EMB, nullptr, a.grad_emb, NOISE_EMB, B, NOISE_EMB, 2 * C, false, s);   // d_emb
     return hipGetLastError() == hipSuccess;
+}
+
+// ---- launch wrappers used by the whole-network training step (dsg_api.cpp) ----
+void t_silu(const float *x, const float *dy, float *out, size_t n, bool bwd, hipStream_t s) {
+    if (bwd) hipLaunchKernelGGL(t_silu_bwd_kernel, dim3(t_blocks(n)), dim3(256), 0, s, x, dy, out, n);
+    else hipLaunchKernelGGL(t_silu_fwd_kernel, dim3(t_blocks(n)), dim3(256), 0, s, x, out, n);
+}
+void t_gelu(const float *x, const float *dy, float *out, size_t n, bool bwd, hipStream_t s) {
+    if (bwd) hipLaunchKernelGGL(t_gelu_bwd_kernel, dim3(t_blocks(n)), dim3(256), 0, s, x, dy, out, n);
+    else hipLaunchKernelGGL(t_gelu_fwd_kernel, dim3(t_blocks(n)), dim3(256), 0, s, x, out, n);
+}
+void t_add(float *a, const float *b, size_t n, hipStream_t s) { hipLaunchKernelGGL(t_add_kernel, dim3(t_blocks(n)), dim3(256), 0, s, a, b, n); }
+void t_ln_fwd(const float *x, const float *gam, const float *bet, float *y, float *stats, int M, int C, hipStream_t s) {
+    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, x, gam, bet, y, stats, M, C);
+}
+void t_ln_bwd(const float *x, const float *gam, const float *stats, const float *dy, float *dx_acc, float *xhat_dy, int M, int C, hipStream_t s) {
+    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, x, gam, stats, dy, dx_acc, xhat_dy, M, C);
+}
+void t_modulate(const float *x, const float *aff, const float *dy, float *out, float *d_aff, int B, int T, int C, bool bwd, hipStream_t s) {
+    if (bwd) hipLaunchKernelGGL(t_modulate_bwd_kernel, dim3((B * C + 63) / 64), dim3(64), 0, s, x, aff, dy, out, d_aff, B, T, C);
+    else hipLaunchKernelGGL(t_modulate_fwd_kernel, dim3(t_blocks((size_t)B * T * C)), dim3(256), 0, s, x, aff, out, T, C, (size_t)B * T * C);
+}
+void t_regroup(const float *src, float *dst, int B, int res, int C, bool gather, hipStream_t s) {
+    const size_t n = (size_t)B * res * res * C;
+    hipLaunchKernelGGL(t_regroup_kernel, dim3(t_blocks(n)), dim3(256), 0, s, src, dst, B, res, C, (int)gather, n);
+}
+void t_concat(const float *x, const float *skip, float *cat, size_t M, int C, hipStream_t s) {
+    hipLaunchKernelGGL(t_concat_kernel, dim3(t_blocks(M * 2 * C)), dim3(256), 0, s, x, skip, cat, C, M * 2 * C);
+}
+void t_split(const float *dcat, float *dx, float *dskip_acc, size_t M, int C, hipStream_t s) {
+    hipLaunchKernelGGL(t_split_kernel, dim3(t_blocks(M * 2 * C)), dim3(256), 0, s, dcat, dx, dskip_acc, C, M * 2 * C);
+}
+void t_adj_out(const float *oa, const uint8_t *flags, float *F, const float *dF, float *d_oa, int B, int N, int Ca, bool bwd, hipStream_t s) {
+    hipLaunchKernelGGL(t_adj_out_kernel, dim3(t_blocks((size_t)B * N * N * Ca)), dim3(256), 0, s, oa, flags, F, dF, d_oa, B, N, Ca, (int)bwd);
+}
+void t_pool_bwd(const float *d_pool, const uint8_t *flags, float *d_rep_acc, int B, int N, int E, hipStream_t s) {
+    hipLaunchKernelGGL(t_pool_bwd_kernel, dim3(t_blocks((size_t)B * N * N * E)), dim3(256), 0, s, d_pool, flags, d_rep_acc, B, N, E);
+}
+void t_rowmask(const float *x, const uint8_t *flags, float *y, size_t M, int C, hipStream_t s) {
+    hipLaunchKernelGGL(t_rowmask_kernel, dim3(t_blocks(M * C)), dim3(256), 0, s, x, flags, y, C, M * C);
 }
 
 }  // namespace dsg

@@ -205,3 +205,39 @@ def swin_block_train(net, block: str, x, emb, grad_out=None):
     h.check(h.L.dsg_block_train(h._h, block.encode(), B, _p(x), _p(emb), _p(gy), _p(x_out), _p(gx), _p(ge), len(BLOCK_PARAM_NAMES) if grads else 0,
                                 names, ptrs, C.c_void_p(st)), "dsg_block_train")
     return x_out, gx, ge, grads
+
+
+@torch.no_grad()
+def train_step_grads(model, loss_func, net_input_a, net_input_x, node_flags, sigmas, net_target_a, net_target_x, loss_weight,
+                     iou_loss_weight=0.0, want_grads=True):
+    """One training iteration up to and including `loss.backward()` (trainer_node_adj.py:96-170) on the device:
+    `model(adjs=net_input_a, nodes=net_input_x, node_flags=..., sigmas=...)` with the network in training form (the self-conditioning
+    coin is drawn from NumPy's global generator like precond.py:90 and the detached self-conditioning pass runs on the sampling path),
+    per-sample losses, and the gradient of `loss_adj.mean() + loss_node.mean()` for every parameter.
+    -> (net_output_a, net_output_x, reg_loss_adj [B], reg_loss_node [B], {state-dict key: gradient}).
+    Correctness-first kernels (`dsg_train_step_grads`), pinned to the reference's autograd; optimiser / EMA / clipping / DDP are not built."""
+    import numpy as np
+    m = model.model
+    h = m._ensure_handle()
+    B, a, x, fl, _, _ = m._canon(net_input_a, net_input_x, node_flags, None, None)
+    _, ta, tx, _, _, _ = m._canon(net_target_a, net_target_x, node_flags, None, None)
+    dev = m._dev
+    sg = torch.as_tensor(sigmas).to(device=dev, dtype=torch.float32).reshape(-1).expand(B).contiguous()
+    w = None if loss_weight is None else loss_weight.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    sa = sx = None
+    if model.self_condition and np.random.rand() < 0.5:   # precond.py:90-98: D of a no-grad pass becomes the (detached) self-cond input
+        sa, sx = torch.empty_like(a), torch.empty_like(x)
+        h.check(h.L.dsg_precond(h.raw, B, _p(a), _p(x), _p(fl), _p(sg), None, None, 0, _p(sa), _p(sx), st), "dsg_precond")
+    keys = [k for k, _ in m.named_parameters()] if want_grads else []
+    sd = dict(m.named_parameters())
+    grads = {k: torch.zeros(tuple(sd[k].shape), device=dev, dtype=torch.float32) for k in keys}
+    names = (C.c_char_p * max(len(keys), 1))(*[k.encode() for k in keys]) if keys else None
+    ptrs = (C.c_void_p * max(len(keys), 1))(*[grads[k].data_ptr() for k in keys]) if keys else None
+    da, dx_ = torch.empty_like(a), torch.empty_like(x)
+    la, ln = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    h.check(h.L.dsg_train_step_grads(h.raw, B, _p(a), _p(x), _p(fl), _p(sg), _p(sa), _p(sx), _p(ta), _p(tx), _p(w),
+                                     float(loss_func.edge_loss_weight), float(loss_func.node_loss_weight), float(iou_loss_weight),
+                                     _p(da), _p(dx_), _p(la), _p(ln), len(keys), names, ptrs, st), "dsg_train_step_grads")
+    oa, on = m._shape_out(da, dx_)
+    return oa, on, la, ln, grads

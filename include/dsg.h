@@ -248,6 +248,29 @@ int dsg_rainbow_loss_backward(int32_t B, int32_t N, int32_t c_adj, int32_t c_nod
 int dsg_block_train(dsg_handle h, const char *block, int32_t B, const float *x_in, const float *emb, const float *grad_out, float *x_out,
                     float *grad_in, float *grad_emb, int32_t n_params, const char *const *names, float *const *grad_params, void *stream);
 
+/* The whole network in training form: F = DiffuseSG.forward(in_adj, in_node, flags, c_noise, sc_adj, sc_node)
+ * (R/model/diffusesg/diffusesg.py:765-830) and, when grad_F_adj != NULL, the gradient of every parameter for the upstream gradients
+ * dL/dF (e.g. from dsg_rainbow_loss_backward) -- what loss.backward() of a training step leaves in the parameters' .grad
+ * (R/runner/trainer/trainer_node_adj.py:163-170), pinned by tests/golden/train_backward.npz.  Correctness-first kernels
+ * (csrc/train_kernels.hip), far from the sampling path's speed; optimiser, EMA and DDP are not built.
+ *   in_adj [B,C_adj,N,N], in_node [B,N,C_node]: the preconditioned inputs c_in(sigma) * noisy (precond.py:100); c_noise [B];
+ *   sc_*: the self-conditioning inputs (constants: the reference detaches them) or NULL; out_F_*: the raw network outputs;
+ *   names[i] (state-dict keys of all parameters) -> grad_params[i] (device buffers of the parameters' shapes, overwritten). */
+int dsg_train_grads(dsg_handle h, int32_t B, const float *in_adj, const float *in_node, const uint8_t *flags, const float *c_noise,
+                    const float *sc_adj, const float *sc_node, const float *grad_F_adj, const float *grad_F_node, float *out_F_adj,
+                    float *out_F_node, int32_t n_params, const char *const *names, float *const *grad_params, void *stream);
+
+/* One training iteration up to and including loss.backward() (R/runner/trainer/trainer_node_adj.py:96-170, 'edm' objective):
+ * D = NodeAdjPrecond(noisy, sigmas) with the network in training form, per-sample losses as dsg_rainbow_loss, and -- when the gradient
+ * buffers are given -- the gradient of  loss_adj.mean() + loss_node.mean()  for every parameter.  sc_*: the detached self-conditioning
+ * inputs (precond.py:90-98; the Python mirror draws the coin and computes them with dsg_precond) or NULL.  The caller supplies the
+ * objective's tensors (dsg_train_inputs); optimiser step, EMA, gradient clipping and DDP are not built. */
+int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const float *noisy_node, const uint8_t *flags, const float *sigmas,
+                         const float *sc_adj, const float *sc_node, const float *target_adj, const float *target_node,
+                         const float *loss_weight, float edge_loss_weight, float node_loss_weight, float iou_loss_weight, float *out_D_adj,
+                         float *out_D_node, float *out_loss_adj, float *out_loss_node, int32_t n_params, const char *const *names,
+                         float *const *grad_params, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -981,6 +981,49 @@ def test_swin_block_forward_backward_vs_reference_autograd(name, prefix, B):
     assert torch.equal(x_out2, x_out)
 
 
+def test_training_step_gradients_vs_reference_autograd():
+    """tests/golden/train_backward.npz: one whole training iteration of the reference (trainer_node_adj.py:96-170 in 'train' mode) up
+    to loss.backward() -- objective, self-conditioning coin, the network in training form, the sigma-weighted loss with the IoU term
+    -- against dsg_train_step_grads: the preconditioned outputs, the loss, and the gradient of EVERY parameter (247-key state dict of
+    the tiny model: L2 norm and a strided sample each) plus the total gradient norm clip_grad_norm_ reports"""
+    from diffusesg_amd.model import build_network
+    from diffusesg_amd.train import NodeAdjEDMObjectiveGeneratorHip, NodeAdjRainbowLossHip, train_step_grads
+    g = load("train_backward.npz")
+    cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case("tiny")
+    model = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")
+    gen = NodeAdjEDMObjectiveGeneratorHip(precond="edm", sigma_dist="edm", other_params=None, dev="cuda", symmetric_noise=False)
+    loss_func = NodeAdjRainbowLossHip(edge_loss_weight=1.0, node_loss_weight=1.0, flag_reweight=False, objective="edm")
+    na, nx, cond, ta, tx, (c_skip, c_out, c_in, c_noise, sigmas, weights) = gen.get_input_output(
+        T(clean_adj), T(clean_node), T(flags), rnd_sigma=T(rnd), noise=(T(eps_adj), T(eps_node)))
+    real = np.random.rand
+    np.random.rand = lambda: coin
+    try:
+        oa, on, la, ln, grads = train_step_grads(model, loss_func, na, nx, T(flags), sigmas, T(clean_adj), T(clean_node), weights,
+                                                 iou_loss_weight=1.0)
+    finally:
+        np.random.rand = real
+    assert_close(oa.cpu().numpy(), g["tiny_pred_adj"], 2e-5, "preconditioned output adj")
+    assert_close(on.cpu().numpy(), g["tiny_pred_node"], 2e-5, "preconditioned output node")
+    loss = float(la.mean() + ln.mean())
+    assert abs(loss - float(g["tiny_loss"])) <= 5e-4 * abs(float(g["tiny_loss"]))
+    names = [str(k) for k in g["tiny_gparam_names"]]
+    assert set(k[len("model."):] if k.startswith("model.") else k for k in names) == set(grads.keys())
+    tot, worst = 0.0, (0.0, "")
+    for k, ref_norm in zip(names, g["tiny_gparam_norms"]):
+        key = k[len("model."):] if k.startswith("model.") else k
+        mine = grads[key].cpu().numpy().reshape(-1)
+        ref = g[f"tiny_gparam/{k}"]
+        stride = max(1, -(-mine.size // 1024))
+        scale = max(float(np.abs(ref).max()), 1e-3 * float(ref_norm) / np.sqrt(mine.size) + 1e-12)
+        err = float(np.abs(mine[::stride] - ref).max()) / scale
+        worst = max(worst, (err, key))
+        nrm = float(np.sqrt((mine.astype(np.float64) ** 2).sum()))
+        assert abs(nrm - float(ref_norm)) <= 2e-3 * float(ref_norm) + 1e-7, (key, nrm, float(ref_norm))
+        tot += nrm ** 2
+    assert worst[0] <= 2e-3, worst
+    assert abs(np.sqrt(tot) - float(g["tiny_total_grad_norm"])) <= 1e-3 * float(g["tiny_total_grad_norm"])
+
+
 def test_train_backward_head_vs_reference_autograd():
     """tests/golden/train_backward.npz (the reference's own autograd over one training step): dL/d(preconditioned outputs) incl.
     the IoU term's clamp / max / min branches, and dL/d(raw network outputs) = c_out(sigma) * that -- the first stage of the
