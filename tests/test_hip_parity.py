@@ -981,15 +981,18 @@ def test_swin_block_forward_backward_vs_reference_autograd(name, prefix, B):
     assert torch.equal(x_out2, x_out)
 
 
-def test_training_step_gradients_vs_reference_autograd():
+@pytest.mark.parametrize("case,cfg_name,B,max_sample", [("tiny", "tiny", 4, 1024), ("tinysc", "tiny", 4, 256), ("vg", "vg", 2, 64)])
+def test_training_step_gradients_vs_reference_autograd(case, cfg_name, B, max_sample):
     """tests/golden/train_backward.npz: one whole training iteration of the reference (trainer_node_adj.py:96-170 in 'train' mode) up
     to loss.backward() -- objective, self-conditioning coin, the network in training form, the sigma-weighted loss with the IoU term
-    -- against dsg_train_step_grads: the preconditioned outputs, the loss, and the gradient of EVERY parameter (247-key state dict of
-    the tiny model: L2 norm and a strided sample each) plus the total gradient norm clip_grad_norm_ reports"""
+    -- against dsg_train_step_grads: the preconditioned outputs, the loss, and the gradient of EVERY parameter (95 tensors of the tiny
+    model, 233 of the Visual Genome model: L2 norm and a strided sample each) plus the total gradient norm clip_grad_norm_ reports.
+    `tinysc` / `vg`: the coin fires, the detached self-conditioning pass (sampling path) feeds the differentiated one."""
     from diffusesg_amd.model import build_network
     from diffusesg_amd.train import NodeAdjEDMObjectiveGeneratorHip, NodeAdjRainbowLossHip, train_step_grads
     g = load("train_backward.npz")
-    cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case("tiny")
+    cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case(cfg_name, B=B)
+    coin = float(g[f"{case}_coin"])
     model = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")
     gen = NodeAdjEDMObjectiveGeneratorHip(precond="edm", sigma_dist="edm", other_params=None, dev="cuda", symmetric_noise=False)
     loss_func = NodeAdjRainbowLossHip(edge_loss_weight=1.0, node_loss_weight=1.0, flag_reweight=False, objective="edm")
@@ -1002,26 +1005,26 @@ def test_training_step_gradients_vs_reference_autograd():
                                                  iou_loss_weight=1.0)
     finally:
         np.random.rand = real
-    assert_close(oa.cpu().numpy(), g["tiny_pred_adj"], 2e-5, "preconditioned output adj")
-    assert_close(on.cpu().numpy(), g["tiny_pred_node"], 2e-5, "preconditioned output node")
+    if f"{case}_pred_adj" in g.files:
+        assert_close(oa.cpu().numpy(), g[f"{case}_pred_adj"], 2e-5, "preconditioned output adj")
+        assert_close(on.cpu().numpy(), g[f"{case}_pred_node"], 2e-5, "preconditioned output node")
     loss = float(la.mean() + ln.mean())
-    assert abs(loss - float(g["tiny_loss"])) <= 5e-4 * abs(float(g["tiny_loss"]))
-    names = [str(k) for k in g["tiny_gparam_names"]]
-    assert set(k[len("model."):] if k.startswith("model.") else k for k in names) == set(grads.keys())
+    assert abs(loss - float(g[f"{case}_loss"])) <= 2e-4 * abs(float(g[f"{case}_loss"]))
+    names = [str(k) for k in g[f"{case}_gparam_names"]]
+    assert set(k[len("model."):] for k in names) == set(grads.keys())
     tot, worst = 0.0, (0.0, "")
-    for k, ref_norm in zip(names, g["tiny_gparam_norms"]):
-        key = k[len("model."):] if k.startswith("model.") else k
+    for k, ref_norm in zip(names, g[f"{case}_gparam_norms"]):
+        key = k[len("model."):]
         mine = grads[key].cpu().numpy().reshape(-1)
-        ref = g[f"tiny_gparam/{k}"]
-        stride = max(1, -(-mine.size // 1024))
-        scale = max(float(np.abs(ref).max()), 1e-3 * float(ref_norm) / np.sqrt(mine.size) + 1e-12)
-        err = float(np.abs(mine[::stride] - ref).max()) / scale
+        ref = g[f"{case}_gparam/{k}"]
+        stride = max(1, -(-mine.size // max_sample))
+        err = float(np.abs(mine[::stride] - ref).max()) / max(float(np.abs(ref).max()), 1e-12)
         worst = max(worst, (err, key))
         nrm = float(np.sqrt((mine.astype(np.float64) ** 2).sum()))
-        assert abs(nrm - float(ref_norm)) <= 2e-3 * float(ref_norm) + 1e-7, (key, nrm, float(ref_norm))
+        assert abs(nrm - float(ref_norm)) <= 1e-4 * float(ref_norm) + 1e-9, (key, nrm, float(ref_norm))
         tot += nrm ** 2
-    assert worst[0] <= 2e-3, worst
-    assert abs(np.sqrt(tot) - float(g["tiny_total_grad_norm"])) <= 1e-3 * float(g["tiny_total_grad_norm"])
+    assert worst[0] <= 2e-4, worst
+    assert abs(np.sqrt(tot) - float(g[f"{case}_total_grad_norm"])) <= 1e-4 * float(g[f"{case}_total_grad_norm"])
 
 
 def test_train_backward_head_vs_reference_autograd():

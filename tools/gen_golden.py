@@ -385,123 +385,111 @@ def gen_train_forward(DiffuseSG, NodeAdjPrecond, out):
 
 def gen_train_backward(DiffuseSG, NodeAdjPrecond, out):
     """G8: gradients of one training step from the reference's own autograd (R/runner/trainer/trainer_node_adj.py:96-170,
-    mode 'train' up to and including loss.backward() and the clip-norm it computes): same inputs, draws and coin as G7.
-    Saved: dL/d(preconditioned outputs), dL/d(raw network outputs F_x, F_feat), the gradient of every parameter of the
-    preconditioned model (tiny config, per tensor: L2 norm and every stride-th element, <= 1024 values; the pinned target of the network backward, which is not built yet), the total gradient
-    norm nn.utils.clip_grad_norm_ reports.  torchvision's box helpers are restated as in G7."""
+    mode 'train' up to and including loss.backward(), the clip-norm it computes and -- tiny case -- the Adam step of
+    utils/learning_utils.py:137-140 with the YAMLs' lr 2e-4 / weight_decay 0).  Cases: `tiny` (inputs, draws and coin of G7: the coin
+    does not fire), `tinysc` (same, coin forced to 0.3: the detached self-conditioning pass feeds the differentiated one), `vg` (the
+    Visual Genome network, B = 2, coin 0.3; 64-token shifted windows on four levels).  Saved per case: loss, dL/d(preconditioned
+    outputs), dL/d(raw network outputs), per parameter the gradient's L2 norm and every stride-th element (<= 1024, tinysc: <= 256, vg: <= 64), the
+    total gradient norm nn.utils.clip_grad_norm_ reports; tiny: the parameters after the optimiser step (<= 256 values each).
+    torchvision's box helpers are restated as in G7."""
     import model.precond.precond as P
     from loss.rainbow_loss import NodeAdjRainbowLoss
     from runner.objectives.edm import NodeAdjEDMObjectiveGenerator
     res = {}
-    name = "tiny"
-    cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case(name)
-    net = build_ref_net(DiffuseSG, cfg)
-    model = NodeAdjPrecond("edm", net, cfg.self_condition, symmetric_noise=False)
-    model.train()
-    gen = NodeAdjEDMObjectiveGenerator(precond="edm", sigma_dist="edm", other_params=None, dev="cpu", symmetric_noise=False)
-    draws = _Replay([rnd, eps_adj, eps_node])
-
-    def fake_randn(*size, **kw):
-        return torch.from_numpy(np.ascontiguousarray(draws.pop()).copy())
-
-    def fake_randn_like(x, **kw):
-        return torch.from_numpy(np.ascontiguousarray(draws.pop()).reshape(tuple(x.shape)).copy()).to(x.dtype)
-
-    raw = {}
-
-    def keep_raw(mod, inp, outp):   # the LAST call of the network is the differentiated one (the coin's extra call runs under no_grad)
-        if outp[0].requires_grad:
-            outp[0].retain_grad(); outp[1].retain_grad()
-            raw["a"], raw["x"] = outp
-    hook = net.register_forward_hook(keep_raw)
-    real_r, real_rl, real_rand = torch.randn, torch.randn_like, P.np.random.rand
-    torch.randn, torch.randn_like = fake_randn, fake_randn_like
-    P.np.random.rand = lambda: coin
-    try:
-        adjs_gt, nodes_gt, node_flags = t(clean_adj.copy()), t(clean_node.copy()), t(flags)
-        net_input_a, net_input_x, net_cond, net_target_a, net_target_x, (c_skip, c_out, c_in, c_noise, sigmas, weights) = \
-            gen.get_input_output(adjs_gt, nodes_gt, node_flags)
-        model.zero_grad(set_to_none=True)
-        net_output_a, net_output_x = model(adjs=net_input_a, nodes=net_input_x, node_flags=node_flags, sigmas=sigmas)
-    finally:
-        torch.randn, torch.randn_like, P.np.random.rand = real_r, real_rl, real_rand
-        hook.remove()
-    net_output_a.retain_grad(); net_output_x.retain_grad()
-    loss_func = NodeAdjRainbowLoss(edge_loss_weight=1.0, node_loss_weight=1.0, flag_reweight=False, objective="edm")
-    reg_loss_adj, reg_loss_node = loss_func(net_pred_a=net_output_a, net_pred_x=net_output_x, net_target_a=net_target_a,
-                                            net_target_x=net_target_x, net_cond=net_cond, adjs_perturbed=net_input_a,
-                                            adjs_gt=adjs_gt, x_perturbed=net_input_x, x_gt=nodes_gt, node_flags=node_flags,
-                                            loss_weight=weights, reduction='none')
-    iou_loss_weight = 1.0
-
-    def box_convert_cxcywh_xyxy(b):
-        cx, cy, w, h = b.unbind(-1)
-        return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
-
-    def box_iou_diag(a, b):
-        area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
-        area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-        lt, rb = torch.max(a[:, :2], b[:, :2]), torch.min(a[:, 2:], b[:, 2:])
-        wh = (rb - lt).clamp(min=0)
-        inter = wh[:, 0] * wh[:, 1]
-        return inter / (area_a + area_b - inter)
-    ob = box_convert_cxcywh_xyxy((net_output_x[..., -4:] + 1.0) / 2.0).clamp(min=0.0, max=1.0)
-    tb = box_convert_cxcywh_xyxy((net_target_x[..., -4:] + 1.0) / 2.0).clamp(min=0.0, max=1.0)
-    node_iou_loss = -(box_iou_diag(ob.view(-1, 4), tb.view(-1, 4)).view(-1)) ** 2.0
-    node_flags_t = node_flags.view(-1)
-    node_iou_loss = (node_iou_loss * node_flags_t.to(torch.float32)).view(-1, node_flags.shape[1])
-    node_iou_loss = node_iou_loss.sum(dim=-1) / node_flags_t.sum(dim=-1).to(torch.float32)
-    reg_loss_node = reg_loss_node + iou_loss_weight * node_iou_loss * weights
-    loss = reg_loss_adj.mean() + reg_loss_node.mean()
-    loss.backward()
-    total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10.0, norm_type=2)   # returns the norm BEFORE clipping
-    res[f"{name}_loss"] = np.array(float(loss.detach()))
-    res[f"{name}_sigmas"], res[f"{name}_weights"] = sigmas.detach().numpy().copy(), weights.detach().numpy().copy()
-    res[f"{name}_pred_adj"], res[f"{name}_pred_node"] = net_output_a.detach().numpy().copy(), net_output_x.detach().numpy().copy()
-    res[f"{name}_grad_pred_adj"], res[f"{name}_grad_pred_node"] = net_output_a.grad.numpy().copy(), net_output_x.grad.numpy().copy()
-    res[f"{name}_grad_F_adj"], res[f"{name}_grad_F_node"] = raw["a"].grad.numpy().copy(), raw["x"].grad.numpy().copy()
-    res[f"{name}_total_grad_norm"] = np.array(float(total_norm))
-    scale = min(1.0, 10.0 / (float(total_norm) + 1e-6))
-    n_par = 0
-    names, norms = [], []
-    for k, p_ in model.named_parameters():   # un-clipped gradients: small tensors whole, large ones as every stride-th element + norm
-        assert p_.grad is not None, k
-        g_ = (p_.grad / scale).numpy().reshape(-1)
-        stride = max(1, -(-g_.size // 1024))
-        res[f"{name}_gparam/{k}"] = g_[::stride].copy()
-        names.append(k); norms.append(float(np.sqrt((g_.astype(np.float64) ** 2).sum())))
-        n_par += p_.numel()
-    res[f"{name}_gparam_names"] = np.array(names)
-    res[f"{name}_gparam_norms"] = np.array(norms)
-    print(f"train backward {name}: loss {float(loss):.6f}, |grad| {float(total_norm):.5f} over {n_par} parameters, "
-          f"|dL/dF_adj| {float(raw['a'].grad.norm()):.4e}, |dL/dF_node| {float(raw['x'].grad.norm()):.4e}")
-    np.savez_compressed(os.path.join(out, "train_backward.npz"), **res)
-
-
-def gen_noise_embed(DiffuseSG, out):
-    """G1 (stand-alone): the noise-conditioning path on its own -- PositionalEmbedding (`map_noise`), map_layer0/1 with SiLU
-    (diffusesg.py:768-771) and every `affine` linear applied to the embedding (PatchEmbed :574, the Swin blocks :238), concatenated
-    in module order: patch_embed, down_layers[l].blocks[j], up_layers[i].blocks[j]."""
-    from torch.nn.functional import silu
-    res = {}
-    c_noise = np.array([-2.3, -0.35, 0.4, 1.0955], np.float32)   # ln(sigma)/4 for sigma in [1e-4, 80]
-    res["c_noise"] = c_noise
-    for name in ("tiny", "vg", "coco"):
-        cfg = CONFIGS[name]()
+    for name, cfg_name, B, forced_coin, max_sample in (("tiny", "tiny", 4, None, 1024), ("tinysc", "tiny", 4, 0.3, 256), ("vg", "vg", 2, 0.3, 64)):
+        cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case(cfg_name, B=B)
+        if forced_coin is not None:
+            coin = forced_coin
         net = build_ref_net(DiffuseSG, cfg)
-        with torch.no_grad():
-            pe = net.map_noise(t(c_noise))
-            emb = silu(net.map_layer1(silu(net.map_layer0(pe))))
-            aff = [net.patch_embed.affine(emb)]
-            for l in net.down_layers:
-                aff += [b.affine(emb) for b in l.blocks]
-            for l in net.up_layers:
-                aff += [b.affine(emb) for b in l.blocks]
-        res[f"{name}_pe"], res[f"{name}_emb"] = pe.numpy(), emb.numpy()
-        if name != "coco":   # (kept small: COCO's 11328 affine outputs add nothing the VG table does not exercise)
-            res[f"{name}_aff"] = torch.cat(aff, dim=1).numpy()
-        print(f"noise embed {name}: pe {tuple(pe.shape)} emb {tuple(emb.shape)} affine outputs {sum(a.shape[1] for a in aff)}")
-    np.savez_compressed(os.path.join(out, "noise_embed.npz"), **res)
+        model = NodeAdjPrecond("edm", net, cfg.self_condition, symmetric_noise=False)
+        model.train()
+        gen = NodeAdjEDMObjectiveGenerator(precond="edm", sigma_dist="edm", other_params=None, dev="cpu", symmetric_noise=False)
+        draws = _Replay([rnd, eps_adj, eps_node])
+
+        def fake_randn(*size, **kw):
+            return torch.from_numpy(np.ascontiguousarray(draws.pop()).copy())
+
+        def fake_randn_like(x, **kw):
+            return torch.from_numpy(np.ascontiguousarray(draws.pop()).reshape(tuple(x.shape)).copy()).to(x.dtype)
+
+        raw = {}
+
+        def keep_raw(mod, inp, outp):   # the LAST call of the network is the differentiated one (the coin's extra call runs under no_grad)
+            if outp[0].requires_grad:
+                outp[0].retain_grad(); outp[1].retain_grad()
+                raw["a"], raw["x"] = outp
+        hook = net.register_forward_hook(keep_raw)
+        real_r, real_rl, real_rand = torch.randn, torch.randn_like, P.np.random.rand
+        torch.randn, torch.randn_like = fake_randn, fake_randn_like
+        P.np.random.rand = lambda: coin
+        try:
+            adjs_gt, nodes_gt, node_flags = t(clean_adj.copy()), t(clean_node.copy()), t(flags)
+            net_input_a, net_input_x, net_cond, net_target_a, net_target_x, (c_skip, c_out, c_in, c_noise, sigmas, weights) = \
+                gen.get_input_output(adjs_gt, nodes_gt, node_flags)
+            optimizer = torch.optim.Adam(model.parameters(), lr=2.0e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+            optimizer.zero_grad(set_to_none=True)
+            net_output_a, net_output_x = model(adjs=net_input_a, nodes=net_input_x, node_flags=node_flags, sigmas=sigmas)
+        finally:
+            torch.randn, torch.randn_like, P.np.random.rand = real_r, real_rl, real_rand
+            hook.remove()
+        net_output_a.retain_grad(); net_output_x.retain_grad()
+        loss_func = NodeAdjRainbowLoss(edge_loss_weight=1.0, node_loss_weight=1.0, flag_reweight=False, objective="edm")
+        reg_loss_adj, reg_loss_node = loss_func(net_pred_a=net_output_a, net_pred_x=net_output_x, net_target_a=net_target_a,
+                                                net_target_x=net_target_x, net_cond=net_cond, adjs_perturbed=net_input_a,
+                                                adjs_gt=adjs_gt, x_perturbed=net_input_x, x_gt=nodes_gt, node_flags=node_flags,
+                                                loss_weight=weights, reduction='none')
+        iou_loss_weight = 1.0
+
+        def box_convert_cxcywh_xyxy(b):
+            cx, cy, w, h = b.unbind(-1)
+            return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+        def box_iou_diag(a, b):
+            area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+            area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+            lt, rb = torch.max(a[:, :2], b[:, :2]), torch.min(a[:, 2:], b[:, 2:])
+            wh = (rb - lt).clamp(min=0)
+            inter = wh[:, 0] * wh[:, 1]
+            return inter / (area_a + area_b - inter)
+        ob = box_convert_cxcywh_xyxy((net_output_x[..., -4:] + 1.0) / 2.0).clamp(min=0.0, max=1.0)
+        tb = box_convert_cxcywh_xyxy((net_target_x[..., -4:] + 1.0) / 2.0).clamp(min=0.0, max=1.0)
+        node_iou_loss = -(box_iou_diag(ob.view(-1, 4), tb.view(-1, 4)).view(-1)) ** 2.0
+        node_flags_t = node_flags.view(-1)
+        node_iou_loss = (node_iou_loss * node_flags_t.to(torch.float32)).view(-1, node_flags.shape[1])
+        node_iou_loss = node_iou_loss.sum(dim=-1) / node_flags_t.sum(dim=-1).to(torch.float32)
+        reg_loss_node = reg_loss_node + iou_loss_weight * node_iou_loss * weights
+        loss = reg_loss_adj.mean() + reg_loss_node.mean()
+        loss.backward()
+        total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10.0, norm_type=2)   # returns the norm BEFORE clipping
+        res[f"{name}_loss"] = np.array(float(loss.detach()))
+        res[f"{name}_coin"] = np.array(coin)
+        res[f"{name}_sigmas"], res[f"{name}_weights"] = sigmas.detach().numpy().copy(), weights.detach().numpy().copy()
+        res[f"{name}_total_grad_norm"] = np.array(float(total_norm))
+        if name != "vg":
+            res[f"{name}_pred_adj"], res[f"{name}_pred_node"] = net_output_a.detach().numpy().copy(), net_output_x.detach().numpy().copy()
+        if name == "tiny":
+            res[f"{name}_grad_pred_adj"], res[f"{name}_grad_pred_node"] = net_output_a.grad.numpy().copy(), net_output_x.grad.numpy().copy()
+            res[f"{name}_grad_F_adj"], res[f"{name}_grad_F_node"] = raw["a"].grad.numpy().copy(), raw["x"].grad.numpy().copy()
+        scale = min(1.0, 10.0 / (float(total_norm) + 1e-6))
+        n_par = 0
+        names, norms = [], []
+        for k, p_ in model.named_parameters():   # un-clipped gradients: small tensors whole, large ones as every stride-th element + norm
+            assert p_.grad is not None, k
+            g_ = (p_.grad / scale).numpy().reshape(-1)
+            stride = max(1, -(-g_.size // max_sample))
+            res[f"{name}_gparam/{k}"] = g_[::stride].copy()
+            names.append(k); norms.append(float(np.sqrt((g_.astype(np.float64) ** 2).sum())))
+            n_par += p_.numel()
+        res[f"{name}_gparam_names"] = np.array(names)
+        res[f"{name}_gparam_norms"] = np.array(norms)
+        if name == "tiny":   # the optimiser step on the clipped gradients (trainer_node_adj.py:170-171)
+            optimizer.step()
+            for k, p_ in model.named_parameters():
+                v_ = p_.detach().numpy().reshape(-1)
+                res[f"{name}_param_after/{k}"] = v_[::max(1, -(-v_.size // 256))].copy()
+        print(f"train backward {name}: loss {float(loss):.6f}, |grad| {float(total_norm):.5f} over {n_par} parameters ({len(names)} tensors), "
+              f"coin {coin:.3f}, |dL/dF_adj| {float(raw['a'].grad.norm()):.4e}")
+    np.savez_compressed(os.path.join(out, "train_backward.npz"), **res)
 
 
 BLOCK_CASES = [("small", "down_layers.0.blocks.1", 2),    # 16x16 tokens, 4x4 windows, shift 2: the -100 region mask is active
