@@ -2066,6 +2066,21 @@ int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const 
     return rc;
 }
 
+int dsg_adam_step(int32_t n_tensors, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                  const int64_t *numel, int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                  float *out_total_norm, void *stream) {
+    if (n_tensors < 1 || !params || !grads || !exp_avg || !exp_avg_sq || !numel || step < 1) return DSG_ERR_INVALID;
+    for (int i = 0; i < n_tensors; i++) if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] < 1) return DSG_ERR_INVALID;
+    return t_adam_step(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, step, lr, beta1, beta2, eps, weight_decay, max_grad_norm,
+                       out_total_norm, (hipStream_t)stream) ? DSG_OK : DSG_ERR_HIP;
+}
+
+int dsg_ema_update(int32_t n_tensors, float *const *ema, const float *const *params, const int64_t *numel, float decay, void *stream) {
+    if (n_tensors < 1 || !ema || !params || !numel) return DSG_ERR_INVALID;
+    for (int i = 0; i < n_tensors; i++) if (!ema[i] || !params[i] || numel[i] < 1) return DSG_ERR_INVALID;
+    return t_ema_update(n_tensors, ema, params, numel, decay, (hipStream_t)stream) ? DSG_OK : DSG_ERR_HIP;
+}
+
 double dsg_profile_clock_ghz(dsg_handle h) { return h ? h->prof_clock_ghz : 0.0; }
 
 int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, int32_t n_adj_type,

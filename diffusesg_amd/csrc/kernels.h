@@ -188,6 +188,9 @@ void t_split(const float *dcat, float *dx, float *dskip_acc, size_t M, int C, hi
 void t_adj_out(const float *oa, const uint8_t *flags, float *F, const float *dF, float *d_oa, int B, int N, int Ca, bool bwd, hipStream_t s);
 void t_pool_bwd(const float *d_pool, const uint8_t *flags, float *d_rep_acc, int B, int N, int E, hipStream_t s);
 void t_rowmask(const float *x, const uint8_t *flags, float *y, size_t M, int C, hipStream_t s);
+bool t_adam_step(int n, float *const *params, float *const *grads, float *const *m, float *const *v, const int64_t *numel, int step, float lr,
+                 float b1, float b2, float eps, float wd, float max_norm, float *host_total_norm, hipStream_t s);
+bool t_ema_update(int n, float *const *ema, const float *const *params, const int64_t *numel, float decay, hipStream_t s);
 
 void launch_rainbow_loss_backward(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w,
                                   float iou_w, const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d, hipStream_t s);

@@ -454,4 +454,72 @@ void t_rowmask(const float *x, const uint8_t *flags, float *y, size_t M, int C, 
     hipLaunchKernelGGL(t_rowmask_kernel, dim3(t_blocks(M * C)), dim3(256), 0, s, x, flags, y, C, M * C);
 }
 
+// ---- optimiser step (torch.optim.Adam, R/utils/learning_utils.py:137-140) with nn.utils.clip_grad_norm_ in front (trainer_node_adj.py:170) ----
+// partial[b] = sum of squares of this block's grid-stride share (double); fixed block count -> deterministic
+__global__ __launch_bounds__(256) void t_sumsq_kernel(const float *g, size_t n, double *partial) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += (double)g[i] * (double)g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+// norms[t] = sqrt(sum of tensor t's partials) as fp32 (torch: per-tensor fp32 norms, then the norm of the norms); out[0] = total norm,
+// out[1] = clip coefficient min(1, max_norm / (total + 1e-6))
+__global__ void t_clip_coef_kernel(const double *partial, int n_tensors, int per, float max_norm, float *out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double tot = 0.0;
+    for (int t = 0; t < n_tensors; t++) {
+        double s = 0.0;
+        for (int b = 0; b < per; b++) s += partial[(size_t)t * per + b];
+        const float nt = sqrtf((float)s);
+        tot += (double)nt * (double)nt;
+    }
+    const float total = sqrtf((float)tot);
+    out[0] = total;
+    out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (total + 1e-6f)) : 1.0f;
+}
+__global__ void t_adam_kernel(float *p, float *g, float *m, float *v, size_t n, const float *clip, float lr, float b1, float b2, float eps, float wd,
+                              float bc1, float bc2_sqrt) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gr = g[i] * clip[1];
+    g[i] = gr;   // clip_grad_norm_ scales the gradients in place
+    if (wd != 0.f) gr = fmaf(wd, p[i], gr);
+    const float mi = m[i] + (gr - m[i]) * (1.0f - b1);               // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = v[i] * b2 + (1.0f - b2) * gr * gr;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mi / denom);
+}
+__global__ void t_ema_kernel(float *ema, const float *p, size_t n, float decay) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ema[i] = ema[i] + (p[i] - ema[i]) * (1.0f - decay);   // ma.lerp_(current, 1 - decay)
+}
+bool t_adam_step(int n, float *const *params, float *const *grads, float *const *m, float *const *v, const int64_t *numel, int step, float lr,
+                 float b1, float b2, float eps, float wd, float max_norm, float *host_total_norm, hipStream_t s) {
+    constexpr int PER = 64;
+    double *partial = nullptr;
+    float *coef = nullptr;
+    if (hipMalloc((void **)&partial, sizeof(double) * (size_t)n * PER) != hipSuccess) return false;
+    if (hipMalloc((void **)&coef, sizeof(float) * 2) != hipSuccess) { (void)hipFree(partial); return false; }
+    for (int t = 0; t < n; t++) hipLaunchKernelGGL(t_sumsq_kernel, dim3(PER), dim3(256), 0, s, grads[t], (size_t)numel[t], partial + (size_t)t * PER);
+    hipLaunchKernelGGL(t_clip_coef_kernel, dim3(1), dim3(1), 0, s, partial, n, PER, max_norm, coef);
+    const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
+    for (int t = 0; t < n; t++)
+        hipLaunchKernelGGL(t_adam_kernel, dim3(t_blocks((size_t)numel[t])), dim3(256), 0, s, params[t], grads[t], m[t], v[t], (size_t)numel[t], coef, lr,
+                           b1, b2, eps, wd, bc1, bc2s);
+    bool ok = hipGetLastError() == hipSuccess;
+    if (host_total_norm) ok = ok && hipMemcpyAsync(host_total_norm, coef, sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess;
+    ok = ok && hipStreamSynchronize(s) == hipSuccess;
+    (void)hipFree(partial); (void)hipFree(coef);
+    return ok;
+}
+bool t_ema_update(int n, float *const *ema, const float *const *params, const int64_t *numel, float decay, hipStream_t s) {
+    for (int t = 0; t < n; t++)
+        hipLaunchKernelGGL(t_ema_kernel, dim3(t_blocks((size_t)numel[t])), dim3(256), 0, s, ema[t], params[t], (size_t)numel[t], decay);
+    return hipGetLastError() == hipSuccess;
+}
+
 }  // namespace dsg

@@ -7,8 +7,10 @@
 Same constructor kwargs, call signatures and return conventions as the reference classes; the arithmetic runs in libdsg.so
 (`dsg_train_inputs`, `dsg_rainbow_loss`, and the preconditioned network through `NodeAdjPrecondHip`).  Of the backward only the
 first stage exists (`NodeAdjRainbowLossHip.backward` -> `dsg_rainbow_loss_backward`: loss -> preconditioned outputs -> raw network
-outputs, checked against the reference's autograd); the network's backward, the optimiser, EMA and DDP are NOT built: `mode='train'`
-raises.
+outputs, checked against the reference's autograd).  Round 2 (late): the whole training iteration exists in correctness-first form --
+`train_step_grads` (network in training form, loss, backward to every parameter: `dsg_train_step_grads`), `AdamHip` (clip + Adam:
+`dsg_adam_step`), `EMAHip` (`dsg_ema_update`; parity unpinned), `train_one_iteration`; gradients all-reduce through
+`diffusesg_amd.dist.all_reduce_mean`.  The kernels are plain fp32 (csrc/train_kernels.hip), not the sampling path's MFMA kernels.
 """
 from __future__ import annotations
 
@@ -163,8 +165,15 @@ def eval_loss_step(model, train_obj_gen, loss_func, adjs_gt, nodes_gt, node_flag
                    iou_loss_weight=0.0, **replay):
     """One iteration of node_adj_move_forward_one_epoch in 'test' mode (trainer_node_adj.py:96-167): objective -> model pass
     under no_grad -> per-sample losses -> loss = adj.mean() + node.mean().  Returns (loss, reg_loss_adj, reg_loss_node, sigmas)."""
+    if mode == "train":
+        if replay.get("optimizer") is None:
+            raise ValueError("mode='train' needs optimizer=AdamHip(model) (and optionally ema_helper=[EMAHip(model, beta), ...])")
+        optimizer, ema_helper = replay.pop("optimizer"), replay.pop("ema_helper", None)
+        loss, ra, rn, sg, _ = train_one_iteration(model, train_obj_gen, loss_func, optimizer, ema_helper, adjs_gt, nodes_gt, node_flags,
+                                                  iou_loss_weight=iou_loss_weight, **replay)
+        return loss, ra, rn, sg
     if mode != "test":
-        raise NotImplementedError("mode='train' needs backward / optimiser / EMA, which are not built (SURVEY §8f-4)")
+        raise NotImplementedError(mode)
     if iou_loss_weight > 0.0 and iou_loss_type != "iou":
         raise NotImplementedError("only iou_loss_type='iou' (the YAML default) is built")
     net_input_a, net_input_x, net_cond, net_target_a, net_target_x, (c_skip, c_out, c_in, c_noise, sigmas, weights) = \
@@ -241,3 +250,111 @@ def train_step_grads(model, loss_func, net_input_a, net_input_x, node_flags, sig
                                      _p(da), _p(dx_), _p(la), _p(ln), len(keys), names, ptrs, st), "dsg_train_step_grads")
     oa, on = m._shape_out(da, dx_)
     return oa, on, la, ln, grads
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class AdamHip(object):
+    """`torch.optim.Adam(model.parameters(), lr, betas=(0.9, 0.999), eps=1e-8, weight_decay)` (utils/learning_utils.py:137-140) with
+    `nn.utils.clip_grad_norm_(model.parameters(), max_norm)` folded in front of the step (trainer_node_adj.py:170) -- `dsg_adam_step`.
+    Operates on the DiffuseSGHip's parameters (moved to the model's device) and on the gradient dict `train_step_grads` returns."""
+
+    def __init__(self, model, lr=2.0e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.net = model.model if hasattr(model, "model") else model
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
+        dev = self.net._dev
+        for p_ in self.net.parameters():
+            p_.data = p_.data.to(dev)
+        self.keys = [k for k, _ in self.net.named_parameters()]
+        self.params = [p_.data for _, p_ in self.net.named_parameters()]
+        self.exp_avg = [torch.zeros_like(p_) for p_ in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p_) for p_ in self.params]
+        self.step_count = 0
+        self.last_total_norm = None
+
+    @torch.no_grad()
+    def step(self, grads, max_grad_norm=10.0):
+        """-> total gradient norm before clipping (what clip_grad_norm_ returns)"""
+        L = _lib.load()
+        self.step_count += 1
+        g = [grads[k] for k in self.keys]
+        numel = (C.c_int64 * len(g))(*[int(t.numel()) for t in g])
+        out = C.c_float(0.0)
+        st = C.c_void_p(torch.cuda.current_stream(self.net._dev).cuda_stream)
+        rc = L.dsg_adam_step(len(g), _ptr_array(self.params), _ptr_array(g), _ptr_array(self.exp_avg), _ptr_array(self.exp_avg_sq), numel,
+                             self.step_count, self.lr, float(self.betas[0]), float(self.betas[1]), self.eps, self.weight_decay,
+                             float(max_grad_norm if max_grad_norm else 0.0), C.byref(out), st)
+        if rc != 0:
+            raise _lib.DsgError(f"dsg_adam_step: status {rc}")
+        self.net._synced_version = None   # the library re-reads (and re-packs) the weights before the next forward
+        self.last_total_norm = float(out.value)
+        return self.last_total_norm
+
+    def zero_grad(self, set_to_none=True):
+        pass   # gradients are returned fresh by every train_step_grads call
+
+
+class EMAHip(object):
+    """`ema_pytorch.EMA(model, beta=coef, update_every=1, update_after_step=0, inv_gamma=1, power=1)` as `get_ema_helper` builds it
+    (utils/learning_utils.py:145-165).  ema_pytorch is absent here (un-vendored, unpinned dependency): PARITY UNPINNED; restated from
+    its published algorithm -- the first `update()` copies the online weights, afterwards
+    decay = clamp(1 - (1 + epoch / inv_gamma)^-power, 0, beta) with epoch = step - update_after_step - 1 (0 for epoch <= 0) and
+    ema <- ema + (online - ema)(1 - decay)."""
+
+    def __init__(self, model, beta=0.9999, update_every=1, update_after_step=0, inv_gamma=1.0, power=1.0, min_value=0.0):
+        self.net = model.model if hasattr(model, "model") else model
+        self.beta, self.update_every, self.update_after_step = float(beta), int(update_every), int(update_after_step)
+        self.inv_gamma, self.power, self.min_value = float(inv_gamma), float(power), float(min_value)
+        self.step, self.initted = 0, False
+        self.keys = [k for k, _ in self.net.named_parameters()]
+        self.shadow = {k: p_.data.detach().clone().to(self.net._dev) for k, p_ in self.net.named_parameters()}
+
+    def get_current_decay(self):
+        epoch = max(self.step - self.update_after_step - 1, 0)
+        if epoch <= 0:
+            return 0.0
+        return min(max(1.0 - (1.0 + epoch / self.inv_gamma) ** (-self.power), self.min_value), self.beta)
+
+    @torch.no_grad()
+    def update(self):
+        step = self.step
+        self.step += 1
+        if step % self.update_every != 0:
+            return
+        online = dict(self.net.named_parameters())
+        if step <= self.update_after_step or not self.initted:
+            for k in self.keys:
+                self.shadow[k].copy_(online[k].data.to(self.shadow[k].device))
+            self.initted = True
+            if step <= self.update_after_step:
+                return
+        L = _lib.load()
+        ema = [self.shadow[k] for k in self.keys]
+        cur = [online[k].data for k in self.keys]
+        numel = (C.c_int64 * len(ema))(*[int(t.numel()) for t in ema])
+        rc = L.dsg_ema_update(len(ema), _ptr_array(ema), _ptr_array(cur), numel, float(self.get_current_decay()),
+                              C.c_void_p(torch.cuda.current_stream(self.net._dev).cuda_stream))
+        if rc != 0:
+            raise _lib.DsgError(f"dsg_ema_update: status {rc}")
+
+    def state_dict(self):
+        return {k: v.clone() for k, v in self.shadow.items()}
+
+
+def train_one_iteration(model, train_obj_gen, loss_func, optimizer, ema_helper, adjs_gt, nodes_gt, node_flags, iou_loss_weight=0.0,
+                        max_grad_norm=10.0, **replay):
+    """One iteration of node_adj_move_forward_one_epoch in 'train' mode (trainer_node_adj.py:96-175): objective -> model pass ->
+    per-sample losses -> loss.backward() -> clip_grad_norm_(10) -> optimizer.step() -> EMA updates.
+    -> (loss, reg_loss_adj, reg_loss_node, sigmas, total_grad_norm)"""
+    net_input_a, net_input_x, net_cond, net_target_a, net_target_x, (c_skip, c_out, c_in, c_noise, sigmas, weights) = \
+        train_obj_gen.get_input_output(adjs_gt, nodes_gt, node_flags, **replay)
+    optimizer.zero_grad(set_to_none=True)
+    oa, on, reg_loss_adj, reg_loss_node, grads = train_step_grads(model, loss_func, net_input_a, net_input_x, node_flags, sigmas,
+                                                                  net_target_a, net_target_x, weights, iou_loss_weight=iou_loss_weight)
+    loss = reg_loss_adj.mean() + reg_loss_node.mean()
+    total_norm = optimizer.step(grads, max_grad_norm=max_grad_norm)
+    if ema_helper is not None:
+        [ema.update() for ema in ema_helper]
+    return loss, reg_loss_adj, reg_loss_node, sigmas, total_norm

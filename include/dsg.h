@@ -271,6 +271,18 @@ int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const 
                          float *out_D_node, float *out_loss_adj, float *out_loss_node, int32_t n_params, const char *const *names,
                          float *const *grad_params, void *stream);
 
+/* The rest of a training iteration (R/runner/trainer/trainer_node_adj.py:170-175), on caller-owned device tensors, no handle:
+ * dsg_adam_step <-> nn.utils.clip_grad_norm_(parameters, max_norm) followed by torch.optim.Adam.step()  (utils/learning_utils.py:137-140:
+ *   betas (0.9, 0.999), eps 1e-8, L2 weight_decay; gradients are scaled in place by the clip coefficient like the reference;
+ *   `step` counts from 1; max_grad_norm <= 0 switches clipping off).  out_total_norm (host, may be NULL): the norm before clipping.
+ * dsg_ema_update <-> ema_pytorch's EMA.update_moving_average: ema <- ema + (param - ema)(1 - decay).  ema_pytorch is an un-vendored,
+ *   unpinned dependency of the reference (setup/requirements.txt:20) and absent here: parity unpinned; the decay schedule is restated
+ *   from its published algorithm in diffusesg_amd/train.py::EMAHip. */
+int dsg_adam_step(int32_t n_tensors, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,
+                  const int64_t *numel, int32_t step, float lr, float beta1, float beta2, float eps, float weight_decay, float max_grad_norm,
+                  float *out_total_norm, void *stream);
+int dsg_ema_update(int32_t n_tensors, float *const *ema, const float *const *params, const int64_t *numel, float decay, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

