@@ -55,3 +55,37 @@ def gather_results(packed: torch.Tensor) -> torch.Tensor:
     out = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(out, packed)
     return out
+
+
+def all_reduce_mean(grads, bucket_bytes: int = 256 << 20):
+    """Data-parallel gradient averaging of a training iteration (the reference wraps the model in DistributedDataParallel,
+    R/utils/dist_training.py, whose backward averages gradients over ranks): the gradient tensors (dict or list, as
+    `train_step_grads` returns them) are packed into a few large flat buckets -- xGMI rings are per-link bound, so few large
+    all-reduces beat one per tensor -- summed with one `all_reduce` each (RCCL with backend "nccl"; gloo in the CPU test) and
+    divided by the world size, in place.  Identity when not distributed."""
+    tensors = list(grads.values()) if isinstance(grads, dict) else list(grads)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not tensors:
+        return grads
+    world = dist.get_world_size()
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size
+        if not bucket:
+            return
+        flat = torch.cat([t.reshape(-1) for t in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        off = 0
+        for t in bucket:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+        bucket, size = [], 0
+
+    for t in tensors:
+        if size and size + t.numel() * t.element_size() > bucket_bytes:
+            flush()
+        bucket.append(t)
+        size += t.numel() * t.element_size()
+    flush()
+    return grads

@@ -354,6 +354,8 @@ def train_one_iteration(model, train_obj_gen, loss_func, optimizer, ema_helper, 
     oa, on, reg_loss_adj, reg_loss_node, grads = train_step_grads(model, loss_func, net_input_a, net_input_x, node_flags, sigmas,
                                                                   net_target_a, net_target_x, weights, iou_loss_weight=iou_loss_weight)
     loss = reg_loss_adj.mean() + reg_loss_node.mean()
+    from . import dist as _dist
+    _dist.all_reduce_mean(grads)   # data parallel: the mean over ranks, what DDP's backward leaves (identity on one rank)
     total_norm = optimizer.step(grads, max_grad_norm=max_grad_norm)
     if ema_helper is not None:
         [ema.update() for ema in ema_helper]

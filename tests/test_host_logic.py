@@ -104,6 +104,41 @@ def test_gather_world2_gloo():
     assert not np.array_equal(res[0][2], res[1][2])                              # seeds differ by rank
 
 
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        grads = {"a.weight": torch.randn(7, 5, generator=g), "a.bias": torch.randn(7, generator=g), "b.weight": torch.randn(300, 40, generator=g)}
+        mine = {k: v.clone() for k, v in grads.items()}
+        out = ddist.all_reduce_mean(grads, bucket_bytes=4096)   # small buckets: several collectives, one tensor larger than a bucket
+        assert out is grads
+        q.put((rank, {k: v.numpy() for k, v in grads.items()}, {k: v.numpy() for k, v in mine.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_mean_world2_gloo():
+    """data-parallel training: every rank ends with the mean of the ranks' gradients (what DDP's backward leaves), bucketed"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for k in res[0][1]:
+        mean = (res[0][2][k] + res[1][2][k]) / 2
+        assert np.allclose(res[0][1][k], mean, atol=1e-7) and np.array_equal(res[0][1][k], res[1][1][k])
+    g = {"w": torch.ones(3)}
+    assert ddist.all_reduce_mean(g) is g and torch.equal(g["w"], torch.ones(3))   # identity when not distributed
+
+
 def reference_style_checkpoint(cfg, path, numpy1_names=False):
     """A file shaped like the one `get_ckpt_data` writes (trainer_utils.py:168-185): 'model' keys carry the precond
     wrapper's 'model.' prefix, `config` is the nested `config.to_dict()` (incl. the torch.device of arg_parser.py:352),
