@@ -21,12 +21,15 @@ namespace dsg {
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void t_gemm_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
                                                      const float *__restrict__ bias, float *__restrict__ C, int ldc, int M, int N, int K,
-                                                     int accumulate) {
+                                                     int accumulate, int kslice) {
+    // kslice > 0: split-K -- block z handles k in [z kslice, (z+1) kslice) and writes its partial product to C + z M N (ldc = N)
     __shared__ float As[32][33], Bs[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // ty 0..7
     const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    const int kbeg = kslice > 0 ? blockIdx.z * kslice : 0;
+    if (kslice > 0) { C += (size_t)blockIdx.z * M * N; K = min(K, kbeg + kslice); }
+    for (int k0 = kbeg; k0 < K; k0 += 32) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int r = ty + 8 * i;   // tile row
@@ -61,25 +64,121 @@ __global__ __launch_bounds__(256) void t_gemm_kernel(const float *__restrict__ A
         }
     }
 }
+// C[i] = (accumulate ? C[i] : 0) + sum_z part[z][i]   (fixed order)
+__global__ void t_splitk_reduce_kernel(const float *part, float *C, int ldc, int M, int N, int S, int accumulate) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * N) return;
+    const int m = i / N, n = i % N;
+    float v = accumulate ? C[(size_t)m * ldc + n] : 0.f;
+    for (int z = 0; z < S; z++) v += part[(size_t)z * M * N + i];
+    C[(size_t)m * ldc + n] = v;
+}
+static float *g_sk_scratch = nullptr;
+static size_t g_sk_cap = 0;
+
+// [R][Cc] -> [Cc][R] (weights on their way into the MFMA GEMM, which wants both operands K-contiguous)
+__global__ __launch_bounds__(256) void t_transpose_kernel(const float *src, int ld, float *dst, int R, int Cc) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int i = ty; i < 32; i += 8) tile[i][tx] = (r0 + i < R && c0 + tx < Cc) ? src[(size_t)(r0 + i) * ld + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < Cc && r0 + tx < R) dst[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+static float *g_wt_scratch = nullptr;
+static size_t g_wt_cap = 0;
+
 void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K,
             bool accumulate, hipStream_t s) {
-    const dim3 grid((N + 31) / 32, (M + 31) / 32), block(256);
-    if (!ta && !tb) hipLaunchKernelGGL((t_gemm_kernel<false, false>), grid, block, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, (int)accumulate);
-    else if (!ta && tb) hipLaunchKernelGGL((t_gemm_kernel<false, true>), grid, block, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, (int)accumulate);
-    else if (ta && !tb) hipLaunchKernelGGL((t_gemm_kernel<true, false>), grid, block, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, (int)accumulate);
-    else hipLaunchKernelGGL((t_gemm_kernel<true, true>), grid, block, 0, s, A, lda, B, ldb, bias, C, ldc, M, N, K, (int)accumulate);
+    // The activation-side products y = x W^T and dx = dy W have the sampling path's GEMM form (A [M,K] row-major, second operand
+    // [N,K]): large ones go to gemm4_f32_kernel (dx after transposing the weight into a scratch tile).  The weight-gradient
+    // products (ta: K = tokens) and everything small or oddly shaped stay on the plain kernel below.
+    static const bool use_mfma = getenv("DSG_TRAIN_PLAIN_GEMM") == nullptr;
+    if (use_mfma && !ta && M >= 512 && K % 32 == 0 && N % 32 == 0 && lda == K && (size_t)N * K <= ((size_t)32 << 20)) {
+        const float *Wop = B;
+        bool ok = true;
+        if (tb) ok = ldb == K;
+        else {
+            const size_t need = (size_t)N * K;
+            if (need > g_wt_cap) {
+                if (g_wt_scratch) (void)hipFree(g_wt_scratch);   // (the stream has been drained by the callers' end-of-step sync before a larger model shows up)
+                g_wt_cap = 0; g_wt_scratch = nullptr;
+                if (hipMalloc((void **)&g_wt_scratch, sizeof(float) * need) == hipSuccess) g_wt_cap = need;
+            }
+            ok = g_wt_cap >= need;
+            if (ok) {
+                hipLaunchKernelGGL(t_transpose_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, s, B, ldb, g_wt_scratch, K, N);   // B [K][N] -> [N][K]
+                Wop = g_wt_scratch;
+            }
+        }
+        if (ok) {
+            GemmArgs g;
+            g.A = A; g.lda = K; g.K1 = K; g.K = K; g.M = M; g.N = N; g.W = Wop; g.bias = bias; g.C = C; g.ldc = ldc;
+            if (accumulate) { g.res = C; g.ldres = ldc; }
+            launch_gemm(g, s);
+            return;
+        }
+    }
+    dim3 grid((N + 31) / 32, (M + 31) / 32), block(256);
+    // weight gradients (K = tokens, M x N = the weight): few output tiles, long K -> split K over up to 64 slices of >= 1024 and add
+    // the partial products in slice order (deterministic)
+    int S = 1, kslice = 0;
+    float *Cout = C;
+    int ldo = ldc;
+    if (K >= 4096 && !bias && (size_t)grid.x * grid.y < 1024) {
+        S = min(64, K / 1024);
+        kslice = ((K + S - 1) / S + 31) / 32 * 32;
+        S = (K + kslice - 1) / kslice;
+        const size_t need = (size_t)S * M * N;
+        if (need > g_sk_cap) {
+            if (g_sk_scratch) (void)hipFree(g_sk_scratch);
+            g_sk_cap = 0; g_sk_scratch = nullptr;
+            if (hipMalloc((void **)&g_sk_scratch, sizeof(float) * need) == hipSuccess) g_sk_cap = need;
+        }
+        if (g_sk_cap >= need) { Cout = g_sk_scratch; ldo = N; grid.z = S; } else { S = 1; kslice = 0; }
+    }
+    const int acc1 = S > 1 ? 0 : (int)accumulate;
+    if (!ta && !tb) hipLaunchKernelGGL((t_gemm_kernel<false, false>), grid, block, 0, s, A, lda, B, ldb, bias, Cout, ldo, M, N, K, acc1, kslice);
+    else if (!ta && tb) hipLaunchKernelGGL((t_gemm_kernel<false, true>), grid, block, 0, s, A, lda, B, ldb, bias, Cout, ldo, M, N, K, acc1, kslice);
+    else if (ta && !tb) hipLaunchKernelGGL((t_gemm_kernel<true, false>), grid, block, 0, s, A, lda, B, ldb, bias, Cout, ldo, M, N, K, acc1, kslice);
+    else hipLaunchKernelGGL((t_gemm_kernel<true, true>), grid, block, 0, s, A, lda, B, ldb, bias, Cout, ldo, M, N, K, acc1, kslice);
+    if (S > 1)
+        hipLaunchKernelGGL(t_splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, g_sk_scratch, C, ldc, M, N, S,
+                           (int)accumulate);
 }
 
-// out[n] = sum_m X[m*ld + n] (double accumulation, fixed order: one thread per column)
-__global__ void t_colsum_kernel(const float *X, int ld, float *out, int M, int N) {
+// out[n] = sum_m X[m*ld + n]: row chunks summed by separate blocks (double, fixed order inside a chunk), then the chunks in order
+__global__ __launch_bounds__(256) void t_colsum_part_kernel(const float *X, int ld, double *part, int M, int N, int rows_per) {
+    __shared__ double red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    double sacc = 0.0;
+    if (c < N) for (int m = r0 + q; m < r1; m += 4) sacc += (double)X[(size_t)m * ld + c];
+    red[q][threadIdx.x & 63] = sacc;
+    __syncthreads();
+    if (q == 0 && c < N) part[(size_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void t_colsum_final_kernel(const double *part, float *out, int N, int R) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
-    double s = 0.0;
-    for (int m = 0; m < M; m++) s += (double)X[(size_t)m * ld + n];
-    out[n] = (float)s;
+    double sacc = 0.0;
+    for (int r = 0; r < R; r++) sacc += part[(size_t)r * N + n];
+    out[n] = (float)sacc;
 }
+static double *g_cs_scratch = nullptr;
+static size_t g_cs_cap = 0;
 void t_colsum(const float *X, int ld, float *out, int M, int N, hipStream_t s) {
-    hipLaunchKernelGGL(t_colsum_kernel, dim3((N + 63) / 64), dim3(64), 0, s, X, ld, out, M, N);
+    const int rows_per = max(64, (M + 255) / 256), R = (M + rows_per - 1) / rows_per;
+    const size_t need = (size_t)R * N;
+    if (need > g_cs_cap) {
+        if (g_cs_scratch) (void)hipFree(g_cs_scratch);
+        g_cs_cap = 0; g_cs_scratch = nullptr;
+        if (hipMalloc((void **)&g_cs_scratch, sizeof(double) * need) == hipSuccess) g_cs_cap = need;
+    }
+    if (g_cs_cap < need) { fprintf(stderr, "dsg: t_colsum: out of memory\n"); abort(); }
+    hipLaunchKernelGGL(t_colsum_part_kernel, dim3((N + 63) / 64, R), dim3(256), 0, s, X, ld, g_cs_scratch, M, N, rows_per);
+    hipLaunchKernelGGL(t_colsum_final_kernel, dim3((N + 63) / 64), dim3(64), 0, s, g_cs_scratch, out, N, R);
 }
 
 __device__ __forceinline__ float t_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }

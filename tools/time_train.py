@@ -1,7 +1,8 @@
 """Wall time of one training iteration (correctness-first kernels) at the VG shape -- for the record in DESIGN.md."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from diffusesg_amd import synth as Y, weights as W
 from diffusesg_amd.model import build_network
 from diffusesg_amd.train import NodeAdjEDMObjectiveGeneratorHip, NodeAdjRainbowLossHip, AdamHip, EMAHip, train_one_iteration
