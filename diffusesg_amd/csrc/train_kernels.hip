@@ -5,9 +5,9 @@
 //   backward  what torch.autograd derives for those lines; checked against the reference's own autograd
 //             (tests/golden/block_backward.npz, tools/gen_golden.py::gen_block_backward)
 //
-// CORRECTNESS FIRST: these are straightforward fp32 kernels (an LDS-tiled FMA GEMM, one thread per element / row / window row),
-// NOT the MFMA kernels of the sampling path -- they exist so that every gradient formula is pinned to the reference before the
-// fast versions are written.  Nothing on the sampling path calls into this file.
+// CORRECTNESS FIRST: these are straightforward fp32 kernels (an LDS-tiled FMA GEMM, one thread per element / row / window row;
+// only the activation-side GEMMs are forwarded to the sampling path's MFMA kernel) -- they exist so that every gradient formula is
+// pinned to the reference before the fast versions are written.  Nothing on the sampling path calls into this file.
 #include "kernels_common.hip.h"
 
 #include <stdio.h>
