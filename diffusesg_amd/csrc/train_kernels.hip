@@ -192,53 +192,72 @@ __global__ void t_modulate_fwd_kernel(const float *x, const float *aff, float *y
     const float u = aff[b * 2 * C + C + c] + x[i] * (aff[b * 2 * C + c] + 1.0f);
     y[i] = u * t_sigmoid(u);
 }
-// dx = du (1 + scale), du = dy silu'(u); d_aff[b] = (sum_t du x | sum_t du): one thread per (b, c), tokens in order
-__global__ void t_modulate_bwd_kernel(const float *x, const float *aff, const float *dy, float *dx, float *d_aff, int B, int T, int C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i % C;
-    const float sc = aff[(size_t)b * 2 * C + c] + 1.0f, sh = aff[(size_t)b * 2 * C + C + c];
+// dx = du (1 + scale), du = dy silu'(u); d_aff[b] = (sum_t du x | sum_t du).  Stage 1: block (64 channels x 4 row lanes) over a chunk of
+// sample b's tokens writes dx and double partials part[b][chunk][2][C]; stage 2 adds the chunks in order.
+__global__ __launch_bounds__(256) void t_modulate_bwd_kernel(const float *x, const float *aff, const float *dy, float *dx, double *part, int T, int C,
+                                                              int rows_per, int chunks) {
+    __shared__ double red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6, b = blockIdx.z, ch = blockIdx.y;
+    const int t0 = ch * rows_per, t1 = min(T, t0 + rows_per);
     double ds = 0.0, dh = 0.0;
-    for (int t = 0; t < T; t++) {
-        const size_t k = ((size_t)b * T + t) * C + c;
-        const float xv = x[k], u = sh + xv * sc, sg = t_sigmoid(u);
-        const float du = dy[k] * (sg * (1.0f + u * (1.0f - sg)));
-        dx[k] = du * sc;
-        ds += (double)(du * xv);
-        dh += (double)du;
+    if (c < C) {
+        const float sc = aff[(size_t)b * 2 * C + c] + 1.0f, sh = aff[(size_t)b * 2 * C + C + c];
+        for (int t = t0 + q; t < t1; t += 4) {
+            const size_t k = ((size_t)b * T + t) * C + c;
+            const float xv = x[k], u = sh + xv * sc, sg = t_sigmoid(u);
+            const float du = dy[k] * (sg * (1.0f + u * (1.0f - sg)));
+            dx[k] = du * sc;
+            ds += (double)(du * xv);
+            dh += (double)du;
+        }
     }
-    d_aff[(size_t)b * 2 * C + c] = (float)ds;
-    d_aff[(size_t)b * 2 * C + C + c] = (float)dh;
+    red[0][q][threadIdx.x & 63] = ds; red[1][q][threadIdx.x & 63] = dh;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        const int l = threadIdx.x;
+        double *p = part + (((size_t)b * chunks + ch) * 2) * C;
+        p[c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        p[C + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    }
+}
+__global__ void t_modulate_bwd_final_kernel(const double *part, float *d_aff, int B, int C, int chunks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 2 * C) return;
+    const int b = i / (2 * C), j = i % (2 * C);
+    double sacc = 0.0;
+    for (int ch = 0; ch < chunks; ch++) sacc += part[(((size_t)b * chunks + ch) * 2) * C + j];
+    d_aff[i] = (float)sacc;
 }
 
-// LayerNorm with affine: one thread per row (C <= 768 here; naive).  stats[m] = (mean, rstd)
-__global__ void t_ln_fwd_kernel(const float *x, const float *gam, const float *bet, float *y, float *stats, int M, int C) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+// LayerNorm with affine: one wave per row (lanes stride over the channels: coalesced), two-pass statistics.  stats[m] = (mean, rstd)
+__global__ __launch_bounds__(256) void t_ln_fwd_kernel(const float *x, const float *gam, const float *bet, float *y, float *stats, int M, int C) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= M) return;
     const float *r = x + (size_t)m * C;
-    double s = 0.0;
-    for (int c = 0; c < C; c++) s += (double)r[c];
-    const float mean = (float)(s / C);
-    double v = 0.0;
-    for (int c = 0; c < C; c++) { const float d = r[c] - mean; v += (double)(d * d); }
-    const float rstd = 1.0f / sqrtf((float)(v / C) + LN_EPS);
-    for (int c = 0; c < C; c++) y[(size_t)m * C + c] = (r[c] - mean) * rstd * gam[c] + bet[c];
-    stats[2 * (size_t)m] = mean; stats[2 * (size_t)m + 1] = rstd;
+    float sacc = 0.f;
+    for (int c = lane; c < C; c += 64) sacc += r[c];
+    const float mean = wave_sum(sacc) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = r[c] - mean; v = fmaf(d, d, v); }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)C + LN_EPS);
+    for (int c = lane; c < C; c += 64) y[(size_t)m * C + c] = (r[c] - mean) * rstd * gam[c] + bet[c];
+    if (lane == 0) { stats[2 * (size_t)m] = mean; stats[2 * (size_t)m + 1] = rstd; }
 }
 // dx (ADDED to dx_acc) = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;  xhat_dy[m][c] = dy xhat (for d_gamma = colsum)
-__global__ void t_ln_bwd_kernel(const float *x, const float *gam, const float *stats, const float *dy, float *dx_acc, float *xhat_dy, int M, int C) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void t_ln_bwd_kernel(const float *x, const float *gam, const float *stats, const float *dy, float *dx_acc,
+                                                        float *xhat_dy, int M, int C) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= M) return;
     const float mean = stats[2 * (size_t)m], rstd = stats[2 * (size_t)m + 1];
     const float *r = x + (size_t)m * C, *d = dy + (size_t)m * C;
-    double sg = 0.0, sgx = 0.0;
-    for (int c = 0; c < C; c++) {
+    float sg = 0.f, sgx = 0.f;
+    for (int c = lane; c < C; c += 64) {
         const float xh = (r[c] - mean) * rstd, g = d[c] * gam[c];
-        sg += (double)g; sgx += (double)(g * xh);
+        sg += g; sgx = fmaf(g, xh, sgx);
         xhat_dy[(size_t)m * C + c] = d[c] * xh;
     }
-    const float mg = (float)(sg / C), mgx = (float)(sgx / C);
-    for (int c = 0; c < C; c++) {
+    const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+    for (int c = lane; c < C; c += 64) {
         const float xh = (r[c] - mean) * rstd, g = d[c] * gam[c];
         dx_acc[(size_t)m * C + c] += rstd * (g - mg - xh * mgx);
     }
@@ -459,12 +478,12 @@ bool train_block(const TrainBlockArgs &a, hipStream_t s) {
     // ---- forward ----
     t_gemm(false, true, a.emb, NOISE_EMB, a.W.aff_w, NOISE_EMB, a.W.aff_b, a.aff, 2 * C, B, 2 * C, NOISE_EMB, false, s);     // params = affine(emb)
     hipLaunchKernelGGL(t_modulate_fwd_kernel, dim3(t_blocks(nMC)), dim3(256), 0, s, a.x_in, a.aff, a.x_mod, T, C, nMC);
-    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, a.x_mod, a.W.n1_w, a.W.n1_b, a.xn1, a.stats1, M, C);
+    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x_mod, a.W.n1_w, a.W.n1_b, a.xn1, a.stats1, M, C);
     t_gemm(false, true, a.xn1, C, a.W.qkv_w, C, a.W.qkv_b, a.qkv, 3 * C, M, 3 * C, C, false, s);
     if (!t_attn_launch(false, a.qkv, a.W.rpb, a.att, nullptr, nullptr, nullptr, B, g, s)) return false;
     if (hipMemcpyAsync(a.x1, a.x_mod, sizeof(float) * nMC, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;
     t_gemm(false, true, a.att, C, a.W.proj_w, C, a.W.proj_b, a.x1, C, M, C, C, true, s);                                      // x1 = shortcut + proj(att)
-    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, a.x1, a.W.n2_w, a.W.n2_b, a.xn2, a.stats2, M, C);
+    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x1, a.W.n2_w, a.W.n2_b, a.xn2, a.stats2, M, C);
     t_gemm(false, true, a.xn2, C, a.W.fc1_w, C, a.W.fc1_b, a.pre, H, M, H, C, false, s);
     hipLaunchKernelGGL(t_gelu_fwd_kernel, dim3(t_blocks(nMH)), dim3(256), 0, s, a.pre, a.hid, nMH);
     if (hipMemcpyAsync(a.x_out, a.x1, sizeof(float) * nMC, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;
@@ -489,7 +508,7 @@ bool train_block_backward(const TrainBlockArgs &a, hipStream_t s) {
     t_colsum(a.t_mh, H, a.G.fc1_b, M, H, s);
     t_gemm(false, false, a.t_mh, H, a.W.fc1_w, C, nullptr, a.t_mc, C, M, C, H, false, s);       // d_xn2 = d_pre W1
     if (hipMemcpyAsync(a.d_x1, dY, sizeof(float) * nMC, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;   // residual branch
-    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, a.x1, a.W.n2_w, a.stats2, a.t_mc, a.d_x1, a.t_mc2, M, C);
+    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x1, a.W.n2_w, a.stats2, a.t_mc, a.d_x1, a.t_mc2, M, C);
     t_colsum(a.t_mc2, C, a.G.n2_w, M, C, s);                                                     // d_gamma2 = colsum(d_xn2 * xhat)
     t_colsum(a.t_mc, C, a.G.n2_b, M, C, s);                                                      // d_beta2 = colsum(d_xn2)
     // attention half: x1 = x_mod + att Wp^T + bp
@@ -502,11 +521,11 @@ bool train_block_backward(const TrainBlockArgs &a, hipStream_t s) {
     t_colsum(a.t_m3c, 3 * C, a.G.qkv_b, M, 3 * C, s);
     t_gemm(false, false, a.t_m3c, 3 * C, a.W.qkv_w, C, nullptr, a.t_mc, C, M, C, 3 * C, false, s);   // d_xn1
     // d_xmod = d_x1 (shortcut) + LN1 backward
-    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, a.x_mod, a.W.n1_w, a.stats1, a.t_mc, a.d_x1, a.t_mc2, M, C);
+    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x_mod, a.W.n1_w, a.stats1, a.t_mc, a.d_x1, a.t_mc2, M, C);
     t_colsum(a.t_mc2, C, a.G.n1_w, M, C, s);
     t_colsum(a.t_mc, C, a.G.n1_b, M, C, s);
     // modulate: x_mod = silu(shift + x (1 + scale)); params = emb Wa^T + ba
-    hipLaunchKernelGGL(t_modulate_bwd_kernel, dim3((B * C + 63) / 64), dim3(64), 0, s, a.x_in, a.aff, a.d_x1, a.grad_in, a.d_aff, B, T, C);
+    t_modulate(a.x_in, a.aff, a.d_x1, a.grad_in, a.d_aff, B, T, C, true, s);
     t_gemm(true, false, a.d_aff, 2 * C, a.emb, NOISE_EMB, nullptr, a.G.aff_w, NOISE_EMB, 2 * C, NOISE_EMB, B, false, s);   // dWa = d_aff^T emb
     t_colsum(a.d_aff, 2 * C, a.G.aff_b, B, 2 * C, s);
     t_gemm(false, false, a.d_aff, 2 * C, a.W.aff_w, NOISE_EMB, nullptr, a.grad_emb, NOISE_EMB, B, NOISE_EMB, 2 * C, false, s);   // d_emb
@@ -524,14 +543,24 @@ void t_gelu(const float *x, const float *dy, float *out, size_t n, bool bwd, hip
 }
 void t_add(float *a, const float *b, size_t n, hipStream_t s) { hipLaunchKernelGGL(t_add_kernel, dim3(t_blocks(n)), dim3(256), 0, s, a, b, n); }
 void t_ln_fwd(const float *x, const float *gam, const float *bet, float *y, float *stats, int M, int C, hipStream_t s) {
-    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, x, gam, bet, y, stats, M, C);
+    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gam, bet, y, stats, M, C);
 }
 void t_ln_bwd(const float *x, const float *gam, const float *stats, const float *dy, float *dx_acc, float *xhat_dy, int M, int C, hipStream_t s) {
-    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 63) / 64), dim3(64), 0, s, x, gam, stats, dy, dx_acc, xhat_dy, M, C);
+    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gam, stats, dy, dx_acc, xhat_dy, M, C);
 }
 void t_modulate(const float *x, const float *aff, const float *dy, float *out, float *d_aff, int B, int T, int C, bool bwd, hipStream_t s) {
-    if (bwd) hipLaunchKernelGGL(t_modulate_bwd_kernel, dim3((B * C + 63) / 64), dim3(64), 0, s, x, aff, dy, out, d_aff, B, T, C);
-    else hipLaunchKernelGGL(t_modulate_fwd_kernel, dim3(t_blocks((size_t)B * T * C)), dim3(256), 0, s, x, aff, out, T, C, (size_t)B * T * C);
+    if (bwd) {
+        const int rows_per = max(64, (T + 63) / 64), chunks = (T + rows_per - 1) / rows_per;
+        const size_t need = (size_t)B * chunks * 2 * C;
+        if (need > g_cs_cap) {
+            if (g_cs_scratch) (void)hipFree(g_cs_scratch);
+            g_cs_cap = 0; g_cs_scratch = nullptr;
+            if (hipMalloc((void **)&g_cs_scratch, sizeof(double) * need) == hipSuccess) g_cs_cap = need;
+        }
+        if (g_cs_cap < need) { fprintf(stderr, "dsg: t_modulate: out of memory\n"); abort(); }
+        hipLaunchKernelGGL(t_modulate_bwd_kernel, dim3((C + 63) / 64, chunks, B), dim3(256), 0, s, x, aff, dy, out, g_cs_scratch, T, C, rows_per, chunks);
+        hipLaunchKernelGGL(t_modulate_bwd_final_kernel, dim3((B * 2 * C + 255) / 256), dim3(256), 0, s, g_cs_scratch, d_aff, B, C, chunks);
+    } else hipLaunchKernelGGL(t_modulate_fwd_kernel, dim3(t_blocks((size_t)B * T * C)), dim3(256), 0, s, x, aff, out, T, C, (size_t)B * T * C);
 }
 void t_regroup(const float *src, float *dst, int B, int res, int C, bool gather, hipStream_t s) {
     const size_t n = (size_t)B * res * res * C;

@@ -7,7 +7,7 @@ from diffusesg_amd import synth as Y, weights as W
 from diffusesg_amd.model import build_network
 from diffusesg_amd.train import NodeAdjEDMObjectiveGeneratorHip, NodeAdjRainbowLossHip, AdamHip, EMAHip, train_one_iteration
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-for B in (8, 64):
+for B in (8, 32, 64):
     cfg, flags, ca, cn, rnd, ea, en, coin = Y.train_case("vg", B=B)
     model = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")
     gen = NodeAdjEDMObjectiveGeneratorHip(precond="edm", sigma_dist="edm", other_params=None, dev="cuda", symmetric_noise=False)
