@@ -39,6 +39,30 @@ def load_checkpoint(path: str) -> Dict:
         return torch.load(path, map_location="cpu", weights_only=True)
 
 
+def get_ckpt_data(model: torch.nn.Module, ema_helper, epoch: int, train_loss, test_loss, config: Dict) -> Dict:
+    """The dictionary the reference's trainer saves (`get_ckpt_data`, trainer_utils.py:168-185): 'model' = model.state_dict() of the
+    preconditioned wrapper ('model.' prefixed keys), the nested config dict, the epoch, NumPy-scalar losses, and one
+    'model_ema_beta_{beta:.4f}' state dict per EMA helper (`diffusesg_amd.train.EMAHip`: its shadow weights, buffers copied from the
+    online model) -- what `load_checkpoint` / `load_model` / the reference's own eval.py read back."""
+    import numpy as np
+    online = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    to_save = {"model": online, "config": dict(config), "epoch": int(epoch), "train_loss": np.float64(train_loss),
+               "test_loss": np.float64(test_loss)}
+    prefix = "model." if any(k.startswith("model.") for k in online) else ""
+    for ema in (ema_helper or []):
+        sd = {k: v.clone() for k, v in online.items()}                      # buffers (relative_position_index, attn_mask) as in the online model
+        for k, v in ema.shadow.items():
+            sd[prefix + k] = v.detach().cpu().clone()
+        to_save["model_ema_beta_{:.4f}".format(ema.beta)] = sd
+    return to_save
+
+
+def save_checkpoint(path: str, model: torch.nn.Module, ema_helper, epoch: int, train_loss, test_loss, config: Dict) -> str:
+    """`torch.save(get_ckpt_data(...), path)` (trainer_utils.py:160-165, file name `{dataset}_{epoch:05d}.pth` is the caller's)."""
+    torch.save(get_ckpt_data(model, ema_helper, epoch, train_loss, test_loss, config), path)
+    return path
+
+
 def ema_weight_keywords(ckp_data: Dict, use_ema=None) -> List[str]:
     """Which state dicts of a checkpoint to evaluate (eval.py:15-40): None -> ['model']; 'all' -> every 'model*' entry;
     a list of betas -> 'model_ema_beta_{beta:.4f}' (1.0 selects the online weights)."""

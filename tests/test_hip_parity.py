@@ -1089,6 +1089,40 @@ def test_training_iteration_adam_step_vs_reference():
         np.random.rand = real
 
 
+def test_train_save_load_sample_round_trip(tmp_path):
+    """train two iterations -> write the checkpoint the reference's trainer writes (get_ckpt_data: online + EMA state dicts, NumPy
+    losses, config) -> read it back with the safe loader into a FRESH network -> its forward equals the trained network's, for the
+    online weights and for an EMA copy"""
+    from diffusesg_amd import io as dio
+    from diffusesg_amd.model import build_network
+    from diffusesg_amd.train import NodeAdjEDMObjectiveGeneratorHip, NodeAdjRainbowLossHip, AdamHip, EMAHip, train_one_iteration
+    cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case("tiny")
+    model = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")
+    gen = NodeAdjEDMObjectiveGeneratorHip(precond="edm", sigma_dist="edm", other_params=None, dev="cuda", symmetric_noise=False)
+    loss_func = NodeAdjRainbowLossHip(edge_loss_weight=1.0, node_loss_weight=1.0, flag_reweight=False, objective="edm")
+    opt, emas = AdamHip(model, lr=1e-3), [EMAHip(model, beta=0.9)]
+    np.random.seed(5)
+    losses = [float(train_one_iteration(model, gen, loss_func, opt, emas, T(clean_adj), T(clean_node), T(flags), iou_loss_weight=1.0)[0])
+              for _ in range(3)]
+    assert all(np.isfinite(losses))
+    path = dio.save_checkpoint(str(tmp_path / "tiny_00003.pth"), model, emas, 3, np.mean(losses), losses[-1], {"model": {"name": "diffuse_sg"}})
+    ckp = dio.load_checkpoint(path)
+    assert set(ckp) == {"model", "config", "epoch", "train_loss", "test_loss", "model_ema_beta_0.9000"} and ckp["epoch"] == 3
+    _, _, adj, node, sc_adj, sc_node = Y.fwd_case("tiny")
+    args = (T(adj), T(node), T(Y.fwd_case("tiny")[1]), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
+    want = [t.clone() for t in model.model(*args)]
+    fresh = build_network(cfg, W.synth_state_dict(cfg, 1), device="cuda")
+    dio.load_model(ckp, fresh, "model")
+    got = fresh.model(*args)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    dio.load_model(ckp, fresh, "model_ema_beta_0.9000")
+    ema_out = fresh.model(*args)
+    assert not torch.equal(ema_out[0], want[0]) and torch.isfinite(ema_out[0]).all()   # the EMA copy lags the online weights
+    # training moved the weights away from the initial ones
+    init = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda").model(*args)
+    assert float((init[0] - want[0]).abs().max()) > 1e-4
+
+
 def test_train_backward_head_vs_reference_autograd():
     """tests/golden/train_backward.npz (the reference's own autograd over one training step): dL/d(preconditioned outputs) incl.
     the IoU term's clamp / max / min branches, and dL/d(raw network outputs) = c_out(sigma) * that -- the first stage of the
