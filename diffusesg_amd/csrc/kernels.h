@@ -51,6 +51,8 @@ struct GemmArgs {
     const float *attn_bias = nullptr;            // [nWt][heads][64][64] key-major, log2(e)-scaled (build_bias_table)
     WinGeom wg{0, 0, 0, 0, 0};
     int attn_batch = 0;
+    int batch = 1;                               // > 1: that many independent products in one launch (fp32 kernel, AMODE 2: split-K slices)
+    size_t batch_strideA = 0, batch_strideW = 0, batch_strideC = 0;   // floats between consecutive products' operands / outputs
     int a_bf16 = 0, c_bf16 = 0;                  // bf16 mode only: A / C are bf16 tensors (lda / ldc in elements); see kernels_lp.hip
     const float *gelu_tab = nullptr;             // filled in by launch_gemm (table-driven GELU of the split kernel)
     unsigned long long *prof = nullptr;          // measurement mode: {min block start, max block end} in 100 MHz ticks

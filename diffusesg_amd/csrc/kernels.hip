@@ -104,7 +104,16 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     __shared__ __attribute__((aligned(16))) float lds[2 * (GBM + GBN) * GLD];
     constexpr int BUF = (GBM + GBN) * GLD;
 
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+    // AMODE 2 (training, weight gradients): `batch` independent products of the same shape in one launch -- the K slices of a
+    // split-K product -- operands / outputs batch_stride{A,W,C} floats apart; everything else as AMODE 0
+    const float *gA = g.A, *gW = g.W;
+    float *gC = g.C;
+    if (AMODE == 2) {
+        const int per = ((tiles_m + 7) / 8) * 8 * tiles_n, z = bid / per;
+        bid -= z * per;
+        gA += (size_t)z * g.batch_strideA; gW += (size_t)z * g.batch_strideW; gC += (size_t)z * g.batch_strideC;
+    }
     const int xcd = bid & 7, seq = bid >> 3;
     const int tm = (seq / tiles_n) * 8 + xcd, tn = seq % tiles_n;
     if (tm >= tiles_m) return;
@@ -133,9 +142,9 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     const int a4_C = g.K >> 2;   // AMODE 1: channels of one source row
     const rsrc_t rsA1 = (EPI == 4) ? make_rsrc(g.A, (unsigned)g.M * g.lda * 4u)
                         : (AMODE == 1) ? make_rsrc(g.A, (unsigned)g.M * (unsigned)g.K * 4u)   // 4*M fine rows of K/4 floats
-                                       : make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
+                                       : make_rsrc(gA + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
     const rsrc_t rsA2 = make_rsrc(g.A2 ? g.A2 + (size_t)m0 * g.lda2 : g.A, g.A2 ? (unsigned)rows_m * g.lda2 * 4u : 0u);
-    const rsrc_t rsW = (EPI == 4) ? make_rsrc(g.W, (unsigned)(3 * g.wg.C) * g.K * 4u) : make_rsrc(g.W + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 4u);
+    const rsrc_t rsW = (EPI == 4) ? make_rsrc(g.W, (unsigned)(3 * g.wg.C) * g.K * 4u) : make_rsrc(gW + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 4u);
     unsigned voffA1[4], voffA2[4], voffW[3];
     unsigned voffA4[4][4];   // AMODE 1: [part][staging row]
     float a_rstd[4], a_nmr[4];
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
     }
     // epilogue: buffer stores; lane-dependent part of the address in voffset, (register, tile) part in a scalar offset.
     // rows >= M fall outside the descriptor and are dropped; columns >= N get an out-of-range voffset.
-    const rsrc_t rsC = make_rsrc(g.C + (size_t)m0 * g.ldc, (unsigned)rows_m * g.ldc * 4u);
+    const rsrc_t rsC = make_rsrc(gC + (size_t)m0 * g.ldc, (unsigned)rows_m * g.ldc * 4u);
     const rsrc_t rsC2 = make_rsrc(g.C2 ? g.C2 + (size_t)m0 * g.ldc2 : g.C, g.C2 ? (unsigned)rows_m * g.ldc2 * 4u : 0u);
     const rsrc_t rsR = make_rsrc(RES ? g.res + (size_t)m0 * g.ldres : g.C, RES ? (unsigned)rows_m * g.ldres * 4u : 0u);
     const unsigned rowl = (unsigned)(wave * 32 + 4 * lhalf);
@@ -566,6 +575,12 @@ void launch_gemm(const GemmArgs &g, hipStream_t s) {
     const int tiles_m = (g.M + GBM - 1) / GBM, tiles_n = (g.N + GBN - 1) / GBN;
     const dim3 grid(((tiles_m + 7) / 8) * 8 * tiles_n), block(256);
     const bool ln = g.ln_stats != nullptr || g.ln_part != nullptr, res = g.res != nullptr;
+    if (g.batch > 1) {   // split-K slices of a training weight-gradient product: plain epilogue only
+        if (ln || res || g.act != ACT_NONE || g.stats_out || g.a4_res > 0 || g.A2 || g.C2 || g.bias) { fprintf(stderr, "dsg: launch_gemm: unsupported batched GEMM\n"); abort(); }
+        const dim3 gridb(grid.x * (unsigned)g.batch);
+        hipLaunchKernelGGL((gemm4_f32_kernel<false, ACT_NONE, false, 0, 8, 2>), gridb, block, 0, s, g, tiles_m, tiles_n);
+        return;
+    }
 #define GEMM_CASE(L, A, R) hipLaunchKernelGGL((gemm4_f32_kernel<L, A, R, 0>), grid, block, 0, s, g, tiles_m, tiles_n)
 #define GEMM_EPI(R, E) hipLaunchKernelGGL((gemm4_f32_kernel<false, ACT_NONE, R, E>), grid, block, 0, s, g, tiles_m, tiles_n)
     if (g.a4_res > 0) {   // PatchMerging gather + LayerNorm(4C) from partials; epilogue: plain, or premod + stats (dual store allowed)

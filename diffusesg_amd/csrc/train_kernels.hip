@@ -11,6 +11,7 @@
 #include "kernels_common.hip.h"
 
 #include <stdio.h>
+#include <algorithm>
 
 namespace dsg {
 
@@ -86,6 +87,19 @@ __global__ __launch_bounds__(256) void t_transpose_kernel(const float *src, int 
     for (int i = ty; i < 32; i += 8)
         if (c0 + i < Cc && r0 + tx < R) dst[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
 }
+// src [R][ld] (R = K tokens, Cc channels used) -> dst [S][Cc][kslice]: slice z holds rows z*kslice .. of src, transposed, zero-padded
+__global__ __launch_bounds__(256) void t_transpose_sliced_kernel(const float *src, int ld, float *dst, int R, int Cc, int kslice) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int z = blockIdx.z, c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;   // k0: offset inside the slice
+    for (int i = ty; i < 32; i += 8) {
+        const int r = z * kslice + k0 + i;
+        tile[i][tx] = (k0 + i < kslice && r < R && c0 + tx < Cc) ? src[(size_t)r * ld + c0 + tx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < Cc && k0 + tx < kslice) dst[((size_t)z * Cc + c0 + i) * kslice + k0 + tx] = tile[tx][i];
+}
 static float *g_wt_scratch = nullptr;
 static size_t g_wt_cap = 0;
 
@@ -117,6 +131,33 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
             g.A = A; g.lda = K; g.K1 = K; g.K = K; g.M = M; g.N = N; g.W = Wop; g.bias = bias; g.C = C; g.ldc = ldc;
             if (accumulate) { g.res = C; g.ldres = ldc; }
             launch_gemm(g, s);
+            return;
+        }
+    }
+    // Weight gradients dW [M = out, N = in] = dy^T x with K = tokens: both operands are transposed into K-contiguous slices
+    // ([S][rows][kslice], zero-padded tail) and the S slice products run as ONE batched launch of the sampling path's MFMA GEMM
+    // (gemm4_f32_kernel AMODE 2); the partial products are then added in slice order.
+    if (use_mfma && ta && !tb && !bias && K >= 4096 && M % 32 == 0 && N % 32 == 0) {
+        int S = std::min(256, std::max(1, (int)(((size_t)K * 48) / ((size_t)M * N) + 1)));   // enough tiles to fill the chip, slices >= 512 long
+        S = std::min(S, K / 512);
+        const int kslice = ((K + S - 1) / S + 31) / 32 * 32;
+        S = (K + kslice - 1) / kslice;
+        const size_t nA = (size_t)S * M * kslice, nB = (size_t)S * N * kslice, nC = (size_t)S * M * N, need = nA + nB + nC;
+        if (need > g_sk_cap) {
+            if (g_sk_scratch) (void)hipFree(g_sk_scratch);
+            g_sk_cap = 0; g_sk_scratch = nullptr;
+            if (hipMalloc((void **)&g_sk_scratch, sizeof(float) * need) == hipSuccess) g_sk_cap = need;
+        }
+        if (g_sk_cap >= need) {
+            float *At = g_sk_scratch, *Bt = At + nA, *Cp = Bt + nB;
+            hipLaunchKernelGGL(t_transpose_sliced_kernel, dim3((M + 31) / 32, (kslice + 31) / 32, S), dim3(256), 0, s, A, lda, At, K, M, kslice);
+            hipLaunchKernelGGL(t_transpose_sliced_kernel, dim3((N + 31) / 32, (kslice + 31) / 32, S), dim3(256), 0, s, B, ldb, Bt, K, N, kslice);
+            GemmArgs g;
+            g.A = At; g.lda = kslice; g.K1 = kslice; g.K = kslice; g.M = M; g.N = N; g.W = Bt; g.C = Cp; g.ldc = N;
+            g.batch = S; g.batch_strideA = (size_t)M * kslice; g.batch_strideW = (size_t)N * kslice; g.batch_strideC = (size_t)M * N;
+            launch_gemm(g, s);
+            hipLaunchKernelGGL(t_splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, Cp, C, ldc, M, N, S,
+                               (int)accumulate);
             return;
         }
     }
