@@ -321,8 +321,7 @@ __global__ void t_add_kernel(float *a, const float *b, size_t n) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Window attention core, forward and backward, one block per (sample, window, head); thread i owns query row i (and, in the
-// column passes of the backward, key/value row i).  qkv [B*T][3C] token-major (as the QKV linear writes it), out / d_out [B*T][C].
+// Window attention core, forward and backward, one block per (sample, window, head).  qkv [B*T][3C] token-major (as the QKV linear writes it), out / d_out [B*T][C].
 //   S = scale q k^T + table[index(i,j)][h] (+ -100 where the shifted window's regions differ);  P = softmax_j S;  O = P v
 // token of (window (wi,wj), position p): rolled coordinate r = (wi ws + p / ws, wj ws + p % ws), original (r + shift) mod res.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -337,100 +336,108 @@ __device__ __forceinline__ int t_token_of(const TAttnGeom &g, int w, int p, int 
 }
 __device__ __forceinline__ int t_region(const TAttnGeom &g, int r) { return r < g.res - g.ws ? 0 : (r < g.res - g.shift ? 1 : 2); }
 
+// Four threads per window row: thread (i, p) owns keys j = p, p+4, ... of query row i in the row passes and head dims 8p..8p+7 (HD = 32)
+// of row i in the passes that produce [Wt, HD] results; 4-lane shuffles combine a row's partial max / sums.
 template <bool BWD>
 __global__ void t_attn_kernel(const float *qkv, const float *table, float *out, const float *d_out, float *d_qkv, float *d_table,
                               TAttnGeom g) {
     extern __shared__ float sm[];
-    const int Wt = g.ws * g.ws, HD = g.C / g.heads, LD = HD + 1;
-    float *qs = sm, *ks = qs + Wt * LD, *vs = ks + Wt * LD, *dos = vs + Wt * LD, *Ps = dos + (BWD ? Wt * LD : 0);   // Ps [Wt][Wt+1]
+    const int Wt = g.ws * g.ws, HD = g.C / g.heads, LD = HD + 1, PL = Wt + 1;
+    float *qs = sm, *ks = qs + Wt * LD, *vs = ks + Wt * LD, *dos = vs + Wt * LD, *Ps = dos + (BWD ? Wt * LD : 0), *dPs = Ps + Wt * PL;
     const int nW = (g.res / g.ws) * (g.res / g.ws), T = g.res * g.res;
     const int h = blockIdx.x % g.heads, w = (blockIdx.x / g.heads) % nW, b = blockIdx.x / (g.heads * nW);
-    const int i = threadIdx.x;
+    const int i = threadIdx.x >> 2, p = threadIdx.x & 3, d0 = p * (HD / 4), DG = HD / 4;
+    const bool act = i < Wt;
     const float scale = 1.0f / sqrtf((float)HD);
+    __shared__ int regs[128], toks[128];
+    __shared__ float dtab[448];   // this block's share of the relative-position-bias gradient ((2 ws - 1)^2 <= 441 entries of head h)
+    const int ntab = (2 * g.ws - 1) * (2 * g.ws - 1);
+    if (BWD) for (int t = threadIdx.x; t < ntab; t += blockDim.x) dtab[t] = 0.f;
     int ri = 0, rj = 0, tok = 0, reg = 0;
-    if (i < Wt) {
+    if (act) {
         tok = t_token_of(g, w, i, ri, rj);
         reg = g.shift > 0 ? 3 * t_region(g, ri) + t_region(g, rj) : 0;
         const float *row = qkv + ((size_t)b * T + tok) * 3 * g.C + h * HD;
-        for (int d = 0; d < HD; d++) { qs[i * LD + d] = row[d]; ks[i * LD + d] = row[g.C + d]; vs[i * LD + d] = row[2 * g.C + d]; }
-        if (BWD) { const float *dr = d_out + ((size_t)b * T + tok) * g.C + h * HD; for (int d = 0; d < HD; d++) dos[i * LD + d] = dr[d]; }
+        for (int d = d0; d < d0 + DG; d++) { qs[i * LD + d] = row[d]; ks[i * LD + d] = row[g.C + d]; vs[i * LD + d] = row[2 * g.C + d]; }
+        if (BWD) { const float *dr = d_out + ((size_t)b * T + tok) * g.C + h * HD; for (int d = d0; d < d0 + DG; d++) dos[i * LD + d] = dr[d]; }
+        if (p == 0) { regs[i] = reg; toks[i] = tok; }
     }
-    __shared__ int regs[128];
-    if (i < Wt) regs[i] = reg;
     __syncthreads();
     const int yi = i / g.ws, xi = i % g.ws;
-    if (i < Wt) {   // row i of P
-        float mx = -3.0e38f;
-        for (int j = 0; j < Wt; j++) {
-            float s = 0.f;
-            for (int d = 0; d < HD; d++) s = fmaf(qs[i * LD + d], ks[j * LD + d], s);
+    // ---- P = softmax(scale q k^T + bias (+ mask)) ----
+    float mx = -3.0e38f;
+    if (act)
+        for (int j = p; j < Wt; j += 4) {
+            float sc = 0.f;
+            for (int d = 0; d < HD; d++) sc = fmaf(qs[i * LD + d], ks[j * LD + d], sc);
             const int idx = (yi - j / g.ws + g.ws - 1) * (2 * g.ws - 1) + (xi - j % g.ws + g.ws - 1);
-            s = s * scale + table[(size_t)idx * g.heads + h];
-            if (g.shift > 0 && regs[j] != reg) s += -100.0f;
-            Ps[i * (Wt + 1) + j] = s;
-            mx = fmaxf(mx, s);
+            sc = sc * scale + table[(size_t)idx * g.heads + h];
+            if (g.shift > 0 && regs[j] != reg) sc += -100.0f;
+            Ps[i * PL + j] = sc;
+            mx = fmaxf(mx, sc);
         }
-        float sum = 0.f;
-        for (int j = 0; j < Wt; j++) { const float e = expf(Ps[i * (Wt + 1) + j] - mx); Ps[i * (Wt + 1) + j] = e; sum += e; }
-        const float inv = 1.0f / sum;
-        for (int j = 0; j < Wt; j++) Ps[i * (Wt + 1) + j] *= inv;
-        if (!BWD) {
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64)); mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float sum = 0.f;
+    if (act)
+        for (int j = p; j < Wt; j += 4) { const float e = expf(Ps[i * PL + j] - mx); Ps[i * PL + j] = e; sum += e; }
+    sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64);
+    if (act) { const float inv = 1.0f / sum; for (int j = p; j < Wt; j += 4) Ps[i * PL + j] *= inv; }
+    __syncthreads();
+    if (!BWD) {
+        if (act) {
             float *o = out + ((size_t)b * T + tok) * g.C + h * HD;
-            for (int d = 0; d < HD; d++) {
+            for (int d = d0; d < d0 + DG; d++) {
                 float a = 0.f;
-                for (int j = 0; j < Wt; j++) a = fmaf(Ps[i * (Wt + 1) + j], vs[j * LD + d], a);
+                for (int j = 0; j < Wt; j++) a = fmaf(Ps[i * PL + j], vs[j * LD + d], a);
                 o[d] = a;
             }
         }
+        return;
     }
-    if (!BWD) return;
-    __syncthreads();
     float *dq = d_qkv + ((size_t)b * T + tok) * 3 * g.C + h * HD;
-    if (i < Wt) {   // column pass 1: dV[i] = sum_q P[q][i] dO[q]
-        for (int d = 0; d < HD; d++) {
+    // ---- dV[i] = sum_q P[q][i] dO[q];  dP[i][j] = dO[i] . v[j] and t_i = sum_j dP P ----
+    float tsum = 0.f;
+    if (act) {
+        for (int d = d0; d < d0 + DG; d++) {
             float a = 0.f;
-            for (int q = 0; q < Wt; q++) a = fmaf(Ps[q * (Wt + 1) + i], dos[q * LD + d], a);
+            for (int q = 0; q < Wt; q++) a = fmaf(Ps[q * PL + i], dos[q * LD + d], a);
             dq[2 * g.C + d] = a;
         }
-    }
-    __syncthreads();
-    if (i < Wt) {   // row pass: dS[i][j] = P (dP - sum_j dP P), overwriting P; the bias gradient; dQ[i] = scale sum_j dS[i][j] k[j]
-        float tsum = 0.f;
-        for (int j = 0; j < Wt; j++) {
+        for (int j = p; j < Wt; j += 4) {
             float dp = 0.f;
             for (int d = 0; d < HD; d++) dp = fmaf(dos[i * LD + d], vs[j * LD + d], dp);
-            tsum = fmaf(dp, Ps[i * (Wt + 1) + j], tsum);
+            dPs[i * PL + j] = dp;
+            tsum = fmaf(dp, Ps[i * PL + j], tsum);
         }
-        for (int j = 0; j < Wt; j++) {
-            float dp = 0.f;
-            for (int d = 0; d < HD; d++) dp = fmaf(dos[i * LD + d], vs[j * LD + d], dp);
-            const float ds = Ps[i * (Wt + 1) + j] * (dp - tsum);
-            Ps[i * (Wt + 1) + j] = ds;
+    }
+    tsum += __shfl_xor(tsum, 1, 64); tsum += __shfl_xor(tsum, 2, 64);
+    __syncthreads();   // every dV column pass has read P before it is overwritten
+    // ---- dS = P (dP - t) overwrites P; the bias gradient ----
+    if (act)
+        for (int j = p; j < Wt; j += 4) {
+            const float ds = Ps[i * PL + j] * (dPs[i * PL + j] - tsum);
+            Ps[i * PL + j] = ds;
             const int idx = (yi - j / g.ws + g.ws - 1) * (2 * g.ws - 1) + (xi - j % g.ws + g.ws - 1);
-            atomicAdd(d_table + (size_t)idx * g.heads + h, ds);
+            atomicAdd(&dtab[idx], ds);   // LDS atomics; one global atomic per table entry and block below (4096 -> 225 per 8x8 window)
         }
-        for (int d = 0; d < HD; d++) {
-            float a = 0.f;
-            for (int j = 0; j < Wt; j++) a = fmaf(Ps[i * (Wt + 1) + j], ks[j * LD + d], a);
-            dq[d] = a * scale;
-        }
-    }
     __syncthreads();
-    if (i < Wt) {   // column pass 2: dK[i] = scale sum_q dS[q][i] q[q]
-        for (int d = 0; d < HD; d++) {
-            float a = 0.f;
-            for (int q = 0; q < Wt; q++) a = fmaf(Ps[q * (Wt + 1) + i], qs[q * LD + d], a);
-            dq[g.C + d] = a * scale;
+    for (int t = threadIdx.x; t < ntab; t += blockDim.x) atomicAdd(d_table + (size_t)t * g.heads + h, dtab[t]);
+    // ---- dQ[i] = scale sum_j dS[i][j] k[j];  dK[i] = scale sum_q dS[q][i] q[q] ----
+    if (act)
+        for (int d = d0; d < d0 + DG; d++) {
+            float a = 0.f, c = 0.f;
+            for (int j = 0; j < Wt; j++) { a = fmaf(Ps[i * PL + j], ks[j * LD + d], a); c = fmaf(Ps[j * PL + i], qs[j * LD + d], c); }
+            dq[d] = a * scale;
+            dq[g.C + d] = c * scale;
         }
-    }
 }
 static bool t_attn_launch(bool bwd, const float *qkv, const float *table, float *out, const float *d_out, float *d_qkv, float *d_table,
                           int B, TAttnGeom g, hipStream_t s) {
     const int Wt = g.ws * g.ws, HD = g.C / g.heads, LD = HD + 1;
-    if (Wt > 128) return false;
-    const size_t lds = sizeof(float) * ((size_t)(bwd ? 4 : 3) * Wt * LD + (size_t)Wt * (Wt + 1));
+    if (Wt > 128 || HD % 4 != 0) return false;
+    const size_t lds = sizeof(float) * ((size_t)(bwd ? 4 : 3) * Wt * LD + (size_t)(bwd ? 2 : 1) * Wt * (Wt + 1));
     const int nW = (g.res / g.ws) * (g.res / g.ws);
-    const dim3 grid(B * nW * g.heads), block(128);
+    const dim3 grid(B * nW * g.heads), block((4 * Wt + 63) / 64 * 64);
     if (bwd) {
         if (hipFuncSetAttribute((const void *)t_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
         hipLaunchKernelGGL((t_attn_kernel<true>), grid, block, lds, s, qkv, table, out, d_out, d_qkv, d_table, g);
