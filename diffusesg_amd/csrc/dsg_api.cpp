@@ -1819,15 +1819,31 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
             if (!missing.empty()) return fail(h, DSG_ERR_INVALID, "missing tensor '%s'", missing.c_str());
             // scratch for the backward: the widest [M, 4C] tensors of any stage, three of them, + block scratch
             A.cap = A.off;
-            HIP_TRY(h, hipMalloc((void **)&A.base, sizeof(float) * A.cap + 64));
+            // the saved-activation arena and the backward scratch are kept between calls (hipMalloc / hipFree of ~10 GB per
+            // iteration cost more than a tenth of it); one training stream per process
+            static float *arena_keep = nullptr; static size_t arena_cap = 0;
+            if (A.cap + 16 > arena_cap) {
+                if (arena_keep) (void)hipFree(arena_keep);
+                arena_keep = nullptr; arena_cap = 0;
+                HIP_TRY(h, hipMalloc((void **)&arena_keep, sizeof(float) * (A.cap + 16)));
+                arena_cap = A.cap + 16;
+            }
+            A.base = arena_keep;
             HIP_TRY(h, hipMalloc((void **)&has_sc_dev, sizeof(int)));
             HIP_TRY(h, hipMemcpy(has_sc_dev, &has_sc_host, sizeof(int), hipMemcpyHostToDevice));
         }
     }
     // widest scratch tensors (backward): sized for level 0's [M0, 4E]; every level has M C constant up to the 2x of merging
     size_t wide = M0 * (size_t)(4 * E);
-    float *scr = nullptr;
-    if (hipMalloc((void **)&scr, sizeof(float) * (wide * 3 + M0 * (size_t)E * 8 + 4096)) != hipSuccess) { (void)hipFree(A.base); (void)hipFree(has_sc_dev); return fail(h, DSG_ERR_HIP, "out of memory"); }
+    static float *scr_keep = nullptr; static size_t scr_cap = 0;
+    const size_t scr_need = wide * 3 + M0 * (size_t)E * 8 + 4096;
+    if (scr_need > scr_cap) {
+        if (scr_keep) (void)hipFree(scr_keep);
+        scr_keep = nullptr; scr_cap = 0;
+        if (hipMalloc((void **)&scr_keep, sizeof(float) * scr_need) != hipSuccess) { (void)hipFree(has_sc_dev); return fail(h, DSG_ERR_HIP, "out of memory"); }
+        scr_cap = scr_need;
+    }
+    float *scr = scr_keep;
     float *t_mh = scr, *t_m3c = scr + wide, *t_w = scr + 2 * wide, *t_mc = scr + 3 * wide, *t_mc2 = t_mc + M0 * E * 2, *d_x = t_mc2 + M0 * E * 2,
           *d_y = d_x + M0 * E * 2;
     auto lin_fwd = [&](const float *x, const float *Wm, const float *bias, float *y, size_t M, int in, int out) {
@@ -2014,7 +2030,7 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
     }
     const hipError_t e = hipStreamSynchronize(s);
     const hipError_t e2 = hipGetLastError();
-    (void)hipFree(scr); (void)hipFree(A.base); (void)hipFree(has_sc_dev); (void)hipFree(mid_buf);
+    (void)hipFree(has_sc_dev); (void)hipFree(mid_buf);
     HIP_TRY(h, e);
     HIP_TRY(h, e2);
     if (!ok) return fail(h, DSG_ERR_HIP, "a training kernel failed to launch");
