@@ -981,12 +981,12 @@ def test_swin_block_forward_backward_vs_reference_autograd(name, prefix, B):
     assert torch.equal(x_out2, x_out)
 
 
-@pytest.mark.parametrize("case,cfg_name,B,max_sample", [("tiny", "tiny", 4, 1024), ("tinysc", "tiny", 4, 256), ("vg", "vg", 2, 64)])
+@pytest.mark.parametrize("case,cfg_name,B,max_sample", [("tiny", "tiny", 4, 1024), ("tinysc", "tiny", 4, 256), ("vg", "vg", 2, 64), ("coco", "coco", 1, 32)])
 def test_training_step_gradients_vs_reference_autograd(case, cfg_name, B, max_sample):
     """tests/golden/train_backward.npz: one whole training iteration of the reference (trainer_node_adj.py:96-170 in 'train' mode) up
     to loss.backward() -- objective, self-conditioning coin, the network in training form, the sigma-weighted loss with the IoU term
     -- against dsg_train_step_grads: the preconditioned outputs, the loss, and the gradient of EVERY parameter (95 tensors of the tiny
-    model, 233 of the Visual Genome model: L2 norm and a strided sample each) plus the total gradient norm clip_grad_norm_ reports.
+    model, 233 of the Visual Genome model, 314 of the COCO-Stuff model: L2 norm and a strided sample each) plus the total gradient norm clip_grad_norm_ reports.
     `tinysc` / `vg`: the coin fires, the detached self-conditioning pass (sampling path) feeds the differentiated one."""
     from diffusesg_amd.model import build_network
     from diffusesg_amd.train import NodeAdjEDMObjectiveGeneratorHip, NodeAdjRainbowLossHip, train_step_grads

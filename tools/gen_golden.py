@@ -388,15 +388,17 @@ def gen_train_backward(DiffuseSG, NodeAdjPrecond, out):
     mode 'train' up to and including loss.backward(), the clip-norm it computes and -- tiny case -- the Adam step of
     utils/learning_utils.py:137-140 with the YAMLs' lr 2e-4 / weight_decay 0).  Cases: `tiny` (inputs, draws and coin of G7: the coin
     does not fire), `tinysc` (same, coin forced to 0.3: the detached self-conditioning pass feeds the differentiated one), `vg` (the
-    Visual Genome network, B = 2, coin 0.3; 64-token shifted windows on four levels).  Saved per case: loss, dL/d(preconditioned
-    outputs), dL/d(raw network outputs), per parameter the gradient's L2 norm and every stride-th element (<= 1024, tinysc: <= 256, vg: <= 64), the
+    Visual Genome network, B = 2, coin 0.3; 64-token shifted windows on four levels), `coco` (the COCO-Stuff network, B = 1, coin 0.3;
+    100-token windows, three levels).  Saved per case: loss, dL/d(preconditioned
+    outputs), dL/d(raw network outputs), per parameter the gradient's L2 norm and every stride-th element (<= 1024, tinysc: <= 256, vg: <= 64, coco: <= 32), the
     total gradient norm nn.utils.clip_grad_norm_ reports; tiny: the parameters after the optimiser step (<= 256 values each).
     torchvision's box helpers are restated as in G7."""
     import model.precond.precond as P
     from loss.rainbow_loss import NodeAdjRainbowLoss
     from runner.objectives.edm import NodeAdjEDMObjectiveGenerator
     res = {}
-    for name, cfg_name, B, forced_coin, max_sample in (("tiny", "tiny", 4, None, 1024), ("tinysc", "tiny", 4, 0.3, 256), ("vg", "vg", 2, 0.3, 64)):
+    for name, cfg_name, B, forced_coin, max_sample in (("tiny", "tiny", 4, None, 1024), ("tinysc", "tiny", 4, 0.3, 256), ("vg", "vg", 2, 0.3, 64),
+                                                          ("coco", "coco", 1, 0.3, 32)):
         cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin = Y.train_case(cfg_name, B=B)
         if forced_coin is not None:
             coin = forced_coin
@@ -465,7 +467,7 @@ def gen_train_backward(DiffuseSG, NodeAdjPrecond, out):
         res[f"{name}_coin"] = np.array(coin)
         res[f"{name}_sigmas"], res[f"{name}_weights"] = sigmas.detach().numpy().copy(), weights.detach().numpy().copy()
         res[f"{name}_total_grad_norm"] = np.array(float(total_norm))
-        if name != "vg":
+        if name not in ("vg", "coco"):
             res[f"{name}_pred_adj"], res[f"{name}_pred_node"] = net_output_a.detach().numpy().copy(), net_output_x.detach().numpy().copy()
         if name == "tiny":
             res[f"{name}_grad_pred_adj"], res[f"{name}_grad_pred_node"] = net_output_a.grad.numpy().copy(), net_output_x.grad.numpy().copy()
