@@ -100,6 +100,7 @@ struct dsg_handle_s {
     std::vector<WSpec> specs;
     std::map<std::string, DevTensor> w;
     bool finalized = false;
+    bool ever_finalized = false;                                  // block plans exist and every weight has been set at least once (training entries read raw weights only)
     std::string err;
     // derived
     std::vector<BlockPlan> down[DSG_MAX_LAYERS], up[DSG_MAX_LAYERS];
@@ -758,6 +759,7 @@ int dsg_finalize_weights(dsg_handle h) {
     if (h->opt_gemm_bf16) if (int rc = ensure_bf16_weights(h)) return rc;
     if (h->opt_gemm_split) if (int rc = ensure_split_weights(h)) return rc;
     h->finalized = true;
+    h->ever_finalized = true;
     return DSG_OK;
 }
 
@@ -1671,7 +1673,7 @@ int dsg_rainbow_loss_backward(int32_t B, int32_t N, int32_t c_adj, int32_t c_nod
 
 int dsg_block_train(dsg_handle h, const char *block, int32_t B, const float *x_in, const float *emb, const float *grad_out, float *x_out,
                     float *grad_in, float *grad_emb, int32_t n_params, const char *const *names, float *const *grad_params, void *stream) {
-    if (!h || !h->finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
+    if (!h || !h->ever_finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
     if (!block || B < 1 || !x_in || !emb || !x_out) return fail(h, DSG_ERR_INVALID, "null argument");
     const BlockPlan *bp = nullptr;
     for (int l = 0; l < h->L; l++)
@@ -1736,7 +1738,9 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
                             const float *sc_adj, const float *sc_node, const float *grad_F_adj, const float *grad_F_node, const TrainMid *mid,
                             float *out_F_adj, float *out_F_node, int32_t n_params, const char *const *names, float *const *grad_params,
                             void *stream) {
-    if (!h || !h->finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
+    // the training form reads the raw weights only, so weights re-uploaded after an optimiser step need no re-packing here
+    // (dsg_finalize_weights must have run once: block plans); the sampling-path entries still insist on `finalized`
+    if (!h || !h->ever_finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
     if (B < 1 || !in_adj || !in_node || !flags || !c_noise || !out_F_adj || !out_F_node) return fail(h, DSG_ERR_INVALID, "null argument");
     const bool bwd = grad_F_adj != nullptr || mid != nullptr;
     if (bwd && ((!mid && !grad_F_node) || !names || !grad_params)) return fail(h, DSG_ERR_INVALID, "backward needs both output gradients and the parameter gradient buffers");
@@ -2049,7 +2053,7 @@ int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const 
                          const float *loss_weight, float edge_loss_weight, float node_loss_weight, float iou_loss_weight, float *out_D_adj,
                          float *out_D_node, float *out_loss_adj, float *out_loss_node, int32_t n_params, const char *const *names,
                          float *const *grad_params, void *stream) {
-    if (!h || !h->finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
+    if (!h || !h->ever_finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
     if (B < 1 || !noisy_adj || !noisy_node || !flags || !sigmas || !target_adj || !target_node || !out_D_adj || !out_D_node || !out_loss_adj ||
         !out_loss_node)
         return fail(h, DSG_ERR_INVALID, "null argument");

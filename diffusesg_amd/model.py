@@ -70,7 +70,12 @@ class DiffuseSGHip(nn.Module):
     def _weights_version(self):
         return tuple((p._version, p.data_ptr()) for p in self.parameters())
 
-    def _ensure_handle(self):
+    def _ensure_handle(self, finalize: bool = True):
+        """The library handle with this module's current weights.  finalize=False (training iterations only): changed weights
+        are uploaded but the sampling path's derived tensors (folded / packed weights, bias tables) are not rebuilt -- the
+        training-form kernels read the raw weights; the next ordinary call rebuilds them."""
+        if self._handle is None:
+            finalize = True
         if self._handle is None:
             if not torch.cuda.is_available():
                 raise _lib.DsgError("DiffuseSGHip needs an MI355X: torch.cuda.is_available() is False and there is no CPU fallback")
@@ -93,8 +98,11 @@ class DiffuseSGHip(nn.Module):
                 else:  # relative_position_index (int64 constant)
                     t = t.detach().contiguous().cpu()
                     self._handle.set_weight(k, t.data_ptr(), tuple(t.shape), False)
-            self._handle.finalize()
             self._synced_version = ver
+            self._finalized_ok = False
+        if finalize and not getattr(self, "_finalized_ok", False):
+            self._handle.finalize()
+            self._finalized_ok = True
         return self._handle
 
     def load_numpy_state_dict(self, sd):

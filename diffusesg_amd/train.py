@@ -227,7 +227,7 @@ def train_step_grads(model, loss_func, net_input_a, net_input_x, node_flags, sig
     Correctness-first kernels (`dsg_train_step_grads`), pinned to the reference's autograd; optimiser / EMA / clipping / DDP are not built."""
     import numpy as np
     m = model.model
-    h = m._ensure_handle()
+    h = m._ensure_handle(finalize=False)   # raw weights only; the sampling path's packed weights are rebuilt when the coin needs them
     B, a, x, fl, _, _ = m._canon(net_input_a, net_input_x, node_flags, None, None)
     _, ta, tx, _, _, _ = m._canon(net_target_a, net_target_x, node_flags, None, None)
     dev = m._dev
@@ -237,6 +237,7 @@ def train_step_grads(model, loss_func, net_input_a, net_input_x, node_flags, sig
     sa = sx = None
     if model.self_condition and np.random.rand() < 0.5:   # precond.py:90-98: D of a no-grad pass becomes the (detached) self-cond input
         sa, sx = torch.empty_like(a), torch.empty_like(x)
+        h = m._ensure_handle()   # this pass runs on the sampling path: needs the packed weights of the CURRENT parameters
         h.check(h.L.dsg_precond(h.raw, B, _p(a), _p(x), _p(fl), _p(sg), None, None, 0, _p(sa), _p(sx), st), "dsg_precond")
     keys = [k for k, _ in m.named_parameters()] if want_grads else []
     sd = dict(m.named_parameters())
