@@ -35,36 +35,46 @@ __device__ __forceinline__ void split3_bits(float a, unsigned &h, unsigned &m, u
     m = __float_as_uint(r1) & 0xffff0000u;
     l = __float_as_uint(r1 - __uint_as_float(m));   // bits [31:16] are used
 }
-constexpr int HBK = 64, HLD = 72;  // k per chunk, LDS row stride in bf16 elements (144 B: 16-B aligned, conflict-free)
+constexpr int HBK = 64;  // k per chunk of the 128x96 tile; K1 of a two-source GEMM must be a multiple of it
 
 // EPI: the same epilogue extensions as gemm4_f32_kernel (kernels.hip): 1 row-statistics partials, 2 / 3 the next block's
 // modulate+SiLU (batch-uniform / per-sample) + partials; LN statistics may come from a producer's partials (g.ln_part).
 // ABF / CBF ("bf16 activations between kernels"): the A tensor is already bf16 (staged into LDS as is: no conversion, half the
 // bytes) / the result is stored as bf16.  Used where the consumer is this kernel and would round the fp32 value to bf16 on its way
 // into LDS anyway (fc1 -> fc2's hidden tensor, attention output -> proj): results are bit-identical to the fp32-tensor path.
-template <bool LN, int ACT, bool RES, int EPI = 0, bool ABF = false, bool CBF = false>
+// RB (round 2, late): 32-row blocks per wave.  RB = 1: 128x96 block tile, K step 64.  RB = 2: 256x96 block tile (a wave owns 64 rows),
+// K step 32: every W fragment read from LDS feeds two MFMAs instead of one -- the 32x96 wave tile asks the LDS for ~340 B/clk per CU
+// (it has 128), the 64x96 one for ~210 -- and the A tile is re-read from L2 by half as many column-tile blocks per row.
+template <bool LN, int ACT, bool RES, int EPI = 0, bool ABF = false, bool CBF = false, int RB = 1>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     static_assert(!(ABF && LN), "a bf16 A tensor carries no LayerNorm");
-    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (GBM + GBN) * HLD];
-    constexpr int BUF = (GBM + GBN) * HLD;
+    constexpr int TM = GBM * RB;                 // block rows
+    constexpr int KB = RB == 1 ? 64 : 32;        // k per chunk
+    constexpr int LDP = KB + 8;                  // LDS row stride in bf16 elements (16-B aligned, conflict-free b128 reads)
+    constexpr int TA = KB / 4, RPA = 256 / TA;   // fp32 A staging: threads per row (float4 each), rows per pass; TM / RPA == 8 passes
+    constexpr int TW = KB / 8, RPW = 256 / TW;   // bf16 staging (W, and A when ABF): threads per row (8 bf16 each), rows per pass
+    constexpr int PW = (GBN + RPW - 1) / RPW;    // W passes (3 or 2; rows >= 96 of the last pass are masked)
+    constexpr int PAB = TM / RPW;                // bf16-A passes (4)
+    static_assert(TM / RPA == 8 && PAB == 4, "staging layout");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (TM + GBN) * LDP];
+    constexpr int BUF = (TM + GBN) * LDP;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, seq = bid >> 3;
     const int tm = (seq / tiles_n) * 8 + xcd, tn = seq % tiles_n;
     if (tm >= tiles_m) return;
-    const int m0 = tm * GBM, n0 = tn * GBN;
+    const int m0 = tm * TM, n0 = tn * GBN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rows_m = min(GBM, g.M - m0), rows_n = min(GBN, g.N - n0);
+    const int rows_m = min(TM, g.M - m0), rows_n = min(GBN, g.N - n0);
     const rsrc_t rsA1 = ABF ? make_rsrc(reinterpret_cast<const __bf16 *>(g.A) + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 2u)
                             : make_rsrc(g.A + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 4u);
     const rsrc_t rsA2 = make_rsrc(g.A2 ? g.A2 + (size_t)m0 * g.lda2 : g.A, g.A2 ? (unsigned)rows_m * g.lda2 * 4u : 0u);
     const rsrc_t rsW = make_rsrc(static_cast<const __bf16 *>(g.Wb) + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 2u);
-    // A staging: 16 threads per row (float4 each = 64 k), rows ra + 16p; W staging: 8 threads per row (8 bf16 each)
-    const int ca = tid & 15, ra = tid >> 4, cw = tid & 7, rw = tid >> 3;
-    unsigned voffA1[8], voffA2[8], voffW[3];
+    const int ca = tid % TA, ra = tid / TA, cw = tid % TW, rw = tid / TW;
+    unsigned voffA1[8], voffA2[8], voffW[PW];
     float a_rstd[8], a_nmr[8];
 #pragma unroll
     for (int p = 0; p < 8; p++) {
-        const int r = ra + 16 * p;
+        const int r = ra + RPA * p;
         voffA1[p] = ((unsigned)r * g.lda + 4u * ca) * 4u;
         voffA2[p] = ((unsigned)r * g.lda2 + 4u * ca) * 4u;
         if (LN) {
@@ -92,22 +102,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
         }
     }
 #pragma unroll
-    for (int p = 0; p < 3; p++) voffW[p] = ((unsigned)(rw + 32 * p) * g.K + 8u * cw) * 2u;
-    unsigned voffAb[4];   // ABF: 8 threads per row (8 bf16 each), rows rw + 32p
+    for (int p = 0; p < PW; p++) voffW[p] = (rw + RPW * p < GBN) ? ((unsigned)(rw + RPW * p) * g.K + 8u * cw) * 2u : 0x7fffffffu;
+    unsigned voffAb[PAB];   // ABF: TW threads per row (8 bf16 each), rows rw + RPW p
 #pragma unroll
-    for (int p = 0; p < 4; p++) voffAb[p] = ((unsigned)(rw + 32 * p) * g.lda + 8u * cw) * 2u;
-    // K may be a multiple of 32 only (e.g. 96): the last chunk is then half valid; the descriptor zero-fills the rest of
-    // the row only at the buffer end, so clamp explicitly
-    const int nk = (g.K + HBK - 1) / HBK;
+    for (int p = 0; p < PAB; p++) voffAb[p] = ((unsigned)(rw + RPW * p) * g.lda + 8u * cw) * 2u;
+    // K may be a multiple of 32 only (e.g. 96): with KB = 64 the last chunk is then half valid; the descriptor zero-fills the rest
+    // of the row only at the buffer end, so clamp explicitly
+    const int nk = (g.K + KB - 1) / KB;
     const int K1 = g.A2 ? g.K1 : g.K;
 
     f32x4 sa[8];
-    bf16x8 sw[3], sab[4];
+    bf16x8 sw[PW], sab[PAB];
     auto issue = [&](int kc) {
-        const int k0 = kc * HBK, k = k0 + 4 * ca;
+        const int k0 = kc * KB, k = k0 + 4 * ca;
         if (ABF) {
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
+            for (int p = 0; p < PAB; p++) {
                 bf16x8 v = {};
                 if (k0 + 8 * cw < g.K) v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsA1, voffAb[p], (unsigned)k0 * 2u, 0));
                 sab[p] = v;
@@ -120,18 +130,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
             sa[p] = v;
         }
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
+        for (int p = 0; p < PW; p++) {
             bf16x8 v = {};
             if (k0 + 8 * cw < g.K) v = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsW, voffW[p], (unsigned)k0 * 2u, 0));
             sw[p] = v;
         }
     };
     auto write = [&](int buf, int kc) {
-        __bf16 *As = lds + buf * BUF, *Ws = As + GBM * HLD;
-        const bool kvalid = kc * HBK + 4 * ca < g.K;
+        __bf16 *As = lds + buf * BUF, *Ws = As + TM * LDP;
+        const bool kvalid = kc * KB + 4 * ca < g.K;
         if (ABF) {
 #pragma unroll
-            for (int p = 0; p < 4; p++) *reinterpret_cast<bf16x8 *>(As + (rw + 32 * p) * HLD + 8 * cw) = sab[p];
+            for (int p = 0; p < PAB; p++) *reinterpret_cast<bf16x8 *>(As + (rw + RPW * p) * LDP + 8 * cw) = sab[p];
         }
 #pragma unroll
         for (int p = 0; p < (ABF ? 0 : 8); p++) {
@@ -143,31 +153,37 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
             u32x2 b;
             b[0] = pack_hi16(bf16_rne_hi(v[0]), bf16_rne_hi(v[1]));
             b[1] = pack_hi16(bf16_rne_hi(v[2]), bf16_rne_hi(v[3]));
-            *reinterpret_cast<u32x2 *>(As + (ra + 16 * p) * HLD + 4 * ca) = b;
+            *reinterpret_cast<u32x2 *>(As + (ra + RPA * p) * LDP + 4 * ca) = b;
         }
 #pragma unroll
-        for (int p = 0; p < 3; p++) *reinterpret_cast<bf16x8 *>(Ws + (rw + 32 * p) * HLD + 8 * cw) = sw[p];
+        for (int p = 0; p < PW; p++)
+            if (rw + RPW * p < GBN) *reinterpret_cast<bf16x8 *>(Ws + (rw + RPW * p) * LDP + 8 * cw) = sw[p];
     };
     const int lrow = lane & 31, lhalf = lane >> 5;
-    f32x16 acc[3];
+    f32x16 acc[RB][3];
 #pragma unroll
-    for (int j = 0; j < 3; j++)
+    for (int rb = 0; rb < RB; rb++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[rb][j][r] = 0.f;
     issue(0);
     write(0, 0);
     __syncthreads();
     for (int kc = 0; kc < nk; kc++) {
         const int cur = kc & 1;
         if (kc + 1 < nk) issue(kc + 1);
-        const __bf16 *As = lds + cur * BUF, *Ws = As + GBM * HLD;
+        const __bf16 *As = lds + cur * BUF, *Ws = As + TM * LDP;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {  // 4 MFMA k-steps of 16; lane (row, half) holds k = 16s + 8*half + 0..7
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(As + (wave * 32 + lrow) * HLD + 16 * s + 8 * lhalf);
+        for (int s = 0; s < KB / 16; s++) {  // MFMA k-steps of 16; lane (row, half) holds k = 16s + 8*half + 0..7
+            bf16x8 b[3];
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const bf16x8 b = *reinterpret_cast<const bf16x8 *>(Ws + (32 * j + lrow) * HLD + 16 * s + 8 * lhalf);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[j], 0, 0, 0);
+            for (int j = 0; j < 3; j++) b[j] = *reinterpret_cast<const bf16x8 *>(Ws + (32 * j + lrow) * LDP + 16 * s + 8 * lhalf);
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(As + (wave * 32 * RB + 32 * rb + lrow) * LDP + 16 * s + 8 * lhalf);
+#pragma unroll
+                for (int j = 0; j < 3; j++) acc[rb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[j], acc[rb][j], 0, 0, 0);
             }
         }
         if (kc + 1 < nk) write(1 - cur, kc + 1);
@@ -177,68 +193,74 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs g, int tiles
                            : make_rsrc(g.C + (size_t)m0 * g.ldc, (unsigned)rows_m * g.ldc * 4u);
     const rsrc_t rsC2 = make_rsrc(g.C2 ? g.C2 + (size_t)m0 * g.ldc2 : g.C, g.C2 ? (unsigned)rows_m * g.ldc2 * 4u : 0u);
     const rsrc_t rsR = make_rsrc(RES ? g.res + (size_t)m0 * g.ldres : g.C, RES ? (unsigned)rows_m * g.ldres * 4u : 0u);
-    const unsigned rowl = (unsigned)(wave * 32 + 4 * lhalf);
     const unsigned OOB = 0x7fffffffu;
     float *ldsf = reinterpret_cast<float *>(lds);   // the K loop's tiles are dead after its last barrier
-    float st_s[16], st_q[16];
-    int brow[16];
-    if (EPI >= 1) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) { st_s[r] = 0.f; st_q[r] = 0.f; }
-    }
-    if (EPI == 3) {   // per-sample (scale,shift): row -> sample through a 128-entry LDS table
-        int *bt = reinterpret_cast<int *>(ldsf) + 4 * 2304;
-        if (tid < GBM) bt[tid] = min(m0 + tid, g.M - 1) / g.mod_T;
+    int *bt = reinterpret_cast<int *>(ldsf) + 4 * 2304;   // EPI == 3: row -> sample table behind the four per-wave reduction slabs
+    if (EPI == 3) {   // per-sample (scale,shift): row -> sample through a TM-entry LDS table
+        for (int t = tid; t < TM; t += 256) bt[t] = min(m0 + t, g.M - 1) / g.mod_T;
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 16; r++) brow[r] = bt[rowl + (r & 3) + 8 * (r >> 2)];
     }
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const int n = n0 + 32 * j + lrow;
-        const bool nok = n < g.N;
-        const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
-        const unsigned vC = nok ? (rowl * g.ldc + (unsigned)n) * 4u : OOB;
-        const unsigned vC2 = nok ? (rowl * g.ldc2 + (unsigned)n) * 4u : OOB;
-        const unsigned vR = nok ? (rowl * g.ldres + (unsigned)n) * 4u : OOB;
-        float msc = 0.f, msh = 0.f;
-        if (EPI == 2 && nok) { msc = g.mod_aff[g.mod_off + n] + 1.0f; msh = g.mod_aff[g.mod_off + g.N + n]; }
+    for (int rb = 0; rb < RB; rb++) {
+        const unsigned rowl = (unsigned)(wave * 32 * RB + 32 * rb + 4 * lhalf);
+        float st_s[16], st_q[16];
+        int brow[16];
+        if (EPI >= 1) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const unsigned rr = (unsigned)((r & 3) + 8 * (r >> 2));
-            float v = acc[j][r] + bias;
-            if (ACT == ACT_GELU) v = gelu_f(v);
-            else if (ACT == ACT_SILU) v = silu_exact(v);
-            if (RES) v += buf_load1(rsR, vR, rr * g.ldres * 4u);
-            if (g.C2) buf_store1(v, rsC2, vC2, rr * g.ldc2 * 4u);
-            if (EPI == 3 && nok) {
-                const float *ar = g.mod_aff + (size_t)brow[r] * g.mod_ld + g.mod_off + n;
-                msc = ar[0] + 1.0f; msh = ar[g.N];
+            for (int r = 0; r < 16; r++) { st_s[r] = 0.f; st_q[r] = 0.f; }
+        }
+        if (EPI == 3) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) brow[r] = bt[rowl + (r & 3) + 8 * (r >> 2)];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int n = n0 + 32 * j + lrow;
+            const bool nok = n < g.N;
+            const float bias = (g.bias && nok) ? g.bias[n] : 0.f;
+            const unsigned vC = nok ? (rowl * g.ldc + (unsigned)n) * 4u : OOB;
+            const unsigned vC2 = nok ? (rowl * g.ldc2 + (unsigned)n) * 4u : OOB;
+            const unsigned vR = nok ? (rowl * g.ldres + (unsigned)n) * 4u : OOB;
+            float msc = 0.f, msh = 0.f;
+            if (EPI == 2 && nok) { msc = g.mod_aff[g.mod_off + n] + 1.0f; msh = g.mod_aff[g.mod_off + g.N + n]; }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const unsigned rr = (unsigned)((r & 3) + 8 * (r >> 2));
+                float v = acc[rb][j][r] + bias;
+                if (ACT == ACT_GELU) v = gelu_f(v);
+                else if (ACT == ACT_SILU) v = silu_exact(v);
+                if (RES) v += buf_load1(rsR, vR, rr * g.ldres * 4u);
+                if (g.C2) buf_store1(v, rsC2, vC2, rr * g.ldc2 * 4u);
+                if (EPI == 3 && nok) {
+                    const float *ar = g.mod_aff + (size_t)brow[r] * g.mod_ld + g.mod_off + n;
+                    msc = ar[0] + 1.0f; msh = ar[g.N];
+                }
+                if (EPI >= 2) v = silu_exact(fmaf(v, msc, msh));
+                if (EPI >= 1 && nok) { st_s[r] += v; st_q[r] = fmaf(v, v, st_q[r]); }
+                if (CBF) buf_store_bf16(v, rsC, nok ? vC >> 1 : OOB, rr * g.ldc * 2u);
+                else buf_store1(v, rsC, vC, rr * g.ldc * 4u);
             }
-            if (EPI >= 2) v = silu_exact(fmaf(v, msc, msh));
-            if (EPI >= 1 && nok) { st_s[r] += v; st_q[r] = fmaf(v, v, st_q[r]); }
-            if (CBF) buf_store_bf16(v, rsC, nok ? vC >> 1 : OOB, rr * g.ldc * 2u);
-            else buf_store1(v, rsC, vC, rr * g.ldc * 4u);
         }
-    }
-    if (EPI >= 1) {   // row statistics of the stored tile: per-wave LDS transpose, fixed-order sums (see gemm4_f32_kernel)
-        float *red = ldsf + wave * 2304;   // [2 quantities][32 rows][36]
+        if (EPI >= 1) {   // row statistics of the stored tile: per-wave LDS transpose, fixed-order sums (see gemm4_f32_kernel)
+            float *red = ldsf + wave * 2304;   // [2 quantities][32 rows][36]
+            __builtin_amdgcn_wave_barrier();   // (RB = 2: the slab is reused by the wave's second row block)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
-            red[row * GLD + lrow] = st_s[r];
-            red[(32 + row) * GLD + lrow] = st_q[r];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const float *src = red + (lhalf * 32 + lrow) * GLD;
-        float tot = 0.f;
+            for (int r = 0; r < 16; r++) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                red[row * GLD + lrow] = st_s[r];
+                red[(32 + row) * GLD + lrow] = st_q[r];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const float *src = red + (lhalf * 32 + lrow) * GLD;
+            float tot = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const f32x4 q4 = *reinterpret_cast<const f32x4 *>(src + 4 * i);
-            tot += (q4[0] + q4[1]) + (q4[2] + q4[3]);
+            for (int i = 0; i < 8; i++) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4 *>(src + 4 * i);
+                tot += (q4[0] + q4[1]) + (q4[2] + q4[3]);
+            }
+            const rsrc_t rsP = make_rsrc(g.stats_out + (size_t)m0 * tiles_n * 2, (unsigned)(rows_m * tiles_n) * 8u);   // [M][tiles_n][2]
+            buf_store1(tot, rsP, (unsigned)(((wave * 32 * RB + 32 * rb + lrow) * tiles_n + tn) * 2 + lhalf) * 4u, 0u);
         }
-        const rsrc_t rsP = make_rsrc(g.stats_out + (size_t)m0 * tiles_n * 2, (unsigned)(rows_m * tiles_n) * 8u);   // [M][tiles_n][2]
-        buf_store1(tot, rsP, (unsigned)(((wave * 32 + lrow) * tiles_n + tn) * 2 + lhalf) * 4u, 0u);
     }
 }
 
@@ -494,8 +516,18 @@ bool launch_gemm_lp(const GemmArgs &g_in, hipStream_t s) {
     g.gelu_tab = gelu_table();
     const int tiles_n = (g.N + GBN - 1) / GBN;
     const bool split = g.Ws3 != nullptr;
-    const int tiles_m = (g.M + (split ? 256 : GBM) - 1) / (split ? 256 : GBM);
+    // bf16 kernel: the 256x96 tile (RB = 2, a wave owns 64 rows) wherever there are enough rows to fill the chip with it
+    static const bool narrow_only = getenv("DSG_BF16_NARROW") != nullptr;   // dev knob: A/B against the 128x96 tile
+    static const bool force_wide = getenv("DSG_BF16_WIDE") != nullptr;      // tests: the wide tile at every size
+    const bool wide = !split && !narrow_only && (force_wide ? g.M >= 256 : (size_t)((g.M + 255) / 256) * tiles_n >= 512);
+    const int tile_m = split ? 256 : (wide ? 2 * GBM : GBM);
+    const int tiles_m = (g.M + tile_m - 1) / tile_m;
     const dim3 grid(round_up8(tiles_m) * tiles_n), block(256);
+#define LAUNCH_BF16(L, A, R, E, AB, CB)                                                                                           \
+    do {                                                                                                                          \
+        if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<L, A, R, E, AB, CB, 2>), grid, block, 0, s, g, tiles_m, tiles_n);          \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<L, A, R, E, AB, CB, 1>), grid, block, 0, s, g, tiles_m, tiles_n);               \
+    } while (0)
     const bool ln = g.ln_stats != nullptr || g.ln_part != nullptr, res = g.res != nullptr;
     if (g.a4_res > 0 || g.attn_bias) return false;               // fp32-kernel-only features
     if (g.a_bf16 || g.c_bf16) {   // bf16 tensors between kernels: only the shapes the forward uses; anything else is a caller bug
@@ -503,12 +535,12 @@ bool launch_gemm_lp(const GemmArgs &g_in, hipStream_t s) {
         const bool c_ok = g.c_bf16 && !g.a_bf16 && !split && ln && (g.act == ACT_GELU || g.act == ACT_NONE) && !res && !g.stats_out && !g.C2;
         if (!a_ok && !c_ok) { fprintf(stderr, "dsg: launch_gemm_lp: unsupported bf16-tensor GEMM\n"); abort(); }
         if (c_ok) {
-            if (g.act == ACT_GELU) hipLaunchKernelGGL((gemm_bf16_kernel<true, ACT_GELU, false, 0, false, true>), grid, block, 0, s, g, tiles_m, tiles_n);
-            else hipLaunchKernelGGL((gemm_bf16_kernel<true, ACT_NONE, false, 0, false, true>), grid, block, 0, s, g, tiles_m, tiles_n);
+            if (g.act == ACT_GELU) LAUNCH_BF16(true, ACT_GELU, false, 0, false, true);
+            else LAUNCH_BF16(true, ACT_NONE, false, 0, false, true);
             return true;
         }
         const int epi = !g.stats_out ? 0 : !g.mod_aff ? 1 : (g.mod_ld == 0 ? 2 : 3);
-#define LP_ABF(E) hipLaunchKernelGGL((gemm_bf16_kernel<false, ACT_NONE, true, E, true, false>), grid, block, 0, s, g, tiles_m, tiles_n)
+#define LP_ABF(E) LAUNCH_BF16(false, ACT_NONE, true, E, true, false)
         if (epi == 0) LP_ABF(0); else if (epi == 1) LP_ABF(1); else if (epi == 2) LP_ABF(2); else LP_ABF(3);
 #undef LP_ABF
         return true;
@@ -517,7 +549,7 @@ bool launch_gemm_lp(const GemmArgs &g_in, hipStream_t s) {
     if (g.stats_out) {
         if (ln || g.act != ACT_NONE) return false;
         const int epi = !g.mod_aff ? 1 : (g.mod_ld == 0 ? 2 : 3);
-#define LP_EPI(R, E) hipLaunchKernelGGL((gemm_bf16_kernel<false, ACT_NONE, R, E>), grid, block, 0, s, g, tiles_m, tiles_n)
+#define LP_EPI(R, E) LAUNCH_BF16(false, ACT_NONE, R, E, false, false)
         if (res) { if (epi == 1) LP_EPI(true, 1); else if (epi == 2) LP_EPI(true, 2); else LP_EPI(true, 3); }
         else { if (epi == 1) LP_EPI(false, 1); else if (epi == 2) LP_EPI(false, 2); else LP_EPI(false, 3); }
 #undef LP_EPI
@@ -526,7 +558,7 @@ bool launch_gemm_lp(const GemmArgs &g_in, hipStream_t s) {
 #define GEMM_CASE(L, A, R)                                                                                     \
     do {                                                                                                       \
         if (split) hipLaunchKernelGGL((gemm_split2_kernel<L, A, R, 4>), grid, block, 0, s, g, tiles_m, tiles_n); \
-        else hipLaunchKernelGGL((gemm_bf16_kernel<L, A, R>), grid, block, 0, s, g, tiles_m, tiles_n);            \
+        else LAUNCH_BF16(L, A, R, 0, false, false);                                                                \
     } while (0)
     if (ln && g.act == ACT_NONE && !res) GEMM_CASE(true, ACT_NONE, false);
     else if (ln && g.act == ACT_GELU && !res) GEMM_CASE(true, ACT_GELU, false);
