@@ -207,8 +207,9 @@ int dsg_debug_gemm(int32_t M, int32_t N, int32_t K, const float *A, const float 
 int dsg_noise_embed(dsg_handle h, int32_t rows, const float *c_noise, float *out_pe, float *out_emb, float *out_aff, void *stream);
 int32_t dsg_affine_width(dsg_handle h);
 
-/* ---- training-time forward (first half: what a test-loss / training step computes before backward) ----
- * No handle: these only need the tensor dimensions.  Return DSG_OK / DSG_ERR_INVALID / DSG_ERR_HIP.
+/* ---- a training iteration: objective, loss, loss backward (no handle: these only need the tensor dimensions), then
+ * the network in training form with its backward, the optimiser step and the EMA update further down.
+ * Return DSG_OK / DSG_ERR_INVALID / DSG_ERR_HIP.
  *
  * dsg_train_inputs <-> NodeAdjEDMObjectiveGenerator.get_input_output   R/runner/objectives/edm.py:160-180, :239-281
  *   (precond = sigma_dist = 'edm', symmetric_noise = False: learning_utils.py:25-29)
@@ -230,7 +231,7 @@ int dsg_rainbow_loss(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const 
  *   loss = mean_b(loss_adj) + mean_b(loss_node) with the terms of dsg_rainbow_loss (IoU term through autograd's clamp / max / min
  *   rules).  out_grad_* = dL/d(preconditioned outputs), layouts of pred_*.  With sigmas [B] (may be NULL) also
  *   out_grad_F_* = dL/d(raw network outputs F) = c_out(sigma_b) * out_grad_*   (D = mask(c_skip x + c_out F), precond.py:101-104).
- *   The backward of the network itself is not built; tests/golden/train_backward.npz holds its target gradients. */
+ *   (dsg_train_step_grads chains this with the network's own backward.) */
 int dsg_rainbow_loss_backward(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *pred_adj, const float *pred_node,
                               const float *target_adj, const float *target_node, const uint8_t *flags, const float *loss_weight,
                               float edge_loss_weight, float node_loss_weight, float iou_loss_weight, const float *sigmas,
@@ -238,8 +239,8 @@ int dsg_rainbow_loss_backward(int32_t B, int32_t N, int32_t c_adj, int32_t c_nod
 
 /* One SwinTransformerBlock in training form: forward x_out = block(x_in, emb) (R/model/diffusesg/diffusesg.py:232-277 with
  * WindowAttention :108-139 and Mlp :19-25) and, when grad_out != NULL, its backward as torch.autograd derives it -- the first
- * piece of the network backward (second half).  Correctness-first kernels (csrc/train_kernels.hip: LDS-tiled FMA GEMM,
- * one thread per row / window row), pinned to the reference's autograd by tests/golden/block_backward.npz; not on the sampling path.
+ * building block of the network backward.  Correctness-first kernels (csrc/train_kernels.hip; only the large GEMMs run
+ * on the sampling path's MFMA kernel), pinned to the reference's autograd by tests/golden/block_backward.npz.
  *   block: state-dict prefix of the block, e.g. "down_layers.0.blocks.1".  x_in, x_out, grad_out, grad_in: [B, T, C] token-major
  *   (the reference's [B, L, C]); emb, grad_emb: [B, 512] (the mapped noise embedding, dsg_noise_embed).  names[i] (relative to the
  *   prefix: "affine.weight", "affine.bias", "norm1.weight", "norm1.bias", "attn.relative_position_bias_table", "attn.qkv.weight",
@@ -252,7 +253,8 @@ int dsg_block_train(dsg_handle h, const char *block, int32_t B, const float *x_i
  * (R/model/diffusesg/diffusesg.py:765-830) and, when grad_F_adj != NULL, the gradient of every parameter for the upstream gradients
  * dL/dF (e.g. from dsg_rainbow_loss_backward) -- what loss.backward() of a training step leaves in the parameters' .grad
  * (R/runner/trainer/trainer_node_adj.py:163-170), pinned by tests/golden/train_backward.npz.  Correctness-first kernels
- * (csrc/train_kernels.hip), far from the sampling path's speed; optimiser, EMA and DDP are not built.
+ * (csrc/train_kernels.hip), well below the sampling path's speed.  dsg_finalize_weights must have run once; weights
+ * set afterwards (an optimiser step) are used as they are -- the training form reads the raw tensors only.
  *   in_adj [B,C_adj,N,N], in_node [B,N,C_node]: the preconditioned inputs c_in(sigma) * noisy (precond.py:100); c_noise [B];
  *   sc_*: the self-conditioning inputs (constants: the reference detaches them) or NULL; out_F_*: the raw network outputs;
  *   names[i] (state-dict keys of all parameters) -> grad_params[i] (device buffers of the parameters' shapes, overwritten). */
@@ -264,7 +266,8 @@ int dsg_train_grads(dsg_handle h, int32_t B, const float *in_adj, const float *i
  * D = NodeAdjPrecond(noisy, sigmas) with the network in training form, per-sample losses as dsg_rainbow_loss, and -- when the gradient
  * buffers are given -- the gradient of  loss_adj.mean() + loss_node.mean()  for every parameter.  sc_*: the detached self-conditioning
  * inputs (precond.py:90-98; the Python mirror draws the coin and computes them with dsg_precond) or NULL.  The caller supplies the
- * objective's tensors (dsg_train_inputs); optimiser step, EMA, gradient clipping and DDP are not built. */
+ * objective's tensors (dsg_train_inputs); dsg_adam_step / dsg_ema_update below finish the iteration, gradient averaging across
+ * ranks is the host's (diffusesg_amd.dist.all_reduce_mean over RCCL). */
 int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const float *noisy_node, const uint8_t *flags, const float *sigmas,
                          const float *sc_adj, const float *sc_node, const float *target_adj, const float *target_node,
                          const float *loss_weight, float edge_loss_weight, float node_loss_weight, float iou_loss_weight, float *out_D_adj,
