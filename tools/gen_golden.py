@@ -461,7 +461,9 @@ def gen_train_backward(DiffuseSG, NodeAdjPrecond, out):
         node_iou_loss = node_iou_loss.sum(dim=-1) / node_flags_t.sum(dim=-1).to(torch.float32)
         reg_loss_node = reg_loss_node + iou_loss_weight * node_iou_loss * weights
         loss = reg_loss_adj.mean() + reg_loss_node.mean()
+        torch.set_num_threads(1)   # index_add / scatter accumulations of autograd are order-dependent across threads: one thread -> bit-stable fixtures
         loss.backward()
+        torch.set_num_threads(8)
         total_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10.0, norm_type=2)   # returns the norm BEFORE clipping
         res[f"{name}_loss"] = np.array(float(loss.detach()))
         res[f"{name}_coin"] = np.array(coin)
@@ -494,6 +496,32 @@ def gen_train_backward(DiffuseSG, NodeAdjPrecond, out):
     np.savez_compressed(os.path.join(out, "train_backward.npz"), **res)
 
 
+def gen_noise_embed(DiffuseSG, out):
+    """G1 (stand-alone): the noise-conditioning path on its own -- PositionalEmbedding (`map_noise`), map_layer0/1 with SiLU
+    (diffusesg.py:768-771) and every `affine` linear applied to the embedding (PatchEmbed :574, the Swin blocks :238), concatenated
+    in module order: patch_embed, down_layers[l].blocks[j], up_layers[i].blocks[j]."""
+    from torch.nn.functional import silu
+    res = {}
+    c_noise = np.array([-2.3, -0.35, 0.4, 1.0955], np.float32)   # ln(sigma)/4 for sigma in [1e-4, 80]
+    res["c_noise"] = c_noise
+    for name in ("tiny", "vg", "coco"):
+        cfg = CONFIGS[name]()
+        net = build_ref_net(DiffuseSG, cfg)
+        with torch.no_grad():
+            pe = net.map_noise(t(c_noise))
+            emb = silu(net.map_layer1(silu(net.map_layer0(pe))))
+            aff = [net.patch_embed.affine(emb)]
+            for l in net.down_layers:
+                aff += [b.affine(emb) for b in l.blocks]
+            for l in net.up_layers:
+                aff += [b.affine(emb) for b in l.blocks]
+        res[f"{name}_pe"], res[f"{name}_emb"] = pe.numpy(), emb.numpy()
+        if name != "coco":   # (kept small: COCO's 11328 affine outputs add nothing the VG table does not exercise)
+            res[f"{name}_aff"] = torch.cat(aff, dim=1).numpy()
+        print(f"noise embed {name}: pe {tuple(pe.shape)} emb {tuple(emb.shape)} affine outputs {sum(a.shape[1] for a in aff)}")
+    np.savez_compressed(os.path.join(out, "noise_embed.npz"), **res)
+
+
 BLOCK_CASES = [("small", "down_layers.0.blocks.1", 2),    # 16x16 tokens, 4x4 windows, shift 2: the -100 region mask is active
                ("tiny", "down_layers.1.blocks.0", 3),     # 4x4 tokens, window = whole map (no partition), C = 192, 6 heads
                ("coco", "down_layers.1.blocks.1", 1)]     # 20x20 tokens, 10x10 windows (100 tokens), shift 5, C = 192
@@ -515,7 +543,9 @@ def gen_block_backward(DiffuseSG, out):
         for p_ in mod.parameters():
             p_.grad = None
         y = mod(xt, et)
+        torch.set_num_threads(1)   # bit-stable accumulation order (see gen_train_backward)
         (y * t(dy)).sum().backward()
+        torch.set_num_threads(8)
         key = f"{name}/{prefix}"
         rs = 1 if name == "tiny" else 4   # token rows kept (every rs-th): the fixture stays small
         res[f"{key}/row_stride"] = np.array(rs)
