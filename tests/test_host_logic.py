@@ -273,3 +273,30 @@ def test_bench_single_rank_selftest_needs_no_process_group():
     rc, lines, err = _run_bench(["--gpus", "1", "--steps", "1", "--warmup", "0", "--config", "tiny", "--batch", "2", "--selftest-launcher"])
     assert rc == 0, err[-2000:]
     assert lines[0]["world_size"] == 1 and lines[0]["gathered_rows"] == 2
+
+
+def test_checkpoint_writer_layout_matches_reference(tmp_path):
+    """io.get_ckpt_data / save_checkpoint write what the reference's trainer writes (trainer_utils.py:168-185): 'model' with the
+    precond wrapper's 'model.' prefix, nested config, epoch, NumPy-scalar losses, 'model_ema_beta_{beta:.4f}' per EMA helper -- and
+    load_checkpoint / load_model / ema_weight_keywords read it back (CPU only: no library call involved)"""
+    from diffusesg_amd import io as dio, synth as Y, weights as W
+    from diffusesg_amd.model import build_network
+    cfg = Y.CONFIGS["tiny"]()
+    model = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")   # parameters stay on the CPU until a forward needs the GPU
+
+    class FakeEMA:   # the two attributes of diffusesg_amd.train.EMAHip the writer uses
+        beta = 0.999
+        shadow = {k: p.detach().clone() * 0.5 for k, p in model.model.named_parameters()}
+    path = dio.save_checkpoint(str(tmp_path / "visual_genome_00007.pth"), model, [FakeEMA()], 7, np.float64(1.25), np.float64(1.5),
+                               {"model": {"name": "diffuse_sg"}, "train": {"ema_coef": [0.999]}})
+    ckp = dio.load_checkpoint(path)
+    assert set(ckp) == {"model", "config", "epoch", "train_loss", "test_loss", "model_ema_beta_0.9990"}
+    assert all(k.startswith("model.") for k in ckp["model"]) and ckp["epoch"] == 7 and float(ckp["train_loss"]) == 1.25
+    assert dio.ema_weight_keywords(ckp, [0.999]) == ["model_ema_beta_0.9990"]
+    k0 = "model.patch_embed.proj.weight"
+    assert torch.equal(ckp["model_ema_beta_0.9990"][k0], ckp["model"][k0] * 0.5)
+    assert torch.equal(ckp["model_ema_beta_0.9990"]["model.down_layers.0.blocks.0.attn.relative_position_index"],
+                       ckp["model"]["model.down_layers.0.blocks.0.attn.relative_position_index"])   # buffers come from the online model
+    fresh = build_network(cfg, W.synth_state_dict(cfg, 3), device="cuda")
+    dio.load_model(ckp, fresh, "model_ema_beta_0.9990")
+    assert torch.equal(dict(fresh.model.named_parameters())["patch_embed.proj.weight"], ckp["model"][k0] * 0.5)
