@@ -144,7 +144,19 @@ def worker(args):
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         if use_pg:
-            dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+            # RCCL prints a version banner to the process's stdout when its first communicator comes up; the contract is ONE JSON
+            # line on rank 0's stdout, so file descriptor 1 points at stderr while the group initialises and runs its first collective
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend="nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+                dist.barrier()
+                torch.cuda.synchronize(dev)
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
     world_seen = dist.get_world_size() if use_pg else 1
 
     cfg = synth.CONFIGS[args.config]()
