@@ -300,3 +300,43 @@ def test_checkpoint_writer_layout_matches_reference(tmp_path):
     fresh = build_network(cfg, W.synth_state_dict(cfg, 3), device="cuda")
     dio.load_model(ckp, fresh, "model_ema_beta_0.9990")
     assert torch.equal(dict(fresh.model.named_parameters())["patch_embed.proj.weight"], ckp["model"][k0] * 0.5)
+
+
+def test_gelu_coefficients_in_the_kernel_are_the_fit_scripts():
+    """csrc/kernels_common.hip.h::gelu_f evaluates max(x,0) - |x| 2^h(min(|x|,6)) with a degree-6 h fitted by tools/fit_gelu.py:
+    the constants in the header are that script's output, and the fp32 evaluation stays within 3e-7 of an fp64 exact-erf GELU"""
+    import importlib.util
+    import re
+    root = os.path.join(os.path.dirname(__file__), "..")
+    spec_ = importlib.util.spec_from_file_location("fit_gelu", os.path.join(root, "tools", "fit_gelu.py"))
+    fg = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(fg)
+    c = fg.fit()
+    src = open(os.path.join(root, "diffusesg_amd", "csrc", "kernels_common.hip.h")).read()
+    body = src[src.index("__device__ __forceinline__ float gelu_f(float x) {"):]
+    body = body[:body.index("}")]
+    consts = [float(v) for v in re.findall(r"(-?\d\.\d+e[+-]\d+|-?\d\.\d{6,})f", body)]
+    assert len(consts) == 7, consts            # Horner order: c6, c5, c4, c3, c2, c1, c0
+    np.testing.assert_allclose(consts, c[::-1], rtol=2e-9)
+    from scipy.special import erfc
+    x = np.linspace(-12, 12, 400001).astype(np.float32)
+    ref = x.astype(np.float64) * 0.5 * erfc(-x.astype(np.float64) / np.sqrt(2))
+    assert np.abs(fg.gelu_f32(x, np.array(consts[::-1])) - ref).max() < 3e-7
+
+
+def test_ema_decay_schedule_restated_from_ema_pytorch():
+    """EMAHip.get_current_decay with the reference's arguments (update_every=1, update_after_step=0, inv_gamma=1, power=1):
+    0 on the first two updates' epochs <= 0, then 1 - 1/(1 + epoch) capped at beta (ema_pytorch is absent: parity unpinned)"""
+    from diffusesg_amd.train import EMAHip
+
+    class Net:   # the attributes EMAHip touches without a GPU
+        _dev = torch.device("cpu")
+        def named_parameters(self):
+            return iter([("w", torch.nn.Parameter(torch.ones(3)))])
+    e = EMAHip(Net(), beta=0.9)
+    seen = []
+    for step in range(1, 14):
+        e.step = step
+        seen.append(e.get_current_decay())
+    assert seen[0] == 0.0 and seen[1] == 0.5 and abs(seen[2] - 2.0 / 3.0) < 1e-12
+    assert seen[-1] == 0.9 and all(b >= a for a, b in zip(seen, seen[1:]))
