@@ -491,7 +491,7 @@ def gen_train_backward(DiffuseSG, NodeAdjPrecond, out):
             for k, p_ in model.named_parameters():
                 v_ = p_.detach().numpy().reshape(-1)
                 res[f"{name}_param_after/{k}"] = v_[::max(1, -(-v_.size // 256))].copy()
-        print(f"train backward {name}: loss {float(loss):.6f}, |grad| {float(total_norm):.5f} over {n_par} parameters ({len(names)} tensors), "
+        print(f"train backward {name}: loss {float(loss.detach()):.6f}, |grad| {float(total_norm):.5f} over {n_par} parameters ({len(names)} tensors), "
               f"coin {coin:.3f}, |dL/dF_adj| {float(raw['a'].grad.norm()):.4e}")
     np.savez_compressed(os.path.join(out, "train_backward.npz"), **res)
 
