@@ -1648,25 +1648,28 @@ int dsg_train_inputs(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const 
 
 int dsg_rainbow_loss(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *pred_adj, const float *pred_node,
                      const float *target_adj, const float *target_node, const uint8_t *flags, const float *loss_weight,
-                     float edge_loss_weight, float node_loss_weight, float iou_loss_weight, float *out_loss_adj, float *out_loss_node,
-                     void *stream) {
+                     float edge_loss_weight, float node_loss_weight, float iou_loss_weight, int32_t iou_loss_type, float *out_loss_adj,
+                     float *out_loss_node, void *stream) {
     if (B < 1 || N < 1 || c_adj < 1 || c_node < 1 || !pred_adj || !pred_node || !target_adj || !target_node || !flags || !out_loss_adj ||
-        !out_loss_node || (iou_loss_weight != 0.f && c_node < 4))
+        !out_loss_node || (iou_loss_weight != 0.f && c_node < 4) || iou_loss_type < DSG_IOU_IOU || iou_loss_type > DSG_IOU_CIOU)
         return DSG_ERR_INVALID;
     launch_rainbow_loss(CStatePtrs{pred_adj, pred_node}, CStatePtrs{target_adj, target_node}, flags, loss_weight, edge_loss_weight,
-                        node_loss_weight, iou_loss_weight, out_loss_adj, out_loss_node, Dims{B, N, c_adj, c_node}, (hipStream_t)stream);
+                        node_loss_weight, iou_loss_weight, iou_loss_type, out_loss_adj, out_loss_node, Dims{B, N, c_adj, c_node},
+                        (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? DSG_OK : DSG_ERR_HIP;
 }
 
 int dsg_rainbow_loss_backward(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *pred_adj, const float *pred_node,
                               const float *target_adj, const float *target_node, const uint8_t *flags, const float *loss_weight,
-                              float edge_loss_weight, float node_loss_weight, float iou_loss_weight, const float *sigmas,
-                              float *out_grad_adj, float *out_grad_node, float *out_grad_F_adj, float *out_grad_F_node, void *stream) {
+                              float edge_loss_weight, float node_loss_weight, float iou_loss_weight, int32_t iou_loss_type,
+                              const float *sigmas, float *out_grad_adj, float *out_grad_node, float *out_grad_F_adj, float *out_grad_F_node,
+                              void *stream) {
     if (B < 1 || N < 1 || c_adj < 1 || c_node < 1 || !pred_adj || !pred_node || !target_adj || !target_node || !flags || !out_grad_adj ||
-        !out_grad_node || (iou_loss_weight != 0.f && c_node < 4) || ((out_grad_F_adj || out_grad_F_node) && !sigmas))
+        !out_grad_node || (iou_loss_weight != 0.f && c_node < 4) || ((out_grad_F_adj || out_grad_F_node) && !sigmas) ||
+        iou_loss_type < DSG_IOU_IOU || iou_loss_type > DSG_IOU_CIOU)
         return DSG_ERR_INVALID;
     launch_rainbow_loss_backward(CStatePtrs{pred_adj, pred_node}, CStatePtrs{target_adj, target_node}, flags, loss_weight,
-                                 edge_loss_weight, node_loss_weight, iou_loss_weight, sigmas, StatePtrs{out_grad_adj, out_grad_node},
+                                 edge_loss_weight, node_loss_weight, iou_loss_weight, iou_loss_type, sigmas, StatePtrs{out_grad_adj, out_grad_node},
                                  StatePtrs{out_grad_F_adj, out_grad_F_node}, Dims{B, N, c_adj, c_node}, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? DSG_OK : DSG_ERR_HIP;
 }
@@ -2050,10 +2053,11 @@ int dsg_train_grads(dsg_handle h, int32_t B, const float *in_adj, const float *i
 
 int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const float *noisy_node, const uint8_t *flags, const float *sigmas,
                          const float *sc_adj, const float *sc_node, const float *target_adj, const float *target_node,
-                         const float *loss_weight, float edge_loss_weight, float node_loss_weight, float iou_loss_weight, float *out_D_adj,
-                         float *out_D_node, float *out_loss_adj, float *out_loss_node, int32_t n_params, const char *const *names,
-                         float *const *grad_params, void *stream) {
+                         const float *loss_weight, float edge_loss_weight, float node_loss_weight, float iou_loss_weight,
+                         int32_t iou_loss_type, float *out_D_adj, float *out_D_node, float *out_loss_adj, float *out_loss_node,
+                         int32_t n_params, const char *const *names, float *const *grad_params, void *stream) {
     if (!h || !h->ever_finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
+    if (iou_loss_type < DSG_IOU_IOU || iou_loss_type > DSG_IOU_CIOU) return fail(h, DSG_ERR_INVALID, "iou_loss_type %d", iou_loss_type);
     if (B < 1 || !noisy_adj || !noisy_node || !flags || !sigmas || !target_adj || !target_node || !out_D_adj || !out_D_node || !out_loss_adj ||
         !out_loss_node)
         return fail(h, DSG_ERR_INVALID, "null argument");
@@ -2069,11 +2073,12 @@ int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const 
         launch_precond_out(CStatePtrs{noisy_adj, noisy_node}, CStatePtrs{Fa, Fn}, sigmas, flags, StatePtrs{out_D_adj, out_D_node},
                            StatePtrs{nullptr, nullptr}, d, s);
         launch_rainbow_loss(CStatePtrs{out_D_adj, out_D_node}, CStatePtrs{target_adj, target_node}, flags, loss_weight, edge_loss_weight,
-                            node_loss_weight, iou_loss_weight, out_loss_adj, out_loss_node, d, s);
+                            node_loss_weight, iou_loss_weight, iou_loss_type, out_loss_adj, out_loss_node, d, s);
         float *tmp = nullptr;
         if (hipMalloc((void **)&tmp, sizeof(float) * (na + nn)) != hipSuccess) return DSG_ERR_HIP;
         launch_rainbow_loss_backward(CStatePtrs{out_D_adj, out_D_node}, CStatePtrs{target_adj, target_node}, flags, loss_weight,
-                                     edge_loss_weight, node_loss_weight, iou_loss_weight, sigmas, StatePtrs{tmp, tmp + na}, StatePtrs{dFa, dFn}, d, s);
+                                     edge_loss_weight, node_loss_weight, iou_loss_weight, iou_loss_type, sigmas, StatePtrs{tmp, tmp + na},
+                                     StatePtrs{dFa, dFn}, d, s);
         const hipError_t e = hipStreamSynchronize(s);
         (void)hipFree(tmp);
         return e == hipSuccess ? DSG_OK : DSG_ERR_HIP;

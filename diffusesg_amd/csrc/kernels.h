@@ -157,8 +157,9 @@ void launch_train_inputs(CStatePtrs clean, const float *rnd, CStatePtrs eps, uin
                          float *weights, StatePtrs noisy, Dims d, hipStream_t s);
 // NodeAdjRainbowLoss(reduction='none') + the trainer's bbox IoU term: per-sample losses [B] (rainbow_loss.py:37-101,
 // trainer_node_adj.py:130-159); one block per sample, fixed-order reduction
+// iou_type: 0 'iou', 1 'giou', 2 'giou_squared', 3 'diou', 4 'ciou' (trainer_node_adj.py:138-153; DSG_IOU_* of dsg.h)
 void launch_rainbow_loss(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w,
-                         float *loss_adj, float *loss_node, Dims d, hipStream_t s);
+                         int iou_type, float *loss_adj, float *loss_node, Dims d, hipStream_t s);
 // ---- training-time block (train_kernels.hip; correctness-first kernels, not on the sampling path) ----
 struct TrainBlockParams {   // the 15 parameter tensors of a SwinTransformerBlock, reference layouts ([out, in] linears)
     float *aff_w, *aff_b, *n1_w, *n1_b, *rpb, *qkv_w, *qkv_b, *proj_w, *proj_b, *n2_w, *n2_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
@@ -195,7 +196,7 @@ bool t_adam_step(int n, float *const *params, float *const *grads, float *const 
 bool t_ema_update(int n, float *const *ema, const float *const *params, const int64_t *numel, float decay, hipStream_t s);
 
 void launch_rainbow_loss_backward(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w,
-                                  float iou_w, const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d, hipStream_t s);
+                                  float iou_w, int iou_type, const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d, hipStream_t s);
 void launch_decode_bits(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,
                         int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d, hipStream_t s);
 

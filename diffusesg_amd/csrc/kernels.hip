@@ -1977,12 +1977,128 @@ void launch_train_inputs(CStatePtrs clean, const float *rnd, CStatePtrs eps, uin
                        weights, noisy, d);
 }
 
-// NodeAdjRainbowLoss.forward(reduction='none') (R/loss/rainbow_loss.py:37-101) and the bbox IoU term of the trainer
-// (R/runner/trainer/trainer_node_adj.py:130-159, type 'iou').  One 256-thread block per sample; every thread sums a fixed
-// strided subset in double, the block adds the 256 partials in a fixed tree: deterministic.
+// The bounding-box term of one node (R/runner/trainer/trainer_node_adj.py:130-153): both boxes go (x+1)/2 -> cxcywh -> xyxy -> clamp[0,1],
+// then by iou_loss_type
+//   0 'iou'          -(box_iou)^2                         torchvision.ops.box_iou: inter / (area_a + area_b - inter), overlap clamp(min=0)
+//   1 'giou'         generalized_box_iou_loss             1 - iou + (area_c - union) / (area_c + eps)
+//   2 'giou_squared' (that)^2
+//   3 'diou'         distance_box_iou_loss                1 - iou + centre distance^2 / (enclosing diagonal^2 + eps)
+//   4 'ciou'         complete_box_iou_loss                diou + alpha v, v = 4/pi^2 (atan(w/h) - atan(wg/hg))^2, alpha = v/(1 - iou + v + eps) (no grad)
+// (types 1-4: torchvision.ops' *_box_iou_loss with reduction='none', eps = 1e-7, iou = inter / (union + eps), intersection only where
+// both overlaps are open; restated from torchvision's published source -- torchvision itself is not installed here.)
+// Forward value in fp32, operation by operation; the gradient with respect to the four raw (cx, cy, w, h)-space channels follows
+// autograd: clamp passes it inside [0,1] inclusive, max/min to the selected argument (a tie splits it evenly), in double.
+struct BoxTerm { float loss; double g[4]; };
+__device__ BoxTerm box_iou_term(const float *pred4, const float *tgt4, int type, bool want_grad) {
+    float bx[2][4], raw[4];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const float *src = q ? tgt4 : pred4;
+        const float cx = __fdiv_rn(FADD(src[0], 1.0f), 2.0f), cy = __fdiv_rn(FADD(src[1], 1.0f), 2.0f);
+        const float bw = __fdiv_rn(FADD(src[2], 1.0f), 2.0f), bh = __fdiv_rn(FADD(src[3], 1.0f), 2.0f);
+        const float v[4] = {FSUB(cx, FMUL(0.5f, bw)), FSUB(cy, FMUL(0.5f, bh)), FADD(cx, FMUL(0.5f, bw)), FADD(cy, FMUL(0.5f, bh))};
+#pragma unroll
+        for (int t = 0; t < 4; t++) { bx[q][t] = fminf(fmaxf(v[t], 0.0f), 1.0f); if (!q) raw[t] = v[t]; }
+    }
+    const float *p = bx[0], *g = bx[1];
+    BoxTerm out;
+    out.g[0] = out.g[1] = out.g[2] = out.g[3] = 0.0;
+    double gc[4] = {0.0, 0.0, 0.0, 0.0};   // d loss / d clamped corner of the prediction
+    const float pw = FSUB(p[2], p[0]), ph = FSUB(p[3], p[1]), gw = FSUB(g[2], g[0]), gh = FSUB(g[3], g[1]);
+    const float a0 = FMUL(pw, ph), a1 = FMUL(gw, gh);
+    const float dwf = FSUB(fminf(p[2], g[2]), fmaxf(p[0], g[0])), dhf = FSUB(fminf(p[3], g[3]), fmaxf(p[1], g[1]));
+    // selection weights of max / min (1 selected, 0.5 tie, 0 not): lo = the prediction's corner is the larger lower corner, ...
+    auto sel_gt = [](float a, float b) { return a > b ? 1.0 : (a == b ? 0.5 : 0.0); };
+    if (type == 0) {
+        const float iw = fmaxf(dwf, 0.0f), ih = fmaxf(dhf, 0.0f);
+        const float inter = FMUL(iw, ih), iou = __fdiv_rn(inter, FSUB(FADD(a0, a1), inter));
+        out.loss = -FMUL(iou, iou);
+        if (want_grad) {
+            const double dw = dwf, dh = dhf, I = (double)iw * ih, U = (double)a0 + a1 - I, io = I / U;
+            const double g_iou = -2.0 * io, g_I = g_iou * (U + I) / (U * U), g_A = g_iou * (-I) / (U * U);
+            gc[0] = g_I * ((dw >= 0 && p[0] > g[0]) ? -(double)ih : 0.0) + g_A * (-(double)ph);
+            gc[1] = g_I * ((dh >= 0 && p[1] > g[1]) ? -(double)iw : 0.0) + g_A * (-(double)pw);
+            gc[2] = g_I * ((dw >= 0 && p[2] < g[2]) ? (double)ih : 0.0) + g_A * (double)ph;
+            gc[3] = g_I * ((dh >= 0 && p[3] < g[3]) ? (double)iw : 0.0) + g_A * (double)pw;
+        }
+    } else {
+        const float eps = 1e-7f;
+        const bool open = dhf > 0.0f && dwf > 0.0f;
+        const float inter = open ? FMUL(dwf, dhf) : 0.0f;
+        const float uni = FSUB(FADD(a0, a1), inter), iou = __fdiv_rn(inter, FADD(uni, eps));
+        const float cw = FSUB(fmaxf(p[2], g[2]), fminf(p[0], g[0])), ch = FSUB(fmaxf(p[3], g[3]), fminf(p[1], g[1]));
+        // d inter, d area_p, d union, d iou per clamped corner
+        double dI[4] = {0, 0, 0, 0};
+        if (open) {
+            dI[0] = -sel_gt(p[0], g[0]) * (double)dhf; dI[1] = -sel_gt(p[1], g[1]) * (double)dwf;
+            dI[2] = sel_gt(g[2], p[2]) * (double)dhf;  dI[3] = sel_gt(g[3], p[3]) * (double)dwf;
+        }
+        const double dA[4] = {-(double)ph, -(double)pw, (double)ph, (double)pw};
+        const double Ue = (double)uni + (double)eps;
+        double dU[4], dIoU[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) { dU[t] = dA[t] - dI[t]; dIoU[t] = (dI[t] * Ue - (double)inter * dU[t]) / (Ue * Ue); }
+        // enclosing box: d cw / d corner, d ch / d corner
+        const double dcw[4] = {-sel_gt(g[0], p[0]), 0.0, sel_gt(p[2], g[2]), 0.0};
+        const double dch[4] = {0.0, -sel_gt(g[1], p[1]), 0.0, sel_gt(p[3], g[3])};
+        if (type == 1 || type == 2) {
+            const float area_c = FMUL(cw, ch);
+            const float miou = FSUB(iou, __fdiv_rn(FSUB(area_c, uni), FADD(area_c, eps)));
+            const float l = FSUB(1.0f, miou);
+            out.loss = type == 2 ? FMUL(l, l) : l;
+            if (want_grad) {
+                const double Ace = (double)area_c + (double)eps, scale = type == 2 ? 2.0 * (double)l : 1.0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const double dAc = dcw[t] * (double)ch + dch[t] * (double)cw;
+                    const double dfrac = ((dAc - dU[t]) * Ace - ((double)area_c - (double)uni) * dAc) / (Ace * Ace);
+                    gc[t] = scale * (-dIoU[t] + dfrac);
+                }
+            }
+        } else {
+            const float diag2 = FADD(FADD(FMUL(cw, cw), FMUL(ch, ch)), eps);
+            const float xp = __fdiv_rn(FADD(p[2], p[0]), 2.0f), yp = __fdiv_rn(FADD(p[3], p[1]), 2.0f);
+            const float xg = __fdiv_rn(FADD(g[0], g[2]), 2.0f), yg = __fdiv_rn(FADD(g[1], g[3]), 2.0f);
+            const float dx = FSUB(xp, xg), dy = FSUB(yp, yg);
+            const float cd2 = FADD(FMUL(dx, dx), FMUL(dy, dy));
+            float l = FADD(FSUB(1.0f, iou), __fdiv_rn(cd2, diag2));
+            float v = 0.f, alpha = 0.f, dat = 0.f;
+            if (type == 4) {
+                dat = FSUB(atanf(__fdiv_rn(pw, ph)), atanf(__fdiv_rn(gw, gh)));
+                v = FMUL(__fdiv_rn(4.0f, FMUL(3.14159265358979323846f, 3.14159265358979323846f)), FMUL(dat, dat));
+                alpha = __fdiv_rn(v, FADD(FADD(FSUB(1.0f, iou), v), eps));
+                l = FADD(l, FMUL(alpha, v));
+            }
+            out.loss = l;
+            if (want_grad) {
+                const double D2 = diag2;
+                const double dcd2[4] = {(double)dx, (double)dy, (double)dx, (double)dy};
+                const double kv = type == 4 ? (double)alpha * (8.0 / (M_PI * M_PI)) * (double)dat / ((double)ph * ph + (double)pw * pw) : 0.0;
+                const double dv[4] = {-kv * (double)ph, kv * (double)pw, kv * (double)ph, -kv * (double)pw};   // dv/dw = k h, dv/dh = -k w
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const double dD2 = 2.0 * (double)cw * dcw[t] + 2.0 * (double)ch * dch[t];
+                    gc[t] = -dIoU[t] + (dcd2[t] * D2 - (double)cd2 * dD2) / (D2 * D2) + dv[t];
+                }
+            }
+        }
+    }
+    if (want_grad) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) if (!(raw[t] >= 0.0f && raw[t] <= 1.0f)) gc[t] = 0.0;   // clamp(min=0, max=1)
+        // corners = (cx - w/2, cy - h/2, cx + w/2, cy + h/2), (cx, cy, w, h) = (x + 1)/2
+        out.g[0] = 0.5 * (gc[0] + gc[2]); out.g[1] = 0.5 * (gc[1] + gc[3]);
+        out.g[2] = 0.25 * (gc[2] - gc[0]); out.g[3] = 0.25 * (gc[3] - gc[1]);
+    }
+    return out;
+}
+
+// NodeAdjRainbowLoss.forward(reduction='none') (R/loss/rainbow_loss.py:37-101) and the bbox term of the trainer
+// (R/runner/trainer/trainer_node_adj.py:130-159, every iou_loss_type: box_iou_term above).  One 256-thread block per sample; every
+// thread sums a fixed strided subset in double, the block adds the 256 partials in a fixed tree: deterministic.
 __global__ __launch_bounds__(256) void rainbow_loss_kernel(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w,
-                                                           float edge_w, float node_w, float iou_w, float *loss_adj, float *loss_node,
-                                                           Dims d) {
+                                                           float edge_w, float node_w, float iou_w, int iou_type, float *loss_adj,
+                                                           float *loss_node, Dims d) {
     __shared__ double red[3][256];
     __shared__ int cnt[2];
     const int b = blockIdx.x, tid = threadIdx.x, N = d.N, Ca = d.Ca, Cn = d.Cn;
@@ -2008,22 +2124,8 @@ __global__ __launch_bounds__(256) void rainbow_loss_kernel(CStatePtrs pred, CSta
     if (iou_w != 0.f)
         for (int i = tid; i < N; i += 256)
             if (f[i]) {
-                float bx[2][4];
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const float *src = (q ? tgt.node : pred.node) + ((size_t)b * N + i) * Cn + (Cn - 4);
-                    const float cx = __fdiv_rn(FADD(src[0], 1.0f), 2.0f), cy = __fdiv_rn(FADD(src[1], 1.0f), 2.0f);
-                    const float bw = __fdiv_rn(FADD(src[2], 1.0f), 2.0f), bh = __fdiv_rn(FADD(src[3], 1.0f), 2.0f);
-                    const float v[4] = {FSUB(cx, FMUL(0.5f, bw)), FSUB(cy, FMUL(0.5f, bh)), FADD(cx, FMUL(0.5f, bw)), FADD(cy, FMUL(0.5f, bh))};
-#pragma unroll
-                    for (int t = 0; t < 4; t++) bx[q][t] = fminf(fmaxf(v[t], 0.0f), 1.0f);
-                }
-                const float a0 = FMUL(FSUB(bx[0][2], bx[0][0]), FSUB(bx[0][3], bx[0][1]));
-                const float a1 = FMUL(FSUB(bx[1][2], bx[1][0]), FSUB(bx[1][3], bx[1][1]));
-                const float iw = fmaxf(FSUB(fminf(bx[0][2], bx[1][2]), fmaxf(bx[0][0], bx[1][0])), 0.0f);
-                const float ih = fmaxf(FSUB(fminf(bx[0][3], bx[1][3]), fmaxf(bx[0][1], bx[1][1])), 0.0f);
-                const float inter = FMUL(iw, ih), iou = __fdiv_rn(inter, FSUB(FADD(a0, a1), inter));
-                si += (double)(-FMUL(iou, iou));
+                const size_t o = ((size_t)b * N + i) * Cn + (Cn - 4);
+                si += (double)box_iou_term(pred.node + o, tgt.node + o, iou_type, false).loss;
             }
     red[0][tid] = sa; red[1][tid] = sn; red[2][tid] = si;
     __syncthreads();
@@ -2038,18 +2140,18 @@ __global__ __launch_bounds__(256) void rainbow_loss_kernel(CStatePtrs pred, CSta
     }
 }
 void launch_rainbow_loss(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w,
-                         float *loss_adj, float *loss_node, Dims d, hipStream_t s) {
-    hipLaunchKernelGGL(rainbow_loss_kernel, dim3(d.B), dim3(256), 0, s, pred, tgt, flags, w, edge_w, node_w, iou_w, loss_adj, loss_node, d);
+                         int iou_type, float *loss_adj, float *loss_node, Dims d, hipStream_t s) {
+    hipLaunchKernelGGL(rainbow_loss_kernel, dim3(d.B), dim3(256), 0, s, pred, tgt, flags, w, edge_w, node_w, iou_w, iou_type, loss_adj,
+                       loss_node, d);
 }
 
 // Backward of  loss = mean_b(loss_adj) + mean_b(loss_node)  (trainer_node_adj.py:163) with respect to the preconditioned
 // outputs D, and with respect to the raw network outputs F:  D = mask(c_skip x + c_out F)  (precond.py:101-104)  =>
-// dL/dF = c_out(sigma_b) dL/dD.  The IoU term follows autograd through (x+1)/2 -> cxcywh->xyxy -> clamp[0,1] -> box_iou:
-// clamp passes the gradient inside [0,1] inclusive, max/min to the selected argument, the overlap's clamp(min=0) where >= 0.
+// dL/dF = c_out(sigma_b) dL/dD.  The bbox term follows autograd (box_iou_term).
 // One block per sample; the first stage of the training backward, checked against the reference's autograd.
 __global__ __launch_bounds__(256) void rainbow_loss_backward_kernel(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w,
-                                                                    float edge_w, float node_w, float iou_w, const float *sigmas,
-                                                                    StatePtrs grad, StatePtrs gradF, Dims d) {
+                                                                    float edge_w, float node_w, float iou_w, int iou_type,
+                                                                    const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d) {
     __shared__ int cnt[2];
     const int b = blockIdx.x, tid = threadIdx.x, N = d.N, Ca = d.Ca, Cn = d.Cn;
     const uint8_t *f = flags + (size_t)b * N;
@@ -2077,31 +2179,9 @@ __global__ __launch_bounds__(256) void rainbow_loss_backward_kernel(CStatePtrs p
         double gb[4] = {0.0, 0.0, 0.0, 0.0};
         const size_t row = ((size_t)b * N + i) * Cn;
         if (f[i] && iou_w != 0.f) {
-            float bx[2][4], raw[4];
+            const BoxTerm bt = box_iou_term(pred.node + row + (Cn - 4), tgt.node + row + (Cn - 4), iou_type, true);
 #pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const float *src = (q ? tgt.node : pred.node) + row + (Cn - 4);
-                const float cx = __fdiv_rn(FADD(src[0], 1.0f), 2.0f), cy = __fdiv_rn(FADD(src[1], 1.0f), 2.0f);
-                const float bw = __fdiv_rn(FADD(src[2], 1.0f), 2.0f), bh = __fdiv_rn(FADD(src[3], 1.0f), 2.0f);
-                const float v[4] = {FSUB(cx, FMUL(0.5f, bw)), FSUB(cy, FMUL(0.5f, bh)), FADD(cx, FMUL(0.5f, bw)), FADD(cy, FMUL(0.5f, bh))};
-#pragma unroll
-                for (int t = 0; t < 4; t++) { bx[q][t] = fminf(fmaxf(v[t], 0.0f), 1.0f); if (!q) raw[t] = v[t]; }
-            }
-            const double aw = FSUB(bx[0][2], bx[0][0]), ah = FSUB(bx[0][3], bx[0][1]);
-            const double a0 = aw * ah, a1 = (double)FSUB(bx[1][2], bx[1][0]) * (double)FSUB(bx[1][3], bx[1][1]);
-            const double dw = FSUB(fminf(bx[0][2], bx[1][2]), fmaxf(bx[0][0], bx[1][0])), dh = FSUB(fminf(bx[0][3], bx[1][3]), fmaxf(bx[0][1], bx[1][1]));
-            const double iw = dw > 0 ? dw : 0, ih = dh > 0 ? dh : 0;
-            const double inter = iw * ih, uni = a0 + a1 - inter, iou = inter / uni;
-            const double g_iou = ki * (-2.0 * iou), g_inter = g_iou * (uni + inter) / (uni * uni), g_area = g_iou * (-inter) / (uni * uni);
-            double gc[4];
-            gc[0] = g_inter * ((dw >= 0 && bx[0][0] > bx[1][0]) ? -ih : 0.0) + g_area * (-ah);
-            gc[1] = g_inter * ((dh >= 0 && bx[0][1] > bx[1][1]) ? -iw : 0.0) + g_area * (-aw);
-            gc[2] = g_inter * ((dw >= 0 && bx[0][2] < bx[1][2]) ? ih : 0.0) + g_area * ah;
-            gc[3] = g_inter * ((dh >= 0 && bx[0][3] < bx[1][3]) ? iw : 0.0) + g_area * aw;
-#pragma unroll
-            for (int t = 0; t < 4; t++) if (!(raw[t] >= 0.0f && raw[t] <= 1.0f)) gc[t] = 0.0;
-            gb[0] = 0.5 * (gc[0] + gc[2]); gb[1] = 0.5 * (gc[1] + gc[3]);
-            gb[2] = 0.25 * (gc[2] - gc[0]); gb[3] = 0.25 * (gc[3] - gc[1]);
+            for (int t = 0; t < 4; t++) gb[t] = ki * bt.g[t];
         }
         for (int c = 0; c < Cn; c++) {
             double g = f[i] ? kn * (double)FSUB(pred.node[row + c], tgt.node[row + c]) : 0.0;
@@ -2112,9 +2192,9 @@ __global__ __launch_bounds__(256) void rainbow_loss_backward_kernel(CStatePtrs p
     }
 }
 void launch_rainbow_loss_backward(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w,
-                                  float iou_w, const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d, hipStream_t s) {
-    hipLaunchKernelGGL(rainbow_loss_backward_kernel, dim3(d.B), dim3(256), 0, s, pred, tgt, flags, w, edge_w, node_w, iou_w, sigmas, grad,
-                       gradF, d);
+                                  float iou_w, int iou_type, const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d, hipStream_t s) {
+    hipLaunchKernelGGL(rainbow_loss_backward_kernel, dim3(d.B), dim3(256), 0, s, pred, tgt, flags, w, edge_w, node_w, iou_w, iou_type, sigmas,
+                       grad, gradF, d);
 }
 
 // Post-decode of 'bits' samples (sampler_node_adj.py:222-285, attribute_code.py:319-328):

@@ -64,7 +64,9 @@ def all_reduce_mean(grads, bucket_bytes: int = 256 << 20):
     all-reduces beat one per tensor -- summed with one `all_reduce` each (RCCL with backend "nccl"; gloo in the CPU test) and
     divided by the world size, in place.  Identity when not distributed."""
     tensors = list(grads.values()) if isinstance(grads, dict) else list(grads)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not tensors:
+    if not (dist.is_available() and dist.is_initialized()) or not tensors:
+        return grads
+    if dist.get_world_size() == 1 and not os.environ.get("DSG_FORCE_COLLECTIVE"):   # (the world-size-1 RCCL test sets it)
         return grads
     world = dist.get_world_size()
     bucket, size = [], 0

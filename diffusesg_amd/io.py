@@ -145,17 +145,37 @@ def unpack_decoded(packed: torch.Tensor, n: int, with_bbox: bool):
     return q_adj, q_node, flags, bbox
 
 
-def save_samples_npz(path: str, *, samples_node_flags, samples_a, samples_x, raw_a, raw_x, samples_x_bbox=None,
-                     gt_node_flags=None, gt_a=None, gt_x=None, gt_x_bbox=None, gt_image_ids=None):
-    """Write `final_samples_array_before_eval.npz` with the reference's keys (sampler_node_adj.py:395-407)."""
-    def npy(t):
-        if t is None:
-            return None
-        return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
-    np.savez_compressed(path,
-                        samples_node_flags=npy(samples_node_flags).astype(bool),
-                        samples_a=npy(samples_a).astype(np.float32), samples_x=npy(samples_x).astype(np.float32),
-                        raw_a=npy(raw_a), raw_x=npy(raw_x),
-                        gt_node_flags=None if gt_node_flags is None else npy(gt_node_flags).astype(bool),
-                        gt_a=npy(gt_a), gt_x=npy(gt_x), samples_x_bbox=npy(samples_x_bbox), gt_x_bbox=npy(gt_x_bbox),
-                        gt_image_ids=npy(gt_image_ids))
+def save_samples_npz(path: str, *, samples_node_flags, samples_a, samples_x, raw_a, raw_x, gt_node_flags, gt_a, gt_x,
+                     samples_x_bbox=None, gt_x_bbox=None, gt_image_ids=None):
+    """Write `final_samples_array_before_eval.npz` with the reference's keys and dtypes (sampler_node_adj.py:395-407): flags bool,
+    quantised graphs float32 (`bin2dec` of float tensors), raw samples / bbox float32, image ids int64.  The consumer
+    (R/helper/eval_sg_samples.py:248-253) reads samples_x, samples_a, gt_x, gt_a, samples_x_bbox, gt_x_bbox and gt_node_flags with
+    a plain `np.load` (no pickle), so every entry is a typed array: the ground-truth entries are mandatory (the reference always
+    has them: they are the data loader's batch, decoded like the samples), and where the reference would store a Python `None`
+    (bbox arrays of a run without bbox channels; `np.load` cannot read that object array back without pickle) a typed
+    zero-width array [B, N, 0] is written instead.  Sample and ground-truth bbox arrays come together or not at all."""
+    def npy(t, dtype):
+        a = t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+        return np.ascontiguousarray(a.astype(dtype))
+    for name, v in (("gt_node_flags", gt_node_flags), ("gt_a", gt_a), ("gt_x", gt_x)):
+        if v is None:
+            raise ValueError(f"save_samples_npz: {name} is required (the evaluator reads it without pickle)")
+    if (samples_x_bbox is None) != (gt_x_bbox is None):
+        raise ValueError("save_samples_npz: samples_x_bbox and gt_x_bbox come together")
+    flags = npy(samples_node_flags, bool)
+    B, n = flags.shape[:2]
+    empty_bbox = np.zeros((B, n, 0), np.float32)
+    arrays = dict(samples_node_flags=flags, samples_a=npy(samples_a, np.float32), samples_x=npy(samples_x, np.float32),
+                  raw_a=npy(raw_a, np.float32), raw_x=npy(raw_x, np.float32),
+                  gt_node_flags=npy(gt_node_flags, bool), gt_a=npy(gt_a, np.float32), gt_x=npy(gt_x, np.float32),
+                  samples_x_bbox=empty_bbox if samples_x_bbox is None else npy(samples_x_bbox, np.float32),
+                  gt_x_bbox=empty_bbox if gt_x_bbox is None else npy(gt_x_bbox, np.float32),
+                  gt_image_ids=np.zeros((0,), np.int64) if gt_image_ids is None else npy(gt_image_ids, np.int64))
+    for k in ("samples_a", "gt_a"):
+        if arrays[k].shape != (B, n, n):
+            raise ValueError(f"save_samples_npz: {k} must be [B, N, N], got {arrays[k].shape}")
+    for k in ("samples_x", "gt_x", "gt_node_flags"):
+        if arrays[k].shape != (B, n):
+            raise ValueError(f"save_samples_npz: {k} must be [B, N], got {arrays[k].shape}")
+    np.savez_compressed(path, **arrays)
+    return path

@@ -86,20 +86,30 @@ def load() -> C.CDLL:
     L.dsg_profile_clock_ghz.restype = C.c_double
     L.dsg_debug_gemm.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     L.dsg_train_inputs.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp]
-    L.dsg_rainbow_loss.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, vp, vp, vp]
+    L.dsg_rainbow_loss.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, i32, vp, vp, vp]
     L.dsg_block_train.argtypes = [vp, C.c_char_p, i32, vp, vp, vp, vp, vp, vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), vp]
     L.dsg_train_grads.argtypes = [vp, i32] + [vp] * 10 + [i32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), vp]
-    L.dsg_train_step_grads.argtypes = [vp, i32] + [vp] * 9 + [C.c_float] * 3 + [vp] * 4 + [i32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), vp]
+    L.dsg_train_step_grads.argtypes = [vp, i32] + [vp] * 9 + [C.c_float] * 3 + [i32] + [vp] * 4 + [i32, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), vp]
     L.dsg_adam_step.argtypes = [i32] + [C.POINTER(C.c_void_p)] * 4 + [C.POINTER(C.c_int64), i32] + [C.c_float] * 6 + [C.POINTER(C.c_float), vp]
     L.dsg_ema_update.argtypes = [i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_float, vp]
     L.dsg_noise_embed.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.dsg_affine_width.argtypes = [vp]
     L.dsg_affine_width.restype = i32
-    L.dsg_rainbow_loss_backward.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp]
+    L.dsg_rainbow_loss_backward.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp, vp]
     L.dsg_profile_forward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     L.dsg_decode_bits.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
     _lib = L
     return L
+
+
+# iou_loss_type of the trainer's bounding-box term (trainer_node_adj.py:138-153) -> DSG_IOU_* (include/dsg.h)
+IOU_LOSS_TYPES = {"iou": 0, "giou": 1, "giou_squared": 2, "diou": 3, "ciou": 4}
+
+
+def iou_loss_type_code(name: str) -> int:
+    if name not in IOU_LOSS_TYPES:
+        raise NotImplementedError(name)   # the reference's `else: raise NotImplementedError` (trainer_node_adj.py:153-154)
+    return IOU_LOSS_TYPES[name]
 
 
 def make_config(cfg) -> DsgConfig:

@@ -85,6 +85,53 @@ def gt_case(cfg: S.ModelConfig, B: int, valid, seed: int = 3):
     return gt_adj, gt_node
 
 
+INTER_ROWS = 12
+
+
+def inter_rows(n_rows: int) -> np.ndarray:
+    """The token rows of a [B*T, C] tap kept by the per-module fixtures of the full-size nets (fwd_vg / fwd_coco 'rows/<tap>'):
+    a fixed pseudo-random, sorted, duplicate-free selection covering both samples."""
+    idx = (np.arange(1, 4 * INTER_ROWS + 1, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(n_rows)
+    return np.sort(np.unique(idx.astype(np.int64))[:INTER_ROWS]) if n_rows > INTER_ROWS else np.arange(n_rows)
+
+
+def tap_shapes(cfg: S.ModelConfig) -> dict:
+    """name -> (tokens per sample, channels) of every named intermediate activation (dsg_debug_tap / the oracle's taps)."""
+    n, E, L = cfg.max_node_num, cfg.embed_dim, len(cfg.depths)
+    out = {"patch_embed": (n * n, E), "read_out": (n * n, E)}
+    for l in range(L):
+        T, C = (n >> l) ** 2, E << l
+        for j in range(cfg.depths[l]):
+            out[f"down{l}.block{j}"] = (T, C)
+        out[f"down{l}"] = (T // 4, 2 * C) if l < L - 1 else (T, C)
+    for i in range(L):
+        l = L - 1 - i
+        T, C = (n >> l) ** 2, E << l
+        if i > 0:
+            out[f"up{i}.upsample"] = (T, C)
+        for j in range(cfg.depths[l]):
+            out[f"up{i}.block{j}"] = (T, C)
+    return out
+
+
+# short trajectories of the full-size nets through the reference's sampler (tests/golden/traj_big.npz):
+# tag -> (config, T, solver, S_churn, valid nodes per sample, seed, stream tag, explicit coins or None = drawn from the stream)
+BIG_TRAJ = {
+    "vg_heun6": ("vg", 6, "heun", 40.0, [30, 30], 17, "vg/smp3", [1, 0, 1, 1, 0, 0, 1, 0, 1, 1, 0]),
+    "vg_euler6": ("vg", 6, "euler", 0.0, [30, 11], 41, "vg/euler6", None),
+    "coco_heun6": ("coco", 6, "heun", 40.0, [20, 40], 53, "coco/smp6", None),
+}
+
+
+def big_traj_case(tag: str):
+    """cfg, T, solver, S_churn, flags, init_adj, init_node, noise_adj, noise_node, coins (uint8) of a BIG_TRAJ case"""
+    name, T, solver, churn, valid, seed, stream, coins = BIG_TRAJ[tag]
+    cfg = CONFIGS[name]()
+    flags, ia, inn, na, nn, cv = sampler_case(cfg, T, len(valid), valid, seed, stream, solver)
+    c = np.asarray(coins, np.uint8) if coins is not None else (cv < 0.5).astype(np.uint8)
+    return cfg, T, solver, churn, flags, ia, inn, na, nn, c
+
+
 # (name in sampler.npz, T, solver, S_churn)
 SAMPLER_RUNS = (("t8_heun", 8, "heun", 40.0), ("t50_heun", 50, "heun", 40.0), ("t8_euler", 8, "euler", 0.0))
 SAMPLER_VALID = [8, 5, 3, 8]
@@ -128,6 +175,34 @@ def train_case(name: str = "tiny", B: int = 4, seed: int = 7):
     eps_node = W.normal(seed, f"trn/{name}/eps_node", (B, n, cfg.c_node))
     coin = float(W.coins(seed, f"trn/{name}", 1)[0])
     return cfg, flags, clean_adj, clean_node, rnd, eps_adj, eps_node, coin
+
+
+IOU_TYPES = ("iou", "giou", "giou_squared", "diou", "ciou")   # trainer_node_adj.py:138-153
+
+
+def iou_case(seed: int = 23):
+    """Inputs of the bounding-box loss fixtures (tests/golden/iou_losses.npz): the tiny config's shapes (N = 8, C_adj = 6, C_node = 12),
+    B = 4 with ragged flags; targets = clean +-1 graphs with bbox channels in (-0.8, 0.8); predictions = targets + noise, with the
+    bbox channels of the prediction spread wide enough that some corners leave [0, 1] (the clamp's zero-gradient branch), some boxes do
+    not overlap their target (the masked intersection) and some enclose / are enclosed by it; per-sample loss weights and sigmas."""
+    cfg = CONFIGS["tiny"]()
+    n, B = cfg.max_node_num, 4
+    flags = W.synth_flags(B, n, TRAIN_VALID)
+    tgt_adj = W.mask_adj(np.sign(W.normal(seed, "iou/adj", (B, cfg.c_adj, n, n))).astype(np.float32), flags)
+    node = np.sign(W.normal(seed, "iou/node", (B, n, cfg.c_node))).astype(np.float32)
+    node[..., -4:] = (2.0 * W.uniform01(seed, "iou/bbox", B * n * 4) - 1.0).astype(np.float32).reshape(B, n, 4) * 0.8
+    tgt_node = W.mask_node(node, flags)
+    pred_adj = W.mask_adj(tgt_adj + 0.4 * W.normal(seed, "iou/eps_adj", (B, cfg.c_adj, n, n)), flags)
+    eps = W.normal(seed, "iou/eps_node", (B, n, cfg.c_node))
+    pred = tgt_node + 0.4 * eps
+    pred[..., -4:] = tgt_node[..., -4:] + np.float32(0.7) * eps[..., -4:]
+    pred[..., -2:] = np.maximum(pred[..., -2:], np.float32(-0.9))        # width / height stay positive: (w + 1)/2 >= 0.05
+    pred[..., -4:-2] = np.clip(pred[..., -4:-2], np.float32(-0.85), np.float32(0.85))   # centres inside the image: no box collapses to zero
+    # width or height under the clamp (complete_box_iou_loss divides w by h: a collapsed box is NaN in torchvision itself)
+    pred_node = W.mask_node(pred.astype(np.float32), flags)
+    weights = (0.5 + 2.0 * W.uniform01(seed, "iou/w", B)).astype(np.float32)
+    sigmas = np.exp(1.2 * W.normal(seed, "iou/sig", (B,)) - 1.2).astype(np.float32)
+    return cfg, flags, pred_adj, pred_node, tgt_adj, tgt_node, weights, sigmas
 
 
 def block_case(cfg, prefix: str, B: int, seed: int = 11):

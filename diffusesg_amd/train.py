@@ -5,9 +5,9 @@
   eval_loss_step                  <-> node_adj_move_forward_one_epoch(mode='test') body     (R/runner/trainer/trainer_node_adj.py:96-167)
 
 Same constructor kwargs, call signatures and return conventions as the reference classes; the arithmetic runs in libdsg.so
-(`dsg_train_inputs`, `dsg_rainbow_loss`, and the preconditioned network through `NodeAdjPrecondHip`).  Of the backward only the
-first stage exists (`NodeAdjRainbowLossHip.backward` -> `dsg_rainbow_loss_backward`: loss -> preconditioned outputs -> raw network
-outputs, checked against the reference's autograd).  Round 2 (late): the whole training iteration exists in correctness-first form --
+(`dsg_train_inputs`, `dsg_rainbow_loss`, and the preconditioned network through `NodeAdjPrecondHip`).  The backward:
+`NodeAdjRainbowLossHip.backward` -> `dsg_rainbow_loss_backward` (loss -> preconditioned outputs -> raw network outputs, every
+`iou_loss_type` of the trainer) and the whole training iteration --
 `train_step_grads` (network in training form, loss, backward to every parameter: `dsg_train_step_grads`), `AdamHip` (clip + Adam:
 `dsg_adam_step`), `EMAHip` (`dsg_ema_update`; parity unpinned), `train_one_iteration`; gradients all-reduce through
 `diffusesg_amd.dist.all_reduce_mean`.  The kernels are plain fp32 (csrc/train_kernels.hip), not the sampling path's MFMA kernels.
@@ -92,10 +92,11 @@ class NodeAdjRainbowLossHip(torch.nn.Module):
     @torch.no_grad()
     def forward(self, net_pred_a, net_pred_x, net_target_a, net_target_x, net_cond, adjs_perturbed=None, adjs_gt=None,
                 x_perturbed=None, x_gt=None, node_flags=None, loss_weight=None, cond_val=None, flag_matching=False,
-                reduction="mean", iou_loss_weight=0.0):
+                reduction="mean", iou_loss_weight=0.0, iou_loss_type="iou"):
         """rainbow_loss.py:24-35.  reduction 'none'/None -> per-sample (loss_adj [B], loss_node [B]); 'mean' follows the
         reference's expression literally (:84-86: a [B] tensor, both terms scaled by edge_loss_weight).
-        `iou_loss_weight` (not a reference kwarg) adds the trainer's bbox term on the device (trainer_node_adj.py:130-159)."""
+        `iou_loss_weight` / `iou_loss_type` (not reference kwargs of this class: the trainer's own arguments) add the trainer's bbox
+        term on the device (trainer_node_adj.py:130-159; 'iou', 'giou', 'giou_squared', 'diou', 'ciou')."""
         if flag_matching:
             raise ValueError("Graph matching is not supported for node-adj loss!")
         if node_flags.dim() != 2:
@@ -118,7 +119,8 @@ class NodeAdjRainbowLossHip(torch.nn.Module):
         ew, nw = (self.edge_loss_weight, self.node_loss_weight) if none else (1.0, 1.0)
         st = torch.cuda.current_stream(dev).cuda_stream
         rc = L.dsg_rainbow_loss(B, n, pa.shape[1], px.shape[2], _p(pa), _p(px), _p(ta), _p(tx), _p(fl), _p(w), float(ew), float(nw),
-                                float(iou_loss_weight if none else 0.0), _p(la), _p(ln), C.c_void_p(st))
+                                float(iou_loss_weight if none else 0.0), _lib.iou_loss_type_code(iou_loss_type), _p(la), _p(ln),
+                                C.c_void_p(st))
         if rc != 0:
             raise _lib.DsgError(f"dsg_rainbow_loss: status {rc}")
         if none:
@@ -131,11 +133,11 @@ class NodeAdjRainbowLossHip(torch.nn.Module):
 
     @torch.no_grad()
     def backward(self, net_pred_a, net_pred_x, net_target_a, net_target_x, node_flags, loss_weight=None, sigmas=None,
-                 iou_loss_weight=0.0):
+                 iou_loss_weight=0.0, iou_loss_type="iou"):
         """First stage of `loss.backward()` of a training step (trainer_node_adj.py:163-170), loss = loss_adj.mean() + loss_node.mean()
         with reduction='none' terms: -> (dL/d net_pred_a, dL/d net_pred_x, dL/dF_a | None, dL/dF_x | None); the last two (with `sigmas`)
-        are the gradients at the raw network outputs, c_out(sigma) * the first two (precond.py:101-104).  The network's own backward is
-        not built."""
+        are the gradients at the raw network outputs, c_out(sigma) * the first two (precond.py:101-104).  (`train_step_grads` chains
+        this with the network's own backward.)"""
         if node_flags.dim() != 2:
             raise NotImplementedError("node-only ablation ([B,N,N] node_flags) is out of scope")
         L = _lib.load()
@@ -152,7 +154,8 @@ class NodeAdjRainbowLossHip(torch.nn.Module):
         fa, fx = (torch.empty_like(pa), torch.empty_like(px)) if sg is not None else (None, None)
         st = torch.cuda.current_stream(dev).cuda_stream
         rc = L.dsg_rainbow_loss_backward(B, n, pa.shape[1], px.shape[2], _p(pa), _p(px), _p(ta), _p(tx), _p(fl), _p(w),
-                                         float(self.edge_loss_weight), float(self.node_loss_weight), float(iou_loss_weight), _p(sg),
+                                         float(self.edge_loss_weight), float(self.node_loss_weight), float(iou_loss_weight),
+                                         _lib.iou_loss_type_code(iou_loss_type), _p(sg),
                                          _p(ga), _p(gx), _p(fa), _p(fx), C.c_void_p(st))
         if rc != 0:
             raise _lib.DsgError(f"dsg_rainbow_loss_backward: status {rc}")
@@ -170,12 +173,11 @@ def eval_loss_step(model, train_obj_gen, loss_func, adjs_gt, nodes_gt, node_flag
             raise ValueError("mode='train' needs optimizer=AdamHip(model) (and optionally ema_helper=[EMAHip(model, beta), ...])")
         optimizer, ema_helper = replay.pop("optimizer"), replay.pop("ema_helper", None)
         loss, ra, rn, sg, _ = train_one_iteration(model, train_obj_gen, loss_func, optimizer, ema_helper, adjs_gt, nodes_gt, node_flags,
-                                                  iou_loss_weight=iou_loss_weight, **replay)
+                                                  iou_loss_weight=iou_loss_weight, iou_loss_type=iou_loss_type, **replay)
         return loss, ra, rn, sg
     if mode != "test":
         raise NotImplementedError(mode)
-    if iou_loss_weight > 0.0 and iou_loss_type != "iou":
-        raise NotImplementedError("only iou_loss_type='iou' (the YAML default) is built")
+    _lib.iou_loss_type_code(iou_loss_type)   # raises NotImplementedError for an unknown type, like trainer_node_adj.py:153-154
     net_input_a, net_input_x, net_cond, net_target_a, net_target_x, (c_skip, c_out, c_in, c_noise, sigmas, weights) = \
         train_obj_gen.get_input_output(adjs_gt, nodes_gt, node_flags, **replay)
     with torch.no_grad():
@@ -183,7 +185,7 @@ def eval_loss_step(model, train_obj_gen, loss_func, adjs_gt, nodes_gt, node_flag
     reg_loss_adj, reg_loss_node = loss_func(net_pred_a=net_output_a, net_pred_x=net_output_x, net_target_a=net_target_a,
                                             net_target_x=net_target_x, net_cond=net_cond, adjs_perturbed=net_input_a, adjs_gt=adjs_gt,
                                             x_perturbed=net_input_x, x_gt=nodes_gt, node_flags=node_flags, loss_weight=weights,
-                                            reduction="none", iou_loss_weight=iou_loss_weight)
+                                            reduction="none", iou_loss_weight=iou_loss_weight, iou_loss_type=iou_loss_type)
     loss = reg_loss_adj.mean() + reg_loss_node.mean()
     return loss, reg_loss_adj, reg_loss_node, sigmas
 
@@ -218,7 +220,7 @@ def swin_block_train(net, block: str, x, emb, grad_out=None):
 
 @torch.no_grad()
 def train_step_grads(model, loss_func, net_input_a, net_input_x, node_flags, sigmas, net_target_a, net_target_x, loss_weight,
-                     iou_loss_weight=0.0, want_grads=True):
+                     iou_loss_weight=0.0, want_grads=True, iou_loss_type="iou"):
     """One training iteration up to and including `loss.backward()` (trainer_node_adj.py:96-170) on the device:
     `model(adjs=net_input_a, nodes=net_input_x, node_flags=..., sigmas=...)` with the network in training form (the self-conditioning
     coin is drawn from NumPy's global generator like precond.py:90 and the detached self-conditioning pass runs on the sampling path),
@@ -248,7 +250,8 @@ def train_step_grads(model, loss_func, net_input_a, net_input_x, node_flags, sig
     la, ln = torch.empty(B, device=dev), torch.empty(B, device=dev)
     h.check(h.L.dsg_train_step_grads(h.raw, B, _p(a), _p(x), _p(fl), _p(sg), _p(sa), _p(sx), _p(ta), _p(tx), _p(w),
                                      float(loss_func.edge_loss_weight), float(loss_func.node_loss_weight), float(iou_loss_weight),
-                                     _p(da), _p(dx_), _p(la), _p(ln), len(keys), names, ptrs, st), "dsg_train_step_grads")
+                                     _lib.iou_loss_type_code(iou_loss_type), _p(da), _p(dx_), _p(la), _p(ln), len(keys), names, ptrs, st),
+            "dsg_train_step_grads")
     oa, on = m._shape_out(da, dx_)
     return oa, on, la, ln, grads
 
@@ -345,7 +348,7 @@ class EMAHip(object):
 
 
 def train_one_iteration(model, train_obj_gen, loss_func, optimizer, ema_helper, adjs_gt, nodes_gt, node_flags, iou_loss_weight=0.0,
-                        max_grad_norm=10.0, **replay):
+                        max_grad_norm=10.0, iou_loss_type="iou", **replay):
     """One iteration of node_adj_move_forward_one_epoch in 'train' mode (trainer_node_adj.py:96-175): objective -> model pass ->
     per-sample losses -> loss.backward() -> clip_grad_norm_(10) -> optimizer.step() -> EMA updates.
     -> (loss, reg_loss_adj, reg_loss_node, sigmas, total_grad_norm)"""
@@ -353,7 +356,8 @@ def train_one_iteration(model, train_obj_gen, loss_func, optimizer, ema_helper, 
         train_obj_gen.get_input_output(adjs_gt, nodes_gt, node_flags, **replay)
     optimizer.zero_grad(set_to_none=True)
     oa, on, reg_loss_adj, reg_loss_node, grads = train_step_grads(model, loss_func, net_input_a, net_input_x, node_flags, sigmas,
-                                                                  net_target_a, net_target_x, weights, iou_loss_weight=iou_loss_weight)
+                                                                  net_target_a, net_target_x, weights, iou_loss_weight=iou_loss_weight,
+                                                                  iou_loss_type=iou_loss_type)
     loss = reg_loss_adj.mean() + reg_loss_node.mean()
     from . import dist as _dist
     _dist.all_reduce_mean(grads)   # data parallel: the mean over ranks, what DDP's backward leaves (identity on one rank)

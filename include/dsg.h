@@ -219,14 +219,19 @@ int32_t dsg_affine_width(dsg_handle h);
 int dsg_train_inputs(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *clean_adj, const float *clean_node,
                      const uint8_t *flags, const float *rnd_sigma, const float *eps_adj, const float *eps_node, uint64_t seed,
                      float *out_sigmas, float *out_weights, float *out_noisy_adj, float *out_noisy_node, void *stream);
+/* iou_loss_type of the trainer's bounding-box term (R/runner/trainer/trainer_node_adj.py:138-153; `--iou_loss_type`, the reference's
+ * README trains with 'giou', its YAMLs default to 'iou'): 'iou' = -(torchvision.ops.box_iou)^2; the others are torchvision.ops'
+ * generalized_ / distance_ / complete_box_iou_loss(reduction='none') ('giou_squared' squares the first).  torchvision is an
+ * un-vendored dependency of the reference and absent from this image: those four are restated from its published algorithm. */
+enum { DSG_IOU_IOU = 0, DSG_IOU_GIOU = 1, DSG_IOU_GIOU_SQUARED = 2, DSG_IOU_DIOU = 3, DSG_IOU_CIOU = 4 };
 /* dsg_rainbow_loss <-> NodeAdjRainbowLoss.forward(reduction='none')    R/loss/rainbow_loss.py:37-101
- *   plus the trainer's bounding-box term with iou_loss_type 'iou'      R/runner/trainer/trainer_node_adj.py:130-159
- *   (last four node channels; 0 switches it off).  Outputs: per-sample losses [B]; the step's scalar loss is
+ *   plus the trainer's bounding-box term (iou_loss_type: DSG_IOU_*)    R/runner/trainer/trainer_node_adj.py:130-159
+ *   (last four node channels; weight 0 switches it off).  Outputs: per-sample losses [B]; the step's scalar loss is
  *   mean(out_loss_adj) + mean(out_loss_node) (trainer_node_adj.py:167). */
 int dsg_rainbow_loss(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *pred_adj, const float *pred_node,
                      const float *target_adj, const float *target_node, const uint8_t *flags, const float *loss_weight,
-                     float edge_loss_weight, float node_loss_weight, float iou_loss_weight, float *out_loss_adj, float *out_loss_node,
-                     void *stream);
+                     float edge_loss_weight, float node_loss_weight, float iou_loss_weight, int32_t iou_loss_type, float *out_loss_adj,
+                     float *out_loss_node, void *stream);
 /* dsg_rainbow_loss_backward: first stage of loss.backward() of a training step   R/runner/trainer/trainer_node_adj.py:163-170
  *   loss = mean_b(loss_adj) + mean_b(loss_node) with the terms of dsg_rainbow_loss (IoU term through autograd's clamp / max / min
  *   rules).  out_grad_* = dL/d(preconditioned outputs), layouts of pred_*.  With sigmas [B] (may be NULL) also
@@ -234,8 +239,9 @@ int dsg_rainbow_loss(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const 
  *   (dsg_train_step_grads chains this with the network's own backward.) */
 int dsg_rainbow_loss_backward(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *pred_adj, const float *pred_node,
                               const float *target_adj, const float *target_node, const uint8_t *flags, const float *loss_weight,
-                              float edge_loss_weight, float node_loss_weight, float iou_loss_weight, const float *sigmas,
-                              float *out_grad_adj, float *out_grad_node, float *out_grad_F_adj, float *out_grad_F_node, void *stream);
+                              float edge_loss_weight, float node_loss_weight, float iou_loss_weight, int32_t iou_loss_type,
+                              const float *sigmas, float *out_grad_adj, float *out_grad_node, float *out_grad_F_adj, float *out_grad_F_node,
+                              void *stream);
 
 /* One SwinTransformerBlock in training form: forward x_out = block(x_in, emb) (R/model/diffusesg/diffusesg.py:232-277 with
  * WindowAttention :108-139 and Mlp :19-25) and, when grad_out != NULL, its backward as torch.autograd derives it -- the first
@@ -270,9 +276,9 @@ int dsg_train_grads(dsg_handle h, int32_t B, const float *in_adj, const float *i
  * ranks is the host's (diffusesg_amd.dist.all_reduce_mean over RCCL). */
 int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const float *noisy_node, const uint8_t *flags, const float *sigmas,
                          const float *sc_adj, const float *sc_node, const float *target_adj, const float *target_node,
-                         const float *loss_weight, float edge_loss_weight, float node_loss_weight, float iou_loss_weight, float *out_D_adj,
-                         float *out_D_node, float *out_loss_adj, float *out_loss_node, int32_t n_params, const char *const *names,
-                         float *const *grad_params, void *stream);
+                         const float *loss_weight, float edge_loss_weight, float node_loss_weight, float iou_loss_weight,
+                         int32_t iou_loss_type, float *out_D_adj, float *out_D_node, float *out_loss_adj, float *out_loss_node,
+                         int32_t n_params, const char *const *names, float *const *grad_params, void *stream);
 
 /* The rest of a training iteration (R/runner/trainer/trainer_node_adj.py:170-175), on caller-owned device tensors, no handle:
  * dsg_adam_step <-> nn.utils.clip_grad_norm_(parameters, max_norm) followed by torch.optim.Adam.step()  (utils/learning_utils.py:137-140:

@@ -786,16 +786,139 @@ NO_FMA int dsgref_train_inputs(dsgref *h, int B, const float *clean_adj, const f
     return 0;
 }
 
+/* The bounding-box term of ONE node, every iou_loss_type of the trainer (R/runner/trainer/trainer_node_adj.py:130-153):
+ *   net_output_x_bbox = (x[..., -4:] + 1) / 2; box_convert(cxcywh -> xyxy).clamp(0, 1); then
+ *   0 'iou'          -(box_iou(a, b).diag())^2            torchvision.ops.boxes.box_iou: wh = (min(rb) - max(lt)).clamp(min=0),
+ *                                                         inter = w h, iou = inter / (area_a + area_b - inter)
+ *   1 'giou'         generalized_box_iou_loss(reduction='none')
+ *   2 'giou_squared' that ** 2
+ *   3 'diou'         distance_box_iou_loss(reduction='none')
+ *   4 'ciou'         complete_box_iou_loss(reduction='none')
+ * torchvision is an un-vendored dependency of the reference (setup/requirements.txt pins torch 2.3.0, whose companion is torchvision
+ * 0.18) and is absent from this image: types 1-4 restate torchvision/ops/{giou,diou,ciou}_loss.py and _utils._loss_inter_union as
+ * published (eps = 1e-7):
+ *   _loss_inter_union: xkis1 = max(x1, x1g) ..., intsct = (xkis2 - xkis1)(ykis2 - ykis1) where (ykis2 > ykis1) & (xkis2 > xkis1) else 0,
+ *                      union = (x2 - x1)(y2 - y1) + (x2g - x1g)(y2g - y1g) - intsct
+ *   giou: iou = intsct / (union + eps); enclosing box (xc1, yc1, xc2, yc2); area_c = (xc2 - xc1)(yc2 - yc1);
+ *         loss = 1 - (iou - (area_c - union) / (area_c + eps))
+ *   diou: loss = 1 - iou + ((x_p - x_g)^2 + (y_p - y_g)^2) / ((xc2 - xc1)^2 + (yc2 - yc1)^2 + eps), centres x_p = (x2 + x1)/2 ...
+ *   ciou: v = 4/pi^2 (atan(w_pred / h_pred) - atan(w_gt / h_gt))^2; alpha = v / (1 - iou + v + eps) under no_grad; loss = diou + alpha v
+ * Parity for these four is therefore "unpinned" against torchvision itself; the fixtures (tests/golden/iou_losses.npz) come from a
+ * torch restatement of the same published code under the reference's autograd engine (tools/gen_golden.py::gen_iou_losses).
+ * grad (optional, 4 doubles): d loss / d the four raw node channels x[-4:], as autograd derives it -- clamp passes the gradient where
+ * min <= v <= max, maximum/minimum to the larger/smaller argument and half to each on a tie, the masked intersection only where open. */
+static float box_term(const float *pred4, const float *tgt4, int type, double *grad) {
+    float bx[2][4], raw[4];
+    for (int q = 0; q < 2; q++) {
+        const float *src = q ? tgt4 : pred4;
+        const float cx = (src[0] + 1.0f) / 2.0f, cy = (src[1] + 1.0f) / 2.0f, bw = (src[2] + 1.0f) / 2.0f, bh = (src[3] + 1.0f) / 2.0f;
+        const float v[4] = {cx - 0.5f * bw, cy - 0.5f * bh, cx + 0.5f * bw, cy + 0.5f * bh};
+        for (int t = 0; t < 4; t++) { bx[q][t] = fminf(fmaxf(v[t], 0.0f), 1.0f); if (!q) raw[t] = v[t]; }
+    }
+    const float x1 = bx[0][0], y1 = bx[0][1], x2 = bx[0][2], y2 = bx[0][3];
+    const float x1g = bx[1][0], y1g = bx[1][1], x2g = bx[1][2], y2g = bx[1][3];
+    double gc[4] = {0, 0, 0, 0};   /* d loss / d (x1, y1, x2, y2) after the clamp */
+    float loss;
+    if (type == 0) {
+        const float a0 = (x2 - x1) * (y2 - y1), a1 = (x2g - x1g) * (y2g - y1g);
+        const float dwf = fminf(x2, x2g) - fmaxf(x1, x1g), dhf = fminf(y2, y2g) - fmaxf(y1, y1g);
+        const float iw = fmaxf(dwf, 0.0f), ih = fmaxf(dhf, 0.0f);
+        const float inter = iw * ih, iou = inter / (a0 + a1 - inter);
+        loss = -(iou * iou);
+        if (grad) {
+            const double aw = x2 - x1, ah = y2 - y1, dw = dwf, dh = dhf;
+            const double I = (double)iw * ih, U = (double)a0 + (double)a1 - I, io = I / U;
+            const double g_iou = -2.0 * io;                              /* d/d iou of -(iou^2) */
+            const double g_inter = g_iou * (U + I) / (U * U);            /* iou = I/U, dU/dI = -1 */
+            const double g_area = g_iou * (-I) / (U * U);
+            gc[0] = g_inter * ((dw >= 0 && x1 > x1g) ? -(double)ih : 0.0) + g_area * (-ah);
+            gc[1] = g_inter * ((dh >= 0 && y1 > y1g) ? -(double)iw : 0.0) + g_area * (-aw);
+            gc[2] = g_inter * ((dw >= 0 && x2 < x2g) ? (double)ih : 0.0) + g_area * ah;
+            gc[3] = g_inter * ((dh >= 0 && y2 < y2g) ? (double)iw : 0.0) + g_area * aw;
+        }
+    } else {
+        const float eps = 1e-7f;
+        /* _loss_inter_union */
+        const float xkis1 = fmaxf(x1, x1g), ykis1 = fmaxf(y1, y1g), xkis2 = fminf(x2, x2g), ykis2 = fminf(y2, y2g);
+        const int mask = (ykis2 > ykis1) && (xkis2 > xkis1);
+        const float intsct = mask ? (xkis2 - xkis1) * (ykis2 - ykis1) : 0.0f;
+        const float uni = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - intsct;
+        const float iou = intsct / (uni + eps);
+        const float xc1 = fminf(x1, x1g), yc1 = fminf(y1, y1g), xc2 = fmaxf(x2, x2g), yc2 = fmaxf(y2, y2g);
+        /* derivative pieces with respect to (x1, y1, x2, y2), in double */
+#define SEL(a, b) ((a) > (b) ? 1.0 : ((a) == (b) ? 0.5 : 0.0))   /* share of maximum(a, b)'s gradient that goes to a */
+        double dI[4] = {0, 0, 0, 0}, dU[4], dIoU[4];
+        if (mask) {
+            dI[0] = -SEL(x1, x1g) * (double)(ykis2 - ykis1); dI[1] = -SEL(y1, y1g) * (double)(xkis2 - xkis1);
+            dI[2] = SEL(x2g, x2) * (double)(ykis2 - ykis1);  dI[3] = SEL(y2g, y2) * (double)(xkis2 - xkis1);
+        }
+        const double dA[4] = {-(double)(y2 - y1), -(double)(x2 - x1), (double)(y2 - y1), (double)(x2 - x1)};
+        const double Ue = (double)uni + (double)eps;
+        for (int t = 0; t < 4; t++) { dU[t] = dA[t] - dI[t]; dIoU[t] = (dI[t] * Ue - (double)intsct * dU[t]) / (Ue * Ue); }
+        const double cw = xc2 - xc1, ch = yc2 - yc1;
+        const double dcw[4] = {-SEL(x1g, x1), 0.0, SEL(x2, x2g), 0.0};   /* xc1 = minimum(x1, x1g): to x1 when x1 < x1g */
+        const double dch[4] = {0.0, -SEL(y1g, y1), 0.0, SEL(y2, y2g)};
+#undef SEL
+        if (type == 1 || type == 2) {
+            const float area_c = (xc2 - xc1) * (yc2 - yc1);
+            const float miouk = iou - ((area_c - uni) / (area_c + eps));
+            const float l = 1.0f - miouk;
+            loss = type == 2 ? l * l : l;
+            if (grad) {
+                const double Ace = (double)area_c + (double)eps, scale = type == 2 ? 2.0 * (double)l : 1.0;
+                for (int t = 0; t < 4; t++) {
+                    const double dAc = dcw[t] * ch + dch[t] * cw;
+                    const double dfrac = ((dAc - dU[t]) * Ace - ((double)area_c - (double)uni) * dAc) / (Ace * Ace);
+                    gc[t] = scale * (-dIoU[t] + dfrac);
+                }
+            }
+        } else {
+            const float diag2 = ((xc2 - xc1) * (xc2 - xc1)) + ((yc2 - yc1) * (yc2 - yc1)) + eps;
+            const float x_p = (x2 + x1) / 2.0f, y_p = (y2 + y1) / 2.0f, x_g = (x1g + x2g) / 2.0f, y_g = (y1g + y2g) / 2.0f;
+            const float cd2 = ((x_p - x_g) * (x_p - x_g)) + ((y_p - y_g) * (y_p - y_g));
+            float l = 1.0f - iou + (cd2 / diag2);
+            float v = 0.0f, alpha = 0.0f, dat = 0.0f;
+            const float w_pred = x2 - x1, h_pred = y2 - y1, w_gt = x2g - x1g, h_gt = y2g - y1g;
+            if (type == 4) {
+                dat = atanf(w_pred / h_pred) - atanf(w_gt / h_gt);
+                v = (4.0f / (3.14159265358979323846f * 3.14159265358979323846f)) * (dat * dat);
+                alpha = v / (1.0f - iou + v + eps);
+                l = l + alpha * v;
+            }
+            loss = l;
+            if (grad) {
+                const double D2 = diag2, dx = (double)x_p - (double)x_g, dy = (double)y_p - (double)y_g;
+                const double dcd2[4] = {dx, dy, dx, dy};   /* 2 (x_p - x_g) * 1/2 */
+                /* dv/dw = 8/pi^2 dat h / (h^2 + w^2), dv/dh = -8/pi^2 dat w / (h^2 + w^2); w = x2 - x1, h = y2 - y1 */
+                const double kv = type == 4 ? (double)alpha * (8.0 / (M_PI * M_PI)) * (double)dat / ((double)h_pred * h_pred + (double)w_pred * w_pred) : 0.0;
+                const double dv[4] = {-kv * h_pred, kv * w_pred, kv * h_pred, -kv * w_pred};
+                for (int t = 0; t < 4; t++) {
+                    const double dD2 = 2.0 * cw * dcw[t] + 2.0 * ch * dch[t];
+                    gc[t] = -dIoU[t] + (dcd2[t] * D2 - (double)cd2 * dD2) / (D2 * D2) + dv[t];
+                }
+            }
+        }
+    }
+    if (grad) {
+        for (int t = 0; t < 4; t++) if (!(raw[t] >= 0.0f && raw[t] <= 1.0f)) gc[t] = 0.0;   /* clamp(min=0, max=1) */
+        /* corners = (cx - w/2, cy - h/2, cx + w/2, cy + h/2), (cx, cy, w, h) = (x + 1) / 2 */
+        grad[0] = 0.5 * (gc[0] + gc[2]);
+        grad[1] = 0.5 * (gc[1] + gc[3]);
+        grad[2] = 0.5 * 0.5 * (gc[2] - gc[0]);
+        grad[3] = 0.5 * 0.5 * (gc[3] - gc[1]);
+    }
+    return loss;
+}
+
 /* NodeAdjRainbowLoss.forward(..., reduction='none') (R/loss/rainbow_loss.py:37-101) for [B,C,N,N] / [B,N,C] tensors, plus the
- * bounding-box IoU term of the trainer (R/runner/trainer/trainer_node_adj.py:130-159, iou_loss_type 'iou'; torchvision's
- * box_convert cxcywh->xyxy and box_iou restated: inter / (area_a + area_b - inter)):
+ * bounding-box term of the trainer (R/runner/trainer/trainer_node_adj.py:130-159; iou_type as box_term above):
  *   loss_adj_b  = sum(mask * w_b * (pred - target)^2) / n_b^2 / C_adj  * edge_loss_weight
  *   loss_node_b = sum(mask * w_b * (pred - target)^2) / n_b   / C_node * node_loss_weight
- *                 + iou_w * w_b * sum_i f_i * (-(iou_i)^2) / n_total      (n_total = valid nodes of the WHOLE batch: the
+ *                 + iou_w * w_b * sum_i f_i * box_term_i / n_total        (n_total = valid nodes of the WHOLE batch: the
  *                   reference divides by node_flags.view(-1).sum(), trainer_node_adj.py:158)
  * Accumulation in double, so that the fixture comparison measures the device kernel's summation, not this one's. */
 int dsgref_rainbow_loss(dsgref *h, int B, const float *pred_adj, const float *pred_node, const float *tgt_adj, const float *tgt_node,
-                        const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w, float *loss_adj,
+                        const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w, int iou_type, float *loss_adj,
                         float *loss_node) {
     const int N = h->N, Ca = h->c_adj, Cn = h->c_node;
     long n_total = 0;
@@ -821,19 +944,9 @@ int dsgref_rainbow_loss(dsgref *h, int B, const float *pred_adj, const float *pr
                     const float d = pred_node[k] - tgt_node[k];
                     sn += (double)(d * d * wb);
                 }
-                if (iou_w != 0.0f) { /* trainer_node_adj.py:131-143 */
-                    float bx[2][4];
-                    for (int q = 0; q < 2; q++) {
-                        const float *src = (q ? tgt_node : pred_node) + ((size_t)b * N + i) * Cn + (Cn - 4);
-                        const float cx = (src[0] + 1.0f) / 2.0f, cy = (src[1] + 1.0f) / 2.0f, bw = (src[2] + 1.0f) / 2.0f, bh = (src[3] + 1.0f) / 2.0f;
-                        const float v[4] = {cx - 0.5f * bw, cy - 0.5f * bh, cx + 0.5f * bw, cy + 0.5f * bh};
-                        for (int t = 0; t < 4; t++) bx[q][t] = fminf(fmaxf(v[t], 0.0f), 1.0f);
-                    }
-                    const float a0 = (bx[0][2] - bx[0][0]) * (bx[0][3] - bx[0][1]), a1 = (bx[1][2] - bx[1][0]) * (bx[1][3] - bx[1][1]);
-                    const float iw = fmaxf(fminf(bx[0][2], bx[1][2]) - fmaxf(bx[0][0], bx[1][0]), 0.0f);
-                    const float ih = fmaxf(fminf(bx[0][3], bx[1][3]) - fmaxf(bx[0][1], bx[1][1]), 0.0f);
-                    const float inter = iw * ih, iou = inter / (a0 + a1 - inter);
-                    si += (double)(-(iou * iou));
+                if (iou_w != 0.0f) { /* trainer_node_adj.py:131-156 */
+                    const size_t o = ((size_t)b * N + i) * Cn + (Cn - 4);
+                    si += (double)box_term(pred_node + o, tgt_node + o, iou_type, NULL);
                 }
             }
         loss_adj[b] = (float)(sa / ((double)n * (double)n) / (double)Ca) * edge_w;
@@ -848,12 +961,12 @@ int dsgref_rainbow_loss(dsgref *h, int B, const float *pred_adj, const float *pr
  * entries, 0 elsewhere;  c_out = sigma sigma_data / sqrt(sigma^2 + sigma_data^2)  (runner/objectives/edm.py:122-126).
  *   d loss_adj[b] / d D_adj  = edge_w * 2 w_b (D - target) / (n_b^2 C_adj)          on f_i f_j
  *   d loss_node[b] / d D_node = node_w * 2 w_b (D - target) / (n_b C_node)          on f_i
- *   IoU term  iou_w w_b sum_i f_i (-(iou_i)^2) / n_total:  autograd through  (x+1)/2 -> cxcywh->xyxy -> clamp[0,1] -> box_iou
- *   (clamp passes the gradient inside [0,1] inclusive; max/min to the selected argument; clamp(min=0) of the overlap where >= 0).
+ *   bbox term  iou_w w_b sum_i f_i box_term_i / n_total:  autograd through  (x+1)/2 -> cxcywh->xyxy -> clamp[0,1] -> the loss of
+ *   iou_type (box_term: clamp passes the gradient inside [0,1] inclusive; max/min to the selected argument).
  * Everything carries the 1/B of the batch mean. */
 int dsgref_rainbow_loss_backward(dsgref *h, int B, const float *pred_adj, const float *pred_node, const float *tgt_adj,
                                  const float *tgt_node, const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w,
-                                 const float *sigmas, float *grad_adj, float *grad_node, float *grad_F_adj, float *grad_F_node) {
+                                 int iou_type, const float *sigmas, float *grad_adj, float *grad_node, float *grad_F_adj, float *grad_F_node) {
     const int N = h->N, Ca = h->c_adj, Cn = h->c_node;
     long n_total = 0;
     for (size_t k = 0; k < (size_t)B * N; k++) n_total += flags[k] ? 1 : 0;
@@ -878,38 +991,9 @@ int dsgref_rainbow_loss_backward(dsgref *h, int B, const float *pred_adj, const 
         for (int i = 0; i < N; i++) {
             double gb[4] = {0, 0, 0, 0};
             if (f[i] && iou_w != 0.0f) {
-                float bx[2][4], raw[4];
-                for (int q = 0; q < 2; q++) {
-                    const float *src = (q ? tgt_node : pred_node) + ((size_t)b * N + i) * Cn + (Cn - 4);
-                    const float cx = (src[0] + 1.0f) / 2.0f, cy = (src[1] + 1.0f) / 2.0f, bw = (src[2] + 1.0f) / 2.0f, bh = (src[3] + 1.0f) / 2.0f;
-                    const float v[4] = {cx - 0.5f * bw, cy - 0.5f * bh, cx + 0.5f * bw, cy + 0.5f * bh};
-                    for (int t = 0; t < 4; t++) { bx[q][t] = fminf(fmaxf(v[t], 0.0f), 1.0f); if (!q) raw[t] = v[t]; }
-                }
-                const double aw = bx[0][2] - bx[0][0], ah = bx[0][3] - bx[0][1];
-                const double a0 = aw * ah, a1 = (double)(bx[1][2] - bx[1][0]) * (double)(bx[1][3] - bx[1][1]);
-                const double dw = fminf(bx[0][2], bx[1][2]) - fmaxf(bx[0][0], bx[1][0]), dh = fminf(bx[0][3], bx[1][3]) - fmaxf(bx[0][1], bx[1][1]);
-                const double iw = dw > 0 ? dw : 0, ih = dh > 0 ? dh : 0;
-                const double inter = iw * ih, uni = a0 + a1 - inter, iou = inter / uni;
-                const double g_iou = ki * (-2.0 * iou);                       /* d/d iou of  ki * (-(iou^2)) */
-                const double g_inter = g_iou * (uni + inter) / (uni * uni);    /* iou = I/U, dU/dI = -1 */
-                const double g_area = g_iou * (-inter) / (uni * uni);
-                /* d inter / d corner (only where the prediction's corner is the selected one and the overlap is open) */
-                double gc[4];
-                gc[0] = (dw >= 0 && bx[0][0] > bx[1][0]) ? -ih : 0.0;
-                gc[1] = (dh >= 0 && bx[0][1] > bx[1][1]) ? -iw : 0.0;
-                gc[2] = (dw >= 0 && bx[0][2] < bx[1][2]) ? ih : 0.0;
-                gc[3] = (dh >= 0 && bx[0][3] < bx[1][3]) ? iw : 0.0;
-                double gcorner[4];
-                gcorner[0] = g_inter * gc[0] + g_area * (-ah);
-                gcorner[1] = g_inter * gc[1] + g_area * (-aw);
-                gcorner[2] = g_inter * gc[2] + g_area * ah;
-                gcorner[3] = g_inter * gc[3] + g_area * aw;
-                for (int t = 0; t < 4; t++) if (!(raw[t] >= 0.0f && raw[t] <= 1.0f)) gcorner[t] = 0.0;   /* clamp */
-                /* corners = (cx - w/2, cy - h/2, cx + w/2, cy + h/2), (cx,cy,w,h) = (x+1)/2 */
-                gb[0] = 0.5 * (gcorner[0] + gcorner[2]);
-                gb[1] = 0.5 * (gcorner[1] + gcorner[3]);
-                gb[2] = 0.5 * 0.5 * (gcorner[2] - gcorner[0]);
-                gb[3] = 0.5 * 0.5 * (gcorner[3] - gcorner[1]);
+                const size_t o = ((size_t)b * N + i) * Cn + (Cn - 4);
+                (void)box_term(pred_node + o, tgt_node + o, iou_type, gb);
+                for (int t = 0; t < 4; t++) gb[t] *= ki;
             }
             for (int c = 0; c < Cn; c++) {
                 const size_t k = ((size_t)b * N + i) * Cn + c;

@@ -50,8 +50,8 @@ def lib():
         L.dsgref_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 10
         L.dsgref_sigma_steps.argtypes = [C.c_void_p, C.c_void_p]
         L.dsgref_train_inputs.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 10
-        L.dsgref_rainbow_loss.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_void_p] * 2
-        L.dsgref_rainbow_loss_backward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_void_p] * 5
+        L.dsgref_rainbow_loss.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_int] + [C.c_void_p] * 2
+        L.dsgref_rainbow_loss_backward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_int] + [C.c_void_p] * 5
         L.dsgref_noise_embed.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
         L.dsgref_decode_bits.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 3
         _lib = L
@@ -190,8 +190,10 @@ class Oracle:
         lib().dsgref_noise_embed(self._h, c.size, _p(c), _p(pe), _p(emb))
         return pe, emb
 
+    IOU_TYPES = {"iou": 0, "giou": 1, "giou_squared": 2, "diou": 3, "ciou": 4}   # trainer_node_adj.py:138-153
+
     def rainbow_loss_backward(self, pred_adj, pred_node, tgt_adj, tgt_node, flags, loss_weight=None, edge_w=1.0, node_w=1.0, iou_w=0.0,
-                              sigmas=None):
+                              sigmas=None, iou_type="iou"):
         """d(loss_adj.mean() + loss_node.mean()) / d(preconditioned outputs) and, with sigmas, / d(raw network outputs)
         -> (grad_adj, grad_node, grad_F_adj | None, grad_F_node | None)"""
         B = flags.shape[0]
@@ -201,11 +203,12 @@ class Oracle:
         w, sg = _f32(loss_weight), _f32(sigmas)
         ga, gn = np.empty(sa, np.float32), np.empty(sn, np.float32)
         fa, fn = (np.empty(sa, np.float32), np.empty(sn, np.float32)) if sg is not None else (None, None)
-        lib().dsgref_rainbow_loss_backward(self._h, B, _p(pa), _p(pn), _p(ta), _p(tn), _p(fl), _p(w), edge_w, node_w, iou_w, _p(sg),
-                                           _p(ga), _p(gn), _p(fa), _p(fn))
+        lib().dsgref_rainbow_loss_backward(self._h, B, _p(pa), _p(pn), _p(ta), _p(tn), _p(fl), _p(w), edge_w, node_w, iou_w,
+                                           self.IOU_TYPES[iou_type], _p(sg), _p(ga), _p(gn), _p(fa), _p(fn))
         return ga, gn, fa, fn
 
-    def rainbow_loss(self, pred_adj, pred_node, tgt_adj, tgt_node, flags, loss_weight=None, edge_w=1.0, node_w=1.0, iou_w=0.0):
+    def rainbow_loss(self, pred_adj, pred_node, tgt_adj, tgt_node, flags, loss_weight=None, edge_w=1.0, node_w=1.0, iou_w=0.0,
+                     iou_type="iou"):
         """loss/rainbow_loss.py:37-101 (reduction='none') + the trainer's IoU term -> (loss_adj [B], loss_node [B])"""
         B = flags.shape[0]
         sa, sn = self._shapes(B)
@@ -213,5 +216,6 @@ class Oracle:
         fl = np.ascontiguousarray(flags, dtype=np.uint8)
         w = _f32(loss_weight)
         la, ln = np.empty(B, np.float32), np.empty(B, np.float32)
-        lib().dsgref_rainbow_loss(self._h, B, _p(pa), _p(pn), _p(ta), _p(tn), _p(fl), _p(w), edge_w, node_w, iou_w, _p(la), _p(ln))
+        lib().dsgref_rainbow_loss(self._h, B, _p(pa), _p(pn), _p(ta), _p(tn), _p(fl), _p(w), edge_w, node_w, iou_w, self.IOU_TYPES[iou_type],
+                                  _p(la), _p(ln))
         return la, ln

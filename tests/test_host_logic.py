@@ -207,16 +207,53 @@ def test_checkpoint_loader_still_refuses_code(tmp_path):
         dio.load_checkpoint(path)
 
 
-def test_npz_writer_keys(tmp_path):
+def test_npz_writer_read_like_the_evaluator(tmp_path):
+    """The archive from the consumer's side: R/helper/eval_sg_samples.py:248-253 opens it with a plain `np.load(path)` (no
+    pickle), reads samples_x, samples_a, gt_x, gt_a, samples_x_bbox, gt_x_bbox, gt_node_flags and turns each into a tensor with
+    `torch.tensor(array)`; shapes / dtypes are what the reference's writer produces from `_decode_*` (sampler_node_adj.py:395-407:
+    float32 quantised graphs [B,N,N] / [B,N], float32 bbox [B,N,4], bool flags)."""
     from diffusesg_amd import io as dio
     B, n = 3, 8
+    g = torch.Generator().manual_seed(0)
+    fl = torch.rand(B, n, generator=g) > 0.3
+    qa = torch.randint(0, 51, (B, n, n), generator=g, dtype=torch.int32)
+    qn = torch.randint(0, 150, (B, n), generator=g, dtype=torch.int32)
+    bb = torch.rand(B, n, 4, generator=g)
+    gt_fl = torch.rand(B, n, generator=g) > 0.3
+    gt_a = torch.randint(0, 51, (B, n, n), generator=g, dtype=torch.int32)
+    gt_x = torch.randint(0, 150, (B, n), generator=g, dtype=torch.int32)
+    gt_bb = torch.rand(B, n, 4, generator=g)
     p = str(tmp_path / "final_samples_array_before_eval.npz")
-    dio.save_samples_npz(p, samples_node_flags=torch.ones(B, n), samples_a=torch.zeros(B, n, n), samples_x=torch.zeros(B, n),
-                         raw_a=torch.zeros(B, 6, n, n), raw_x=torch.zeros(B, n, 8), samples_x_bbox=torch.zeros(B, n, 4))
-    z = np.load(p, allow_pickle=True)   # our own file; None entries are object arrays exactly as in the reference's archive
-    assert set(z.files) == {"samples_node_flags", "samples_a", "samples_x", "raw_a", "raw_x", "gt_node_flags", "gt_a", "gt_x",
-                            "samples_x_bbox", "gt_x_bbox", "gt_image_ids"}
-    assert z["samples_node_flags"].dtype == bool and z["raw_a"].shape == (B, 6, n, n)
+    dio.save_samples_npz(p, samples_node_flags=fl, samples_a=qa, samples_x=qn, raw_a=torch.zeros(B, 6, n, n), raw_x=torch.zeros(B, n, 8),
+                         samples_x_bbox=bb, gt_node_flags=gt_fl, gt_a=gt_a, gt_x=gt_x, gt_x_bbox=gt_bb, gt_image_ids=torch.arange(B))
+    # --- the consumer's statements ---
+    data = np.load(p)
+    samples_x, samples_a, gt_x_, gt_a_ = data['samples_x'], data['samples_a'], data['gt_x'], data['gt_a']
+    samples_x_bbox, gt_x_bbox, node_flags = data['samples_x_bbox'], data['gt_x_bbox'], data['gt_node_flags']
+    tens = [torch.tensor(a) for a in (samples_x, samples_a, gt_x_, gt_a_, samples_x_bbox, gt_x_bbox, node_flags)]
+    # --- what it must have got ---
+    assert [t.dtype for t in tens] == [torch.float32] * 6 + [torch.bool]
+    assert tens[0].shape == (B, n) and tens[1].shape == (B, n, n) and tens[4].shape == (B, n, 4) and tens[6].shape == (B, n)
+    assert torch.equal(tens[0], qn.float()) and torch.equal(tens[1], qa.float()) and torch.equal(tens[2], gt_x.float())
+    assert torch.equal(tens[3], gt_a.float()) and torch.equal(tens[4], bb) and torch.equal(tens[5], gt_bb) and torch.equal(tens[6], gt_fl)
+    assert set(data.files) == {"samples_node_flags", "samples_a", "samples_x", "raw_a", "raw_x", "gt_node_flags", "gt_a", "gt_x",
+                               "samples_x_bbox", "gt_x_bbox", "gt_image_ids"}
+    assert data["samples_node_flags"].dtype == bool and data["raw_a"].shape == (B, 6, n, n) and data["gt_image_ids"].dtype == np.int64
+    # every entry loads without pickle (the reference's None entries would not); a run without bbox channels writes typed empties
+    p2 = str(tmp_path / "nobbox.npz")
+    dio.save_samples_npz(p2, samples_node_flags=fl, samples_a=qa, samples_x=qn, raw_a=torch.zeros(B, 6, n, n), raw_x=torch.zeros(B, n, 8),
+                         gt_node_flags=gt_fl, gt_a=gt_a, gt_x=gt_x)
+    d2 = np.load(p2)
+    for k in d2.files:
+        assert d2[k].dtype != object, k
+    assert d2["samples_x_bbox"].shape == (B, n, 0) and d2["gt_x_bbox"].shape == (B, n, 0)
+    # the ground truth is not optional, and bbox arrays come in pairs
+    with pytest.raises(ValueError):
+        dio.save_samples_npz(p2, samples_node_flags=fl, samples_a=qa, samples_x=qn, raw_a=torch.zeros(B, 6, n, n), raw_x=torch.zeros(B, n, 8),
+                             gt_node_flags=gt_fl, gt_a=None, gt_x=gt_x)
+    with pytest.raises(ValueError):
+        dio.save_samples_npz(p2, samples_node_flags=fl, samples_a=qa, samples_x=qn, raw_a=torch.zeros(B, 6, n, n), raw_x=torch.zeros(B, n, 8),
+                             samples_x_bbox=bb, gt_node_flags=gt_fl, gt_a=gt_a, gt_x=gt_x)
 
 
 def test_pack_decoded_roundtrip():

@@ -106,10 +106,18 @@ def gen_forward(DiffuseSG, out):
         res = {}
         inter = {}
         hooks = []
-        if name in ("tiny", "small"):
+        if name in ("tiny", "small", "vg", "coco"):
             def mk_hook(key):
                 def h(_m, _i, o):
-                    inter[key] = o.detach().numpy().copy()
+                    a = o.detach().numpy().copy()
+                    if name in ("vg", "coco"):
+                        # full-size nets: a fixed pseudo-random sample of Y.INTER_ROWS token rows per tap (every block of every
+                        # (T, C, shift) class, merges, breakups) keeps the fixture small; rows of [B*T, C] in token order
+                        if key == "read_out":
+                            a = a.transpose(0, 2, 3, 1)
+                        a = a.reshape(-1, a.shape[-1])
+                        a = a[Y.inter_rows(a.shape[0])]
+                    inter[key] = a
                 return h
             hooks.append(net.patch_embed.register_forward_hook(mk_hook("patch_embed")))
             for i, l in enumerate(net.down_layers):
@@ -129,7 +137,7 @@ def gen_forward(DiffuseSG, out):
                 oa, on = net(t(a_in.copy()), t(n_in.copy()), t(flags), t(c_noise), t(sa_in.copy()), t(sn_in.copy()))
                 res["sc_adj_out"], res["sc_node_out"] = oa.numpy(), on.numpy()
                 for k, v in inter.items():
-                    res["inter/" + k] = v
+                    res[("rows/" if name in ("vg", "coco") else "inter/") + k] = v
                 inter.clear()
             for h in hooks:
                 h.remove()
@@ -185,7 +193,7 @@ def gen_precond(DiffuseSG, NodeAdjPrecond, out):
 
 
 def run_ref_sampler(NodeAdjEDMSampler, NodeAdjPrecond, DiffuseSG, cfg, *, T, B, valid, seed, tag,
-                    solver="heun", S_churn=40, gt=None, weight_seed=0):
+                    solver="heun", S_churn=40, gt=None, weight_seed=0, coins=None):
     import model.precond.precond as P
     n = cfg.max_node_num
     net = build_ref_net(DiffuseSG, cfg, weight_seed)
@@ -195,6 +203,8 @@ def run_ref_sampler(NodeAdjEDMSampler, NodeAdjPrecond, DiffuseSG, cfg, *, T, B, 
                             clip_samples_scope="x_0", dev="cpu", objective="edm",
                             self_condition=cfg.self_condition, symmetric_noise=False)
     flags, init_adj, init_node, noise_adj, noise_node, coin_vals = Y.sampler_case(cfg, T, B, valid, seed, tag, solver)
+    if coins is not None:   # an explicit 0/1 coin sequence: the reference fires the coin when its draw is < 0.5
+        coin_vals = np.where(np.asarray(coins) != 0, 0.25, 0.75)
     noise = []
     for i in range(T):   # draw order inside one step: adjacency first, then nodes (edm.py:361-364)
         noise.append(noise_adj[i])
@@ -253,6 +263,21 @@ def gen_sampler(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, out):
                                 clip_samples_scope="x_0", dev="cpu", self_condition=True, symmetric_noise=False)
         res[f"sigma_steps_{T}"] = smp.sigma_steps.numpy().copy()
     np.savez_compressed(os.path.join(out, "sampler.npz"), **res)
+
+
+def gen_big_trajectories(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, out):
+    """Short trajectories of the full-size networks through the REFERENCE's sampler (replayed noise and coins): the headline VG
+    configuration (6 Heun+churn steps; 6 Euler steps without churn = BASELINE configs[2]'s variant) and the COCO-Stuff one.
+    The GPU tests used to recompute these with the CPU oracle on every run (~100 s); as fixtures they are pinned to the
+    reference itself.  Cases (inputs from Y.sampler_case): Y.BIG_TRAJ."""
+    res = {}
+    for tag, (name, T, solver, churn, valid, seed, stream, coins) in Y.BIG_TRAJ.items():
+        cfg = CONFIGS[name]()
+        a, nd, _sig, used = run_ref_sampler(NodeAdjEDMSampler, NodeAdjPrecond, DiffuseSG, cfg, T=T, B=len(valid), valid=valid, seed=seed,
+                                            tag=stream, solver=solver, S_churn=churn, coins=coins)
+        res[f"{tag}_adj"], res[f"{tag}_node"], res[f"{tag}_coins_used"] = a, nd, np.array(used)
+        print(f"big trajectory {tag}: max|adj| {np.abs(a).max():.3f} max|node| {np.abs(nd).max():.3f} coins used {used}", flush=True)
+    np.savez_compressed(os.path.join(out, "traj_big.npz"), **res)
 
 
 def gen_decode(out):
@@ -381,6 +406,135 @@ def gen_train_forward(DiffuseSG, NodeAdjPrecond, out):
         res[f"{name}_loss"] = np.array(float(loss))
         print(f"train forward {name}: sigmas {sigmas.numpy()}, loss_adj {reg_loss_adj.numpy()}, loss_node {reg_loss_node_iou.numpy()}, loss {float(loss):.6f}")
     np.savez_compressed(os.path.join(out, "train_forward.npz"), **res)
+
+
+# ---- torchvision.ops box losses, restated (torchvision is not installed in this image; it is an un-vendored dependency of the
+# reference).  Statement-for-statement after torchvision/ops/_utils.py::_loss_inter_union, giou_loss.py, diou_loss.py, ciou_loss.py
+# (0.18, the companion of the pinned torch 2.3.0), reduction='none', so that the reference's own autograd engine differentiates them.
+def _tv_loss_inter_union(boxes1, boxes2):
+    x1, y1, x2, y2 = boxes1.unbind(dim=-1)
+    x1g, y1g, x2g, y2g = boxes2.unbind(dim=-1)
+    xkis1, ykis1 = torch.max(x1, x1g), torch.max(y1, y1g)
+    xkis2, ykis2 = torch.min(x2, x2g), torch.min(y2, y2g)
+    intsctk = torch.zeros_like(x1)
+    mask = (ykis2 > ykis1) & (xkis2 > xkis1)
+    intsctk[mask] = (xkis2[mask] - xkis1[mask]) * (ykis2[mask] - ykis1[mask])
+    unionk = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - intsctk
+    return intsctk, unionk
+
+
+def _tv_generalized_box_iou_loss(boxes1, boxes2, eps=1e-7):
+    intsctk, unionk = _tv_loss_inter_union(boxes1, boxes2)
+    iouk = intsctk / (unionk + eps)
+    x1, y1, x2, y2 = boxes1.unbind(dim=-1)
+    x1g, y1g, x2g, y2g = boxes2.unbind(dim=-1)
+    xc1, yc1 = torch.min(x1, x1g), torch.min(y1, y1g)
+    xc2, yc2 = torch.max(x2, x2g), torch.max(y2, y2g)
+    area_c = (xc2 - xc1) * (yc2 - yc1)
+    miouk = iouk - ((area_c - unionk) / (area_c + eps))
+    return 1 - miouk
+
+
+def _tv_diou_iou_loss(boxes1, boxes2, eps=1e-7):
+    intsct, union = _tv_loss_inter_union(boxes1, boxes2)
+    iou = intsct / (union + eps)
+    x1, y1, x2, y2 = boxes1.unbind(dim=-1)
+    x1g, y1g, x2g, y2g = boxes2.unbind(dim=-1)
+    xc1, yc1 = torch.min(x1, x1g), torch.min(y1, y1g)
+    xc2, yc2 = torch.max(x2, x2g), torch.max(y2, y2g)
+    diagonal_distance_squared = ((xc2 - xc1) ** 2) + ((yc2 - yc1) ** 2) + eps
+    x_p, y_p = (x2 + x1) / 2, (y2 + y1) / 2
+    x_g, y_g = (x1g + x2g) / 2, (y1g + y2g) / 2
+    centers_distance_squared = ((x_p - x_g) ** 2) + ((y_p - y_g) ** 2)
+    loss = 1 - iou + (centers_distance_squared / diagonal_distance_squared)
+    return loss, iou
+
+
+def _tv_complete_box_iou_loss(boxes1, boxes2, eps=1e-7):
+    import math
+    diou_loss, iou = _tv_diou_iou_loss(boxes1, boxes2)
+    x1, y1, x2, y2 = boxes1.unbind(dim=-1)
+    x1g, y1g, x2g, y2g = boxes2.unbind(dim=-1)
+    w_pred, h_pred = x2 - x1, y2 - y1
+    w_gt, h_gt = x2g - x1g, y2g - y1g
+    v = (4 / (math.pi ** 2)) * torch.pow((torch.atan(w_pred / h_pred) - torch.atan(w_gt / h_gt)), 2)
+    with torch.no_grad():
+        alpha = v / (1 - iou + v + eps)
+    return diou_loss + alpha * v
+
+
+def gen_iou_losses(out):
+    """G10: the trainer's bounding-box term for every iou_loss_type (R/runner/trainer/trainer_node_adj.py:130-159, the block restated
+    literally below) on top of the imported NodeAdjRainbowLoss(reduction='none'), and the gradient of
+    loss_adj.mean() + loss_node.mean() with respect to the model outputs through the reference's autograd.  `box_convert` /
+    `box_iou` as in G7; the three torchvision losses restated above.  Inputs: diffusesg_amd.synth.iou_case."""
+    from loss.rainbow_loss import NodeAdjRainbowLoss
+    cfg, flags, pred_adj, pred_node, tgt_adj, tgt_node, wts, sigmas = Y.iou_case()
+    res = {}
+    edge_w, node_w, iou_loss_weight = 2.0, 0.5, 1.5
+
+    def box_convert(b, in_fmt, out_fmt):
+        assert (in_fmt, out_fmt) == ("cxcywh", "xyxy")
+        cx, cy, w, h = b.unbind(-1)
+        return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], dim=-1)
+
+    def box_iou(a, b):   # torchvision.ops.boxes.box_iou, full [M, M] matrix like the reference's call
+        area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+        area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        lt, rb = torch.max(a[:, None, :2], b[:, :2]), torch.min(a[:, None, 2:], b[:, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[:, :, 0] * wh[:, :, 1]
+        return inter / (area_a[:, None] + area_b - inter)
+    generalized_box_iou_loss = lambda a, b, reduction: _tv_generalized_box_iou_loss(a, b)
+    distance_box_iou_loss = lambda a, b, reduction: _tv_diou_iou_loss(a, b)[0]
+    complete_box_iou_loss = lambda a, b, reduction: _tv_complete_box_iou_loss(a, b)
+    loss_func = NodeAdjRainbowLoss(edge_loss_weight=edge_w, node_loss_weight=node_w, flag_reweight=False, objective="edm")
+    torch.set_num_threads(1)
+    for iou_loss_type in Y.IOU_TYPES:
+        net_output_a, net_output_x = t(pred_adj.copy()).requires_grad_(True), t(pred_node.copy()).requires_grad_(True)
+        net_target_a, net_target_x, node_flags, weights = t(tgt_adj.copy()), t(tgt_node.copy()), t(flags), t(wts.copy())
+        reg_loss_adj, reg_loss_node = loss_func(net_pred_a=net_output_a, net_pred_x=net_output_x, net_target_a=net_target_a,
+                                                net_target_x=net_target_x, net_cond=None, adjs_perturbed=None, adjs_gt=net_target_a,
+                                                x_perturbed=None, x_gt=net_target_x, node_flags=node_flags, loss_weight=weights,
+                                                reduction='none')
+        # ---- trainer_node_adj.py:130-159 ----
+        net_output_x_bbox = (net_output_x[..., -4:] + 1.0) / 2.0
+        net_target_x_bbox = (net_target_x[..., -4:] + 1.0) / 2.0
+        net_output_x_bbox = box_convert(net_output_x_bbox, in_fmt='cxcywh', out_fmt='xyxy').clamp(min=0.0, max=1.0)
+        net_target_x_bbox = box_convert(net_target_x_bbox, in_fmt='cxcywh', out_fmt='xyxy').clamp(min=0.0, max=1.0)
+        if iou_loss_type == 'iou':
+            bbox_iou_loss = box_iou(net_output_x_bbox.view(-1, 4), net_target_x_bbox.view(-1, 4))
+            node_iou_loss = - (bbox_iou_loss.diag().view(-1)) ** 2.0
+        elif iou_loss_type == 'ciou':
+            node_iou_loss = complete_box_iou_loss(net_output_x_bbox.view(-1, 4), net_target_x_bbox.view(-1, 4), reduction='none')
+        elif iou_loss_type == 'diou':
+            node_iou_loss = distance_box_iou_loss(net_output_x_bbox.view(-1, 4), net_target_x_bbox.view(-1, 4), reduction='none')
+        elif iou_loss_type == 'giou' or iou_loss_type == 'giou_squared':
+            node_iou_loss = generalized_box_iou_loss(net_output_x_bbox.view(-1, 4), net_target_x_bbox.view(-1, 4), reduction='none')
+            if iou_loss_type == 'giou_squared':
+                node_iou_loss = node_iou_loss ** 2.0
+        else:
+            raise NotImplementedError
+        node_flags_t = node_flags.view(-1)
+        per_node = node_iou_loss.detach().clone()
+        node_iou_loss = node_iou_loss * node_flags_t.to(torch.float32)
+        node_iou_loss = node_iou_loss.view(-1, node_flags.shape[1])
+        node_iou_loss = node_iou_loss.sum(dim=-1) / node_flags_t.sum(dim=-1).to(torch.float32)
+        reg_loss_node = reg_loss_node + iou_loss_weight * node_iou_loss * weights
+        # ---- :163-170 ----
+        loss = reg_loss_adj.mean() + reg_loss_node.mean()
+        loss.backward()
+        assert torch.isfinite(net_output_x.grad).all() and torch.isfinite(per_node[node_flags_t]).all(), iou_loss_type
+        res[f"{iou_loss_type}_loss_adj"], res[f"{iou_loss_type}_loss_node"] = reg_loss_adj.detach().numpy().copy(), reg_loss_node.detach().numpy().copy()
+        res[f"{iou_loss_type}_grad_adj"], res[f"{iou_loss_type}_grad_node"] = net_output_a.grad.numpy().copy(), net_output_x.grad.numpy().copy()
+        res[f"{iou_loss_type}_per_node"] = per_node.numpy().copy()
+        f_ = node_flags_t.numpy().astype(bool)
+        raw = box_convert((net_output_x.detach()[..., -4:] + 1.0) / 2.0, 'cxcywh', 'xyxy').view(-1, 4).numpy()[f_]
+        print(f"iou losses {iou_loss_type}: loss_node {reg_loss_node.detach().numpy()}, valid boxes {f_.sum()}, clamped corners "
+              f"{int(((raw < 0) | (raw > 1)).sum())}, |grad bbox| {float(net_output_x.grad[..., -4:].abs().max()):.3e}")
+    res["edge_w"], res["node_w"], res["iou_w"] = np.array(edge_w), np.array(node_w), np.array(iou_loss_weight)
+    torch.set_num_threads(8)
+    np.savez_compressed(os.path.join(out, "iou_losses.npz"), **res)
 
 
 def gen_train_backward(DiffuseSG, NodeAdjPrecond, out):
@@ -591,6 +745,8 @@ def main():
         gen_train_forward(DiffuseSG, NodeAdjPrecond, args.out)
     if args.only in ("", "train", "train_bwd"):
         gen_train_backward(DiffuseSG, NodeAdjPrecond, args.out)
+    if args.only in ("", "iou"):
+        gen_iou_losses(args.out)
     if args.only in ("", "noise"):
         gen_noise_embed(DiffuseSG, args.out)
     if args.only in ("", "block_bwd"):
@@ -601,6 +757,8 @@ def main():
         gen_precond(DiffuseSG, NodeAdjPrecond, args.out)
     if args.only in ("", "sampler"):
         gen_sampler(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, args.out)
+    if args.only in ("", "big"):
+        gen_big_trajectories(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, args.out)
 
 
 if __name__ == "__main__":

@@ -27,7 +27,10 @@ def run(name, B, T, valid, reps):
         print(f"{name} B={B} T={T} {label:26s}: {min(ts)*1e3:9.1f} ms per sample()  = {B/min(ts):8.2f} graphs/s  ({smp.last_stats})", flush=True)
     ref = res["eager"][1]
     for k, (_, o) in res.items():
-        print(f"   {k}: max |diff| vs eager {float((o - ref).abs().max()):.3e} (max |out| {float(ref.abs().max()):.3f})")
+        print(f"   {k}: max |diff| vs eager {float((o - ref).abs().max()):.3e} (max |out| {float(ref.abs().max()):.3f})", flush=True)
+    for k, (_, o) in res.items():
+        assert torch.equal(o, ref), f"{name} B={B} T={T}: {k} differs from eager"
+    print(f"   {name} B={B} T={T}: all three modes bit-identical", flush=True)
 
 if __name__ == "__main__":
     run("tiny", 4, 1000, 8, 3)
