@@ -61,6 +61,29 @@ void launch_gemm(const GemmArgs &g, hipStream_t s);
 // fused LN1 -> QKV -> window attention for 64-token windows (fp32 kernel); returns false if the geometry is not supported
 bool launch_gemm_qkv_attn(const GemmArgs &g, hipStream_t s);
 void launch_f32_to_bf16(const float *src, void *dst, size_t n, hipStream_t s);
+
+// ---- bf16 block pipeline (kernels_bx.hip; "gemm_bf16" mode): C = epilogue(A[M,K] . W[N,K]^T), A and W bf16 in HBM ----
+struct BxGemm {
+    const void *A = nullptr;  int lda = 0;        // bf16 [M, K1], leading dimension in elements (multiple of 8)
+    const void *A2 = nullptr; int lda2 = 0;       // optional second source for k >= K1 (concat along K); K1 a multiple of the k chunk
+    int K1 = 0;
+    const void *W = nullptr;                      // bf16 [N, K]
+    const float *bias = nullptr;                  // [N] or null
+    const float *res = nullptr; int ldres = 0;    // fp32 residual, added after the activation
+    float *C = nullptr; int ldc = 0;              // fp32 destination (optional; may alias res)
+    void *Cb = nullptr; int ldcb = 0;             // bf16 destination (optional): the stored value, or with ln_out its LayerNorm (no affine)
+    void *C2b = nullptr; int ldc2b = 0;           // bf16 copy of the value BEFORE the modulation below (skip connection)
+    int M = 0, N = 0, K = 0;                      // K % 8 == 0, N % 4 == 0
+    int act = ACT_NONE;                           // ACT_NONE | ACT_GELU
+    // the next Swin block's modulate+SiLU applied to the stored value (GemmArgs::mod_* semantics)
+    const float *mod_aff = nullptr; int mod_ld = 0, mod_off = 0, mod_T = 1;
+    int ln_out = 0;                               // Cb = (v - mean(v)) * rstd(v) over the whole row: N must be 96, 192 or 384 (one tile)
+};
+bool launch_gemm_bx(const BxGemm &g, hipStream_t s);   // false: shape not covered (nothing launched)
+// x fp32 [B*T, C] -> optional in-place modulate+SiLU (aff != null) -> xn bf16: LayerNorm without affine (ln) or the plain copy
+void launch_ln_bx(float *x, const float *aff, int aff_ld, int aff_off, void *xn, int B, int T, int C, bool ln, hipStream_t s);
+// window attention on bf16 qkv [B*T, 3C] -> bf16 out [B*T, C]; biasT as launch_window_attn; false: window size not covered
+bool launch_attn_bx(const void *qkv, const float *biasT, void *out, int B, const WinGeom &g, hipStream_t s);
 void launch_f32_split3(const float *src, void *dst, size_t n, hipStream_t s);
 // device table of the fused MLP's table-driven GELU; must be called once (outside any stream capture) before the first launch
 const float *gelu_table();
