@@ -295,7 +295,8 @@ def worker(args):
                 break
         # peak of the pipe the dominant kernel runs on, in ALGORITHMIC (2*M*N*K) FLOP/s: the split kernel issues six bf16
         # MFMA products per algorithmic product, so its ceiling is the bf16 dense peak / 6
-        kern, peak = {"f32": ("gemm4_f32_kernel", PEAK_F32_MFMA_TFLOPS), "bf16": ("gemm_bf16_kernel", PEAK_BF16_MFMA_TFLOPS),
+        bf16_kern = "gemm_bx_kernel" if (mode == "bf16" and h.get_option("bf16_pipe")) else "gemm_bf16_kernel"
+        kern, peak = {"f32": ("gemm4_f32_kernel", PEAK_F32_MFMA_TFLOPS), "bf16": (bf16_kern, PEAK_BF16_MFMA_TFLOPS),
                       "f32-split": ("gemm_split2_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0)}[mode]
         if mode != "f32":
             gemm_avg_ms_inkernel = None
@@ -308,7 +309,9 @@ def worker(args):
                     "forward_breakdown": breakdown}
         # whole-path achieved rate: graphs/s/GPU x forwards per graph x FLOPs per forward
         roofline["whole_path_tflops"] = nfe * B * f_fwd / elapsed / 1e12
-        roofline["whole_path_frac"] = roofline["whole_path_tflops"] / PEAK_F32_MFMA_TFLOPS
+        # against the peak of the pipe the mode's GEMMs run on (bf16 mode: most of the path's FLOPs are bf16-MFMA products; the
+        # fp32 PatchEmbed / read-out / heads are priced against that peak too, which only understates the fraction)
+        roofline["whole_path_frac"] = roofline["whole_path_tflops"] / peak
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             progress(f"cpu_baseline: timing the oracle on the host cores for up to {args.cpu_budget_s:.0f} s")

@@ -74,6 +74,7 @@ struct Workspace {
     const float *cur_sc_adj = nullptr, *cur_sc_node = nullptr;
     const int *cur_has_sc = nullptr;
     float *pe, *emb0, *emb, *aff, *tok_in, *x, *y, *qkv, *att, *hid, *stats, *pool, *hn, *pool_ext, *pool_part;
+    void *xn = nullptr;   // bf16 [B*T, C]: the normalised input of the next QKV / fc1 GEMM (bf16 block pipeline, kernels_bx.hip)
     float *skips[DSG_MAX_LAYERS];
     // sampler state
     float *x_adj, *x_node, *xh_adj, *xh_node, *sig;
@@ -124,6 +125,7 @@ struct dsg_handle_s {
     bool opt_fused_rowstats = true;   // modulate+SiLU and LayerNorm statistics in the producing GEMM's epilogue (fp32 kernel)
     bool opt_gemm_bf16 = false;                                   // bf16-MFMA GEMMs (fp32 accumulate), opt-in precision mode
     int opt_bf16_act = 2;                                         // in that mode: 1 hidden / attention-output tensors stored as bf16 (bit-identical), 2 also qkv
+    bool opt_bf16_pipe = true;                                    // in that mode: the bf16 block pipeline of kernels_bx.hip (0: round 2's kernels_lp.hip path)
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
     bool opt_gemm_split = false;                                  // split-bf16 GEMMs (3 planes, 6 products): fp32-accurate, opt-in
@@ -531,6 +533,7 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     h->opt_fused_merge = env_on("DSG_FUSED_MERGE", true);
     if (getenv("DSG_FUSED_MLP_MAXC")) h->opt_fused_mlp_maxc = atoi(getenv("DSG_FUSED_MLP_MAXC"));
     h->opt_gemm_bf16 = env_on("DSG_GEMM_BF16", false);
+    h->opt_bf16_pipe = env_on("DSG_BF16_PIPE", true);
     h->opt_gemm_split = env_on("DSG_GEMM_SPLIT", false);
     *out = h;
     return DSG_OK;
@@ -774,7 +777,7 @@ size_t per_sample_floats(dsg_handle h, std::vector<size_t> *parts = nullptr) {
         sa, sn, sa, sn, sa, sn,                  // in, sc, f
         (size_t)E, NOISE_EMB, NOISE_EMB, (size_t)h->aff_n,   // pe, emb0, emb, aff
         T0 * h->Kp,                              // tok_in
-        T0 * E, T0 * E,                          // x, y
+        T0 * E, T0 * E, T0 * E / 2,              // x, y, xn (bf16)
         3 * T0 * E, T0 * E,                      // qkv, att
         (size_t)h->cfg.mlp_ratio * T0 * E,       // hid
         2 * T0,                                  // stats
@@ -809,6 +812,7 @@ int get_workspace(dsg_handle h, int B, Workspace **out) {
     ALLOC(w->aff, (size_t)B * h->aff_n);
     ALLOC(w->tok_in, (size_t)B * T0 * h->Kp);
     ALLOC(w->x, (size_t)B * T0 * E); ALLOC(w->y, (size_t)B * T0 * E);
+    { float *xn_; ALLOC(xn_, (size_t)B * T0 * E / 2 + 64); w->xn = xn_; }
     ALLOC(w->qkv, (size_t)B * 3 * T0 * E); ALLOC(w->att, (size_t)B * T0 * E);
     ALLOC(w->hid, (size_t)B * h->cfg.mlp_ratio * T0 * E);
     ALLOC(w->stats, (size_t)B * 2 * T0);
@@ -970,27 +974,19 @@ void embed_rows(dsg_handle h, const float *c_noise, int rows, float *pe, float *
     P_GEMM(g);
 }
 
-// DiffuseSG.forward on the workspace's fixed buffers: (in_adj,in_node,sc_*,flags,c_noise) -> (f_adj,f_node)
-void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
-    // the fused PatchMerging writes the coarser level into the other activation buffer and swaps the two names; put them back
-    // on every exit so that each forward (and each captured graph) starts from the same assignment
-    struct SwapGuard { Workspace *w; float *x, *y; ~SwapGuard() { w->x = x; w->y = y; } } swap_guard{w, w->x, w->y};
+// input assembly + PatchEmbed (diffusesg.py:784-802, 562-577) -> w->x.  Returns true when the first block's modulate+SiLU rode
+// along (fused kernel only).  fp32 path: only when that block is the fused C = 96 attention kernel (which then skips it);
+// any_first_block: whatever the first block is (the bf16 block pipeline normalises the modulated tensor in its own row pass).
+bool patch_embed_stage(dsg_handle h, Workspace *w, bool fp32_rule, hipStream_t s) {
     const dsg_config &c = h->cfg;
-    const int B = w->B, N = h->N, E = h->E, L = h->L, T0 = N * N;
-    char name[64];
+    const int B = w->B, N = h->N, E = h->E, T0 = N * N;
     GemmArgs g;
-    w->aff_ld = w->uniform ? 0 : h->aff_n;
-    if (!w->uniform) {
-        // noise embedding (diffusesg.py:768-771) and every block's (scale,shift) in one GEMM
-        embed_rows(h, w->c_noise, B, w->pe, w->emb0, w->emb, w->aff, s);
-    }
-    // input assembly + PatchEmbed (diffusesg.py:784-802, 562-577)
     bool pe_done = false, pe_premod = false;
     if (h->opt_fused_pe && h->pe_wp) {
         ProfScope ps_(h, s, PK_FUSED, 2.0 * (double)B * T0 * E * h->Cin, "launch_fused_patch_embed96");
         // the first block's modulate+SiLU rides along when that block is the fused C = 96 attention kernel (which then skips it)
         const BlockPlan *b0 = h->down[0].empty() ? nullptr : &h->down[0][0];
-        pe_premod = wants_premod(h, b0) && h->opt_fused_attn && b0->wqp;
+        pe_premod = wants_premod(h, b0) && (fp32_rule ? (h->opt_fused_attn && b0->wqp) : true);
         pe_done = launch_fused_patch_embed96(w->in_adj, w->in_node, w->cur_sc_adj, w->cur_sc_node, w->cur_has_sc, w->flags, h->pe_wp,
                                              WT(h, "patch_embed.proj.bias"), WT(h, "patch_embed.norm.weight"),
                                              WT(h, "patch_embed.norm.bias"), w->aff, w->aff_ld, h->pe_aff_off, pe_premod ? b0->aff_off : -1,
@@ -1007,6 +1003,209 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
         P_KERN(PK_ROW, 0.0, launch_ln_mod(w->y, WT(h, "patch_embed.norm.weight"), WT(h, "patch_embed.norm.bias"), w->aff, w->aff_ld, h->pe_aff_off,
                       w->x, B, T0, E, s));
     }
+    return pe_premod;
+}
+
+// final norm + read_out + heads (diffusesg.py:758-761, :806-825): w->x -> (f_adj, f_node)
+void readout_stage(dsg_handle h, Workspace *w, hipStream_t s) {
+    const int B = w->B, N = h->N, E = h->E, T0 = N * N;
+    GemmArgs g;
+    const int M0 = B * T0;
+    if (h->opt_fused_readout && h->ro_fap && h->taps.empty()) {
+        // one pass over x: LN, folded read_out+fc1, GELU, fc2, masked adjacency store; pooled LN(x) for the node head
+        P_KERN(PK_FUSED, 2.0 * (double)M0 * E * (E + 32.0),
+               launch_fused_readout96(w->x, WT(h, "norm.weight"), WT(h, "norm.bias"), h->ro_fap, h->ro_fa, h->ro_f2p,
+                                      WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, w->pool_part, w->pool_ext, B, N, h->Ca, s));
+        g = GemmArgs();
+        g.A = w->pool_ext; g.lda = 128; g.K1 = 128; g.K = 128; g.M = B * N; g.N = E; g.act = ACT_GELU;
+        g.W = h->ro_gext; g.bias = WT(h, "readout_node_mlp.fc1.bias"); g.C = w->hn; g.ldc = E;
+        P_GEMM(g);
+        P_KERN(PK_ROW, 0.0, launch_head_node(w->hn, WT(h, "readout_node_mlp.fc2.weight"), WT(h, "readout_node_mlp.fc2.bias"), w->flags,
+                                             w->f_node, B, N, E, h->Cn, s));
+        return;
+    }
+    // faithful chain (diffusesg.py:758-761): final norm, three 1x1 convs
+    P_KERN(PK_ROW, 0.0, launch_ln_stats(w->x, w->stats, M0, E, s));
+    g = GemmArgs();
+    g.A = w->x; g.lda = E; g.K1 = E; g.K = E; g.M = M0; g.N = E;
+    g.ln_stats = w->stats;   // final norm's gamma/beta folded into ro0_wf / ro0_bf
+    g.W = h->ro0_wf; g.bias = h->ro0_bf; g.C = w->y; g.ldc = E;
+    P_GEMM(g);
+    g = GemmArgs();
+    g.A = w->y; g.lda = E; g.K1 = E; g.K = E; g.M = M0; g.N = E;
+    g.W = WT(h, "read_out.1.weight"); g.bias = WT(h, "read_out.1.bias"); g.C = w->att; g.ldc = E;
+    P_GEMM(g);
+    g.A = w->att; g.W = WT(h, "read_out.2.weight"); g.bias = WT(h, "read_out.2.bias"); g.C = w->y;
+    P_GEMM(g);  // y = shared_rep, token-major
+    tap(h, "read_out", w->y, (size_t)M0 * E, s);
+    // adjacency head (diffusesg.py:806-809, :825)
+    g.A = w->y; g.W = WT(h, "readout_adj_mlp.fc1.weight"); g.bias = WT(h, "readout_adj_mlp.fc1.bias"); g.act = ACT_GELU;
+    g.C = w->att;
+    P_GEMM(g);
+    P_KERN(PK_ROW, 0.0, launch_head_adj(w->att, WT(h, "readout_adj_mlp.fc2.weight"), WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, B, N, E,
+                    h->Ca, s));
+    // node head (diffusesg.py:812-822)
+    P_KERN(PK_ELEM, 0.0, launch_pool(w->y, w->flags, w->pool, B, N, E, s));
+    g = GemmArgs();
+    g.A = w->pool; g.lda = E; g.K1 = E; g.K = E; g.M = B * N; g.N = E; g.act = ACT_GELU;
+    g.W = WT(h, "readout_node_mlp.fc1.weight"); g.bias = WT(h, "readout_node_mlp.fc1.bias"); g.C = w->hn; g.ldc = E;
+    P_GEMM(g);
+    P_KERN(PK_ROW, 0.0, launch_head_node(w->hn, WT(h, "readout_node_mlp.fc2.weight"), WT(h, "readout_node_mlp.fc2.bias"), w->flags, w->f_node, B, N,
+                     E, h->Cn, s));
+}
+
+// ================= the bf16 block pipeline ("gemm_bf16" mode; kernels_bx.hip) =================
+// Every tensor a GEMM reads is bf16 in HBM; the residual stream x stays fp32.  State of a level between two launches:
+//   BX_RAW   x holds the un-modulated activation
+//   BX_MOD   x holds silu(shift + x (1 + scale)) of the block about to run (its shortcut), w->xn is not valid yet
+//   BX_READY x as BX_MOD and w->xn = LayerNorm-1 of it without affine (gamma / beta are folded into qkv_wf / qkv_bf)
+enum BxState { BX_RAW = 0, BX_MOD = 1, BX_READY = 2 };
+bool bx_on(dsg_handle h) { return h->opt_gemm_bf16 && !h->opt_gemm_split && h->opt_bf16_pipe; }
+
+#define P_BX(g, tag)                                                                                                           \
+    do {                                                                                                                       \
+        char tg_[96];                                                                                                          \
+        if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm_bx %s M=%d N=%d K=%d ln=%d", tag, (g).M, (g).N, (g).K, (g).ln_out);   \
+        ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)(g).M * (double)(g).N * (double)(g).K, tg_);                               \
+        if (!launch_gemm_bx((g), s)) { fprintf(stderr, "dsg: gemm_bx: shape not covered (%s M=%d N=%d K=%d)\n", tag, (g).M, (g).N, (g).K); abort(); } \
+    } while (0)
+
+bool bx_full_row(int C) { return C == 96 || C == 192 || C == 384; }   // widths a single GEMM tile spans: LayerNorm in the epilogue
+
+// the "produce the next consumer's input" part of a GEMM that writes a level's activation x [M, C]: the next block's modulate+SiLU
+// and its LayerNorm-1 as bf16 (full-row widths), or the plain bf16 copy (PatchBreakup reads the un-normalised tensor).  Returns the
+// state x / xn are in after the launch plus whatever row pass finish_bx still has to run.
+BxState attach_bx_out(dsg_handle h, Workspace *w, BxGemm &g, const BlockPlan *next, bool want_copy) {
+    const bool fuse = h->taps.empty();   // taps want the un-modulated block outputs
+    if (next && fuse) {
+        g.mod_aff = w->aff; g.mod_ld = w->aff_ld; g.mod_off = next->aff_off; g.mod_T = next->res * next->res;
+        if (bx_full_row(g.N)) { g.ln_out = 1; g.Cb = w->xn; g.ldcb = g.N; return BX_READY; }
+        return BX_MOD;
+    }
+    if (!next && want_copy) { g.Cb = w->xn; g.ldcb = g.N; }
+    return BX_RAW;
+}
+
+// One Swin block (diffusesg.py:232-277) on x [B*T, C] in place; `st`: what the producer left (above).  next / want_copy as run_block.
+BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st, const BlockPlan *next, bool want_copy, hipStream_t s) {
+    const int B = w->B, T = b.res * b.res, C = b.C, M = B * T, Hd = h->cfg.mlp_ratio * C;
+    const std::string &p = b.prefix;
+    // x <- silu(shift + x (1 + scale)) (also the shortcut) and LayerNorm-1 -> xn, whatever the producer has not done
+    if (st == BX_RAW) P_KERN(PK_ROW, 0.0, launch_ln_bx(w->x, w->aff, w->aff_ld, b.aff_off, w->xn, B, T, C, true, s));
+    else if (st == BX_MOD) P_KERN(PK_ROW, 0.0, launch_ln_bx(w->x, nullptr, 0, 0, w->xn, B, T, C, true, s));
+    BxGemm g;
+    g.A = w->xn; g.lda = C; g.K = C; g.M = M; g.N = 3 * C;
+    g.W = bf16_of(h, b.qkv_wf); g.bias = b.qkv_bf; g.Cb = w->qkv; g.ldcb = 3 * C;
+    P_BX(g, "qkv");
+    WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
+    {
+        ProfScope ps_(h, s, PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, "attn_bx");
+        if (!launch_attn_bx(w->qkv, b.biasT, w->att, B, wg, s)) launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s, true, true);
+    }
+    g = BxGemm();
+    g.A = w->att; g.lda = C; g.K = C; g.M = M; g.N = C;
+    g.W = bf16_of(h, WT(h, p + ".attn.proj.weight")); g.bias = WT(h, p + ".attn.proj.bias");
+    g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
+    const bool full = bx_full_row(C);
+    if (full) { g.ln_out = 1; g.Cb = w->xn; g.ldcb = C; }   // LayerNorm-2 of x + proj(...) (gamma / beta folded into fc1_wf / fc1_bf)
+    P_BX(g, "proj");
+    if (!full) P_KERN(PK_ROW, 0.0, launch_ln_bx(w->x, nullptr, 0, 0, w->xn, B, T, C, true, s));
+    g = BxGemm();
+    g.A = w->xn; g.lda = C; g.K = C; g.M = M; g.N = Hd;
+    g.W = bf16_of(h, b.fc1_wf); g.bias = b.fc1_bf; g.act = ACT_GELU; g.Cb = w->hid; g.ldcb = Hd;
+    P_BX(g, "fc1");
+    g = BxGemm();
+    g.A = w->hid; g.lda = Hd; g.K = Hd; g.M = M; g.N = C;
+    g.W = bf16_of(h, WT(h, p + ".mlp.fc2.weight")); g.bias = WT(h, p + ".mlp.fc2.bias");
+    g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
+    const BxState out = attach_bx_out(h, w, g, next, want_copy);
+    P_BX(g, "fc2");
+    return out;
+}
+
+// DiffuseSG.forward in the bf16 block pipeline; same structure (and the same fp32 noise embedding, PatchEmbed, read-out and heads)
+// as forward_fixed below
+void forward_fixed_bx(dsg_handle h, Workspace *w, hipStream_t s) {
+    const int B = w->B, N = h->N, E = h->E, L = h->L, T0 = N * N;
+    char name[64];
+    BxGemm g;
+    w->aff_ld = w->uniform ? 0 : h->aff_n;
+    if (!w->uniform) embed_rows(h, w->c_noise, B, w->pe, w->emb0, w->emb, w->aff, s);
+    BxState st = patch_embed_stage(h, w, false, s) ? BX_MOD : BX_RAW;
+    tap(h, "patch_embed", w->x, (size_t)B * T0 * E, s);
+    // encoder (diffusesg.py:745-748); skips are stored as bf16 (their only reader is PatchBreakup's pre_linear)
+    for (int l = 0; l < L; l++) {
+        const int C = E << l, res = N >> l, T = res * res;
+        for (size_t j = 0; j < h->down[l].size(); j++) {
+            const BlockPlan *next = j + 1 < h->down[l].size() ? &h->down[l][j + 1] : (l == L - 1 && !h->up[0].empty() ? &h->up[0][0] : nullptr);
+            st = run_block_bx(h, w, h->down[l][j], st, next, false, s);   // (PatchMerging gathers from the fp32 x: no bf16 copy needed)
+            snprintf(name, sizeof(name), "down%d.block%d", l, (int)j);
+            tap(h, name, w->x, (size_t)B * T * C, s);
+        }
+        if (l < L - 1) {
+            const std::string p = "down_layers." + std::to_string(l) + ".downsample";
+            // 2x2 gather + LayerNorm(4C) -> bf16 [B*T/4, 4C] (in w->hid), then the reduction; its epilogue stores the skip copy and
+            // prepares the next level's first block
+            P_KERN(PK_ROW, 0.0, launch_merge_ln(w->x, WT(h, p + ".norm.weight"), WT(h, p + ".norm.bias"), w->hid, B, res, C, s, true));
+            g = BxGemm();
+            g.A = w->hid; g.lda = 4 * C; g.K = 4 * C; g.M = B * T / 4; g.N = 2 * C;
+            g.W = bf16_of(h, WT(h, p + ".reduction.weight")); g.C = w->x; g.ldc = 2 * C;
+            g.C2b = w->skips[l]; g.ldc2b = 2 * C;
+            st = attach_bx_out(h, w, g, h->down[l + 1].empty() ? nullptr : &h->down[l + 1][0], false);
+            P_BX(g, "merge");
+        }
+        snprintf(name, sizeof(name), "down%d", l);
+        tap(h, name, w->x, l < L - 1 ? (size_t)B * (T / 4) * 2 * C : (size_t)B * T * C, s);
+    }
+    // decoder (diffusesg.py:751-756)
+    for (int i = 0; i < L; i++) {
+        const int l = L - 1 - i, C = E << l, res = N >> l, T = res * res;
+        if (i > 0) {
+            const std::string p = "up_layers." + std::to_string(i) + ".upsample";
+            const int D = 4 * C, Tc = T / 4;
+            // pre_linear on cat([x, skip]): x's bf16 copy was left in w->xn by the previous level's last block, the skip is bf16
+            g = BxGemm();
+            g.A = w->xn; g.lda = D / 2; g.K1 = D / 2; g.A2 = w->skips[l]; g.lda2 = D / 2; g.K = D; g.M = B * Tc; g.N = D;
+            g.W = bf16_of(h, WT(h, p + ".pre_linear.weight")); g.C = w->hid; g.ldc = D;
+            P_BX(g, "pre_linear");
+            P_KERN(PK_ROW, 0.0, launch_breakup_ln(w->hid, WT(h, p + ".norm.weight"), WT(h, p + ".norm.bias"), WT(h, p + ".post_norm.weight"),
+                              WT(h, p + ".post_norm.bias"), w->y, B, res / 2, D, s, true));
+            g = BxGemm();
+            g.A = w->y; g.lda = C; g.K = C; g.M = B * T; g.N = C;
+            g.W = bf16_of(h, WT(h, p + ".post_linear.weight")); g.C = w->x; g.ldc = C;
+            st = attach_bx_out(h, w, g, h->up[i].empty() ? nullptr : &h->up[i][0], false);
+            P_BX(g, "post_linear");
+            snprintf(name, sizeof(name), "up%d.upsample", i);
+            tap(h, name, w->x, (size_t)B * T * C, s);
+        }
+        for (size_t j = 0; j < h->up[i].size(); j++) {
+            const BlockPlan *next = j + 1 < h->up[i].size() ? &h->up[i][j + 1] : nullptr;   // then PatchBreakup / the read-out
+            st = run_block_bx(h, w, h->up[i][j], st, next, /*want_copy=*/i + 1 < L, s);
+            snprintf(name, sizeof(name), "up%d.block%d", i, (int)j);
+            tap(h, name, w->x, (size_t)B * T * C, s);
+        }
+        if (h->up[i].empty() && i + 1 < L)   // a level without blocks: PatchBreakup still needs x's bf16 copy
+            P_KERN(PK_ROW, 0.0, launch_ln_bx(w->x, nullptr, 0, 0, w->xn, B, T, C, false, s));
+    }
+    readout_stage(h, w, s);
+}
+
+// DiffuseSG.forward on the workspace's fixed buffers: (in_adj,in_node,sc_*,flags,c_noise) -> (f_adj,f_node)
+void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
+    if (bx_on(h)) { forward_fixed_bx(h, w, s); return; }
+    // the fused PatchMerging writes the coarser level into the other activation buffer and swaps the two names; put them back
+    // on every exit so that each forward (and each captured graph) starts from the same assignment
+    struct SwapGuard { Workspace *w; float *x, *y; ~SwapGuard() { w->x = x; w->y = y; } } swap_guard{w, w->x, w->y};
+    const dsg_config &c = h->cfg;
+    const int B = w->B, N = h->N, E = h->E, L = h->L, T0 = N * N;
+    char name[64];
+    GemmArgs g;
+    w->aff_ld = w->uniform ? 0 : h->aff_n;
+    if (!w->uniform) {
+        // noise embedding (diffusesg.py:768-771) and every block's (scale,shift) in one GEMM
+        embed_rows(h, w->c_noise, B, w->pe, w->emb0, w->emb, w->aff, s);
+    }
+    const bool pe_premod = patch_embed_stage(h, w, true, s);
     tap(h, "patch_embed", w->x, (size_t)B * T0 * E, s);
     // encoder (diffusesg.py:745-748)
     bool premod = pe_premod;   // is w->x already modulated for the next block (generic blocks: with LN1 partials in w->stats)?
@@ -1081,49 +1280,7 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
             tap(h, name, w->x, (size_t)B * T * C, s);
         }
     }
-    // final norm + read_out + heads
-    const int M0 = B * T0;
-    if (h->opt_fused_readout && h->ro_fap && h->taps.empty()) {
-        // one pass over x: LN, folded read_out+fc1, GELU, fc2, masked adjacency store; pooled LN(x) for the node head
-        P_KERN(PK_FUSED, 2.0 * (double)M0 * E * (E + 32.0),
-               launch_fused_readout96(w->x, WT(h, "norm.weight"), WT(h, "norm.bias"), h->ro_fap, h->ro_fa, h->ro_f2p,
-                                      WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, w->pool_part, w->pool_ext, B, N, h->Ca, s));
-        g = GemmArgs();
-        g.A = w->pool_ext; g.lda = 128; g.K1 = 128; g.K = 128; g.M = B * N; g.N = E; g.act = ACT_GELU;
-        g.W = h->ro_gext; g.bias = WT(h, "readout_node_mlp.fc1.bias"); g.C = w->hn; g.ldc = E;
-        P_GEMM(g);
-        P_KERN(PK_ROW, 0.0, launch_head_node(w->hn, WT(h, "readout_node_mlp.fc2.weight"), WT(h, "readout_node_mlp.fc2.bias"), w->flags,
-                                             w->f_node, B, N, E, h->Cn, s));
-        return;
-    }
-    // faithful chain (diffusesg.py:758-761): final norm, three 1x1 convs
-    P_KERN(PK_ROW, 0.0, launch_ln_stats(w->x, w->stats, M0, E, s));
-    g = GemmArgs();
-    g.A = w->x; g.lda = E; g.K1 = E; g.K = E; g.M = M0; g.N = E;
-    g.ln_stats = w->stats;   // final norm's gamma/beta folded into ro0_wf / ro0_bf
-    g.W = h->ro0_wf; g.bias = h->ro0_bf; g.C = w->y; g.ldc = E;
-    P_GEMM(g);
-    g = GemmArgs();
-    g.A = w->y; g.lda = E; g.K1 = E; g.K = E; g.M = M0; g.N = E;
-    g.W = WT(h, "read_out.1.weight"); g.bias = WT(h, "read_out.1.bias"); g.C = w->att; g.ldc = E;
-    P_GEMM(g);
-    g.A = w->att; g.W = WT(h, "read_out.2.weight"); g.bias = WT(h, "read_out.2.bias"); g.C = w->y;
-    P_GEMM(g);  // y = shared_rep, token-major
-    tap(h, "read_out", w->y, (size_t)M0 * E, s);
-    // adjacency head (diffusesg.py:806-809, :825)
-    g.A = w->y; g.W = WT(h, "readout_adj_mlp.fc1.weight"); g.bias = WT(h, "readout_adj_mlp.fc1.bias"); g.act = ACT_GELU;
-    g.C = w->att;
-    P_GEMM(g);
-    P_KERN(PK_ROW, 0.0, launch_head_adj(w->att, WT(h, "readout_adj_mlp.fc2.weight"), WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, B, N, E,
-                    h->Ca, s));
-    // node head (diffusesg.py:812-822)
-    P_KERN(PK_ELEM, 0.0, launch_pool(w->y, w->flags, w->pool, B, N, E, s));
-    g = GemmArgs();
-    g.A = w->pool; g.lda = E; g.K1 = E; g.K = E; g.M = B * N; g.N = E; g.act = ACT_GELU;
-    g.W = WT(h, "readout_node_mlp.fc1.weight"); g.bias = WT(h, "readout_node_mlp.fc1.bias"); g.C = w->hn; g.ldc = E;
-    P_GEMM(g);
-    P_KERN(PK_ROW, 0.0, launch_head_node(w->hn, WT(h, "readout_node_mlp.fc2.weight"), WT(h, "readout_node_mlp.fc2.bias"), w->flags, w->f_node, B, N,
-                     E, h->Cn, s));
+    readout_stage(h, w, s);
 }
 
 // run forward_fixed either eagerly or by replaying a captured graph
@@ -1314,6 +1471,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "fused_qkv_attn") h->opt_fused_qkv_attn = value != 0;
     else if (n == "loop_graph") h->opt_loop_graph = value != 0;
     else if (n == "bf16_act") h->opt_bf16_act = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "bf16_pipe") h->opt_bf16_pipe = value != 0;
     else if (n == "fused_merge") { h->opt_fused_merge = value != 0; h->opt_fused_merge_small = value > 1; }   // 2: at every size
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
@@ -1339,7 +1497,8 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "fused_rowstats") *value = h->opt_fused_rowstats;
     else if (n == "fused_qkv_attn") *value = h->opt_fused_qkv_attn;
     else if (n == "loop_graph") *value = h->opt_loop_graph;
-    else if (n == "bf16_act") *value = (h->opt_gemm_bf16 && !h->opt_gemm_split) ? h->opt_bf16_act : 0;   // only acts in bf16 mode
+    else if (n == "bf16_act") *value = (h->opt_gemm_bf16 && !h->opt_gemm_split && !h->opt_bf16_pipe) ? h->opt_bf16_act : 0;   // acts in round 2's bf16 path only
+    else if (n == "bf16_pipe") *value = bx_on(h);   // the bf16 block pipeline runs (bf16 mode only)
     else if (n == "fused_merge") *value = h->opt_fused_merge ? (h->opt_fused_merge_small ? 2 : 1) : 0;
     else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
     else if (n == "gemm_split") *value = h->opt_gemm_split;
@@ -1632,6 +1791,93 @@ int dsg_debug_gemm(int32_t M, int32_t N, int32_t K, const float *A, const float 
     launch_gemm(g, s);
     const hipError_t e = hipStreamSynchronize(s);
     if (wlp) (void)hipFree(wlp);
+    return (e == hipSuccess && hipGetLastError() == hipSuccess) ? DSG_OK : DSG_ERR_HIP;
+}
+
+static float time_launches(hipStream_t s, int iters, const std::function<void()> &launch) {
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.f;
+    for (int i = 0; i < 3; i++) launch();
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; i++) launch();
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms / (float)iters;
+}
+
+int dsg_debug_gemm_bx(int32_t M, int32_t N, int32_t K, const float *A, const float *W, const float *bias, const float *res, int32_t act,
+                      const float *mod, int32_t ln_out, float *out_C, float *out_Cb, float *out_C2b, int32_t time_iters, float *out_ms,
+                      void *stream) {
+    if (M < 1 || N < 1 || K < 8 || !A || !W || (!out_C && !out_Cb)) return DSG_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    void *ab = nullptr, *wb = nullptr, *cb = nullptr, *c2b = nullptr;
+    auto cleanup = [&]() { (void)hipFree(ab); (void)hipFree(wb); (void)hipFree(cb); (void)hipFree(c2b); };
+    if (hipMalloc(&ab, (size_t)M * K * 2) != hipSuccess || hipMalloc(&wb, (size_t)N * K * 2) != hipSuccess ||
+        hipMalloc(&cb, (size_t)M * N * 2) != hipSuccess || hipMalloc(&c2b, (size_t)M * N * 2) != hipSuccess) { cleanup(); return DSG_ERR_HIP; }
+    launch_f32_to_bf16(A, ab, (size_t)M * K, s);
+    launch_f32_to_bf16(W, wb, (size_t)N * K, s);
+    BxGemm g;
+    g.A = ab; g.lda = K; g.K = K; g.M = M; g.N = N; g.W = wb; g.bias = bias; g.act = act;
+    if (res) { g.res = res; g.ldres = N; }
+    if (out_C) { g.C = out_C; g.ldc = N; }
+    if (out_Cb) { g.Cb = cb; g.ldcb = N; g.ln_out = ln_out; }
+    if (out_C2b) { g.C2b = c2b; g.ldc2b = N; }
+    if (mod) { g.mod_aff = mod; g.mod_ld = 0; g.mod_off = 0; g.mod_T = 1; }
+    const bool ok = launch_gemm_bx(g, s);
+    if (ok && out_Cb) launch_bf16_to_f32(cb, out_Cb, (size_t)M * N, s);
+    if (ok && out_C2b) launch_bf16_to_f32(c2b, out_C2b, (size_t)M * N, s);
+    if (ok && time_iters > 0 && out_ms) {   // timing: the residual stream is updated in place like in the forward (C aliases res)
+        if (g.res && g.C) { g.C = const_cast<float *>(g.res); g.ldc = g.ldres; }
+        *out_ms = time_launches(s, time_iters, [&]() { (void)launch_gemm_bx(g, s); });
+        if (getenv("DSG_BX_DBG")) {   // phase clocks of a DSG_BX_EXP=4 build (tools/bx_exp.sh): mean over blocks, per tile
+            const int nb = 4096;
+            unsigned long long *dbg = nullptr;
+            if (hipMalloc((void **)&dbg, sizeof(unsigned long long) * 8 * nb) == hipSuccess) {
+                (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * 8 * nb, s);
+                g.dbg = dbg;
+                (void)launch_gemm_bx(g, s);
+                std::vector<unsigned long long> hbuf(8 * nb);
+                (void)hipMemcpyAsync(hbuf.data(), dbg, sizeof(unsigned long long) * 8 * nb, hipMemcpyDeviceToHost, s);
+                (void)hipStreamSynchronize(s);
+                double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+                int cnt = 0;
+                for (int b = 0; b < nb; b++) if (hbuf[8 * b + 6]) { cnt++; for (int i = 0; i < 7; i++) sum[i] += (double)hbuf[8 * b + i]; }
+                if (cnt) {
+                    const double tiles = sum[5] / cnt;
+                    fprintf(stderr, "   bx phases (kclk per tile, mean of %d blocks, %.1f tiles each): mfma+issue %.2f | barrier1 %.2f | wait+refill %.2f | barrier2 %.2f | "
+                                    "epilogue %.2f | block total %.2f kclk\n", cnt, tiles, sum[0] / cnt / tiles / 1e3, sum[1] / cnt / tiles / 1e3, sum[2] / cnt / tiles / 1e3,
+                            sum[3] / cnt / tiles / 1e3, sum[4] / cnt / tiles / 1e3, sum[6] / cnt / 1e3);
+                }
+                (void)hipFree(dbg);
+                g.dbg = nullptr;
+            }
+        }
+    }
+    const hipError_t e = hipStreamSynchronize(s);
+    cleanup();
+    if (!ok) return DSG_ERR_INVALID;
+    return (e == hipSuccess && hipGetLastError() == hipSuccess) ? DSG_OK : DSG_ERR_HIP;
+}
+
+int dsg_debug_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int32_t heads, const float *qkv, const float *biasT, float *out,
+                      int32_t time_iters, float *out_ms, void *stream) {
+    if (B < 1 || res < 1 || ws < 1 || res % ws != 0 || heads < 1 || !qkv || !biasT || !out) return DSG_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int C = 32 * heads;
+    const size_t M = (size_t)B * res * res;
+    void *qb = nullptr, *ob = nullptr;
+    if (hipMalloc(&qb, M * 3 * C * 2) != hipSuccess || hipMalloc(&ob, M * C * 2) != hipSuccess) { (void)hipFree(qb); (void)hipFree(ob); return DSG_ERR_HIP; }
+    launch_f32_to_bf16(qkv, qb, M * 3 * C, s);
+    const bool ok = launch_attn_bx(qb, biasT, ob, B, WinGeom{res, ws, shift, heads, C}, s);
+    if (ok) launch_bf16_to_f32(ob, out, M * C, s);
+    if (ok && time_iters > 0 && out_ms)
+        *out_ms = time_launches(s, time_iters, [&]() { (void)launch_attn_bx(qb, biasT, ob, B, WinGeom{res, ws, shift, heads, C}, s); });
+    const hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(qb); (void)hipFree(ob);
+    if (!ok) return DSG_ERR_INVALID;
     return (e == hipSuccess && hipGetLastError() == hipSuccess) ? DSG_OK : DSG_ERR_HIP;
 }
 

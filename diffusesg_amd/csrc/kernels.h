@@ -78,6 +78,7 @@ struct BxGemm {
     // the next Swin block's modulate+SiLU applied to the stored value (GemmArgs::mod_* semantics)
     const float *mod_aff = nullptr; int mod_ld = 0, mod_off = 0, mod_T = 1;
     int ln_out = 0;                               // Cb = (v - mean(v)) * rstd(v) over the whole row: N must be 96, 192 or 384 (one tile)
+    unsigned long long *dbg = nullptr;            // DSG_BX_EXP == 4 builds only: per-block phase clocks [grid][8] (tools/bx_exp.sh)
 };
 bool launch_gemm_bx(const BxGemm &g, hipStream_t s);   // false: shape not covered (nothing launched)
 // x fp32 [B*T, C] -> optional in-place modulate+SiLU (aff != null) -> xn bf16: LayerNorm without affine (ln) or the plain copy
@@ -85,6 +86,7 @@ void launch_ln_bx(float *x, const float *aff, int aff_ld, int aff_off, void *xn,
 // window attention on bf16 qkv [B*T, 3C] -> bf16 out [B*T, C]; biasT as launch_window_attn; false: window size not covered
 bool launch_attn_bx(const void *qkv, const float *biasT, void *out, int B, const WinGeom &g, hipStream_t s);
 void launch_f32_split3(const float *src, void *dst, size_t n, hipStream_t s);
+void launch_bf16_to_f32(const void *src, float *dst, size_t n, hipStream_t s);
 // device table of the fused MLP's table-driven GELU; must be called once (outside any stream capture) before the first launch
 const float *gelu_table();
 
@@ -120,10 +122,10 @@ void launch_ln_stats(const float *x, float *stats, int M, int C, hipStream_t s);
 void launch_ln_mod(const float *x, const float *g, const float *b, const float *aff, int aff_ld, int aff_off,
                    float *y, int B, int T, int C, hipStream_t s);
 // PatchMerging gather + LN(4C): x [B,res*res,C] -> y [B,(res/2)^2,4C]
-void launch_merge_ln(const float *x, const float *g, const float *b, float *y, int B, int res, int C, hipStream_t s);
+void launch_merge_ln(const float *x, const float *g, const float *b, float *y, int B, int res, int C, hipStream_t s, bool out_bf16 = false);
 // PatchBreakup middle: LN(D) -> 4 chunks scattered 2x2 -> LN(D/4): y [B,res*res,D] -> z [B,(2res)^2,D/4]
 void launch_breakup_ln(const float *y, const float *g, const float *b, const float *pg, const float *pb, float *z,
-                       int B, int res, int D, hipStream_t s);
+                       int B, int res, int D, hipStream_t s, bool out_bf16 = false);   // out_bf16: y / z are bf16 tensors
 // positional embedding of the noise label: pe [B,E]
 void launch_noise_pe(const float *c_noise, float *pe, int B, int E, hipStream_t s);
 // input assembly: token-major [B*N*N, Kp] (zero padded), channel order of diffusesg.py:792-802

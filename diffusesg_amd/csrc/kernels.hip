@@ -1503,6 +1503,7 @@ void launch_ln_mod(const float *x, const float *g, const float *b, const float *
 }
 
 // PatchMerging (diffusesg.py:323-332): out row (i,j) = LN_4C(cat[x(2i,2j), x(2i+1,2j), x(2i,2j+1), x(2i+1,2j+1)])
+template <bool OBF>   // OBF: y is a bf16 tensor (the bf16 block pipeline's reduction GEMM reads bf16)
 __global__ __launch_bounds__(256) void merge_ln_kernel(const float *x, const float *g, const float *bta, float *y, int res,
                                                        int C, int M) {
     const int lane = threadIdx.x & 63;
@@ -1535,18 +1536,24 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float *x, const flo
     const float rstd = fast_rsqrt(wave_sum(var) / (float)(4 * C) + LN_EPS);
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(g), *b4 = reinterpret_cast<const f32x4 *>(bta);
     f32x4 *yr = reinterpret_cast<f32x4 *>(y + (size_t)m * 4 * C);
+    u32x2_c *yb = reinterpret_cast<u32x2_c *>(reinterpret_cast<unsigned short *>(y) + (size_t)m * 4 * C);
 #pragma unroll
     for (int q = 0; q < ROW_MAXV4; q++) {
         const int c = lane + 64 * q;
-        if (c < D4) yr[c] = (v[q] - mean) * rstd * g4[c] + b4[c];
+        if (c < D4) {
+            const f32x4 o = (v[q] - mean) * rstd * g4[c] + b4[c];
+            if (OBF) yb[c] = pack_bf16x4(o); else yr[c] = o;
+        }
     }
 }
-void launch_merge_ln(const float *x, const float *g, const float *b, float *y, int B, int res, int C, hipStream_t s) {
+void launch_merge_ln(const float *x, const float *g, const float *b, float *y, int B, int res, int C, hipStream_t s, bool out_bf16) {
     const int M = B * (res / 2) * (res / 2);
-    hipLaunchKernelGGL(merge_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y, res, C, M);
+    if (out_bf16) hipLaunchKernelGGL(merge_ln_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y, res, C, M);
+    else hipLaunchKernelGGL(merge_ln_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y, res, C, M);
 }
 
 // PatchBreakup middle (diffusesg.py:386-400): LN_D(row) -> chunk q -> token (2i+(q&1), 2j+(q>>1)) -> LN_{D/4}
+template <bool OBF>   // OBF: z is a bf16 tensor (the bf16 block pipeline's post_linear GEMM reads bf16)
 __global__ __launch_bounds__(256) void breakup_ln_kernel(const float *y, const float *g, const float *bta, const float *pg,
                                                          const float *pb, float *z, int res, int D, int M) {
     const int lane = threadIdx.x & 63;
@@ -1617,14 +1624,17 @@ __global__ __launch_bounds__(256) void breakup_ln_kernel(const float *y, const f
 #pragma unroll
             for (int p = 1; p < 4; p++) if (part == p) { mu = cmean[p]; rs = crstd[p]; }
             const size_t orow = (size_t)b * 4 * T + (size_t)(2 * i + di) * R + (2 * j + dj);
-            reinterpret_cast<f32x4 *>(z + orow * Co)[cc] = (v[q] - mu) * rs * pg4[cc] + pb4[cc];
+            const f32x4 o = (v[q] - mu) * rs * pg4[cc] + pb4[cc];
+            if (OBF) reinterpret_cast<u32x2_c *>(reinterpret_cast<unsigned short *>(z) + orow * Co)[cc] = pack_bf16x4(o);
+            else reinterpret_cast<f32x4 *>(z + orow * Co)[cc] = o;
         }
     }
 }
 void launch_breakup_ln(const float *y, const float *g, const float *b, const float *pg, const float *pb, float *z, int B,
-                       int res, int D, hipStream_t s) {
+                       int res, int D, hipStream_t s, bool out_bf16) {
     const int M = B * res * res;
-    hipLaunchKernelGGL(breakup_ln_kernel, dim3((M + 3) / 4), dim3(256), 0, s, y, g, b, pg, pb, z, res, D, M);
+    if (out_bf16) hipLaunchKernelGGL(breakup_ln_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, y, g, b, pg, pb, z, res, D, M);
+    else hipLaunchKernelGGL(breakup_ln_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, y, g, b, pg, pb, z, res, D, M);
 }
 
 // PositionalEmbedding (diffusesg.py:507-513): freqs = (1/10000)^(k/(E/2)); [cos(x f), sin(x f)]

@@ -21,16 +21,10 @@
 namespace dsg {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2_c u32x2;   // pack_bf16 / pack_bf16x4: kernels_common.hip.h
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // RNE (v_cvt_pk_bf16_f32); a in the low half
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ u32x2 pack_bf16x4(const f32x4 v) { u32x2 r; r[0] = pack_bf16(v[0], v[1]); r[1] = pack_bf16(v[2], v[3]); return r; }
 __device__ __forceinline__ void buf_store2(u32x2 v, rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b64(v, r, voff, soff, 0);
 }
@@ -40,205 +34,393 @@ __device__ __forceinline__ void buf_store4(f32x4 v, rsrc_t r, unsigned voff, uns
 __device__ __forceinline__ u32x4 buf_load_u4(rsrc_t r, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); }
 
 // -------------------------------------------------------------------------------------------------
-// GEMM.  LDS: two stages of (BM + BN) rows x (KB + 8) bf16 (row stride 144 B / 80 B: conflict-free ds_read_b128); register-staged
-// (global -> VGPR one chunk ahead -> LDS), one barrier per chunk.
+// GEMM.  At the bf16 matrix rate a 64-deep k chunk of a wave tile is ~0.4 us of MFMA work -- less than a loaded L2 / HBM round trip --
+// and K is short (96..1536), so the loop is built around memory latency, not around the matrix pipe:
+//   * the global loads run TWO chunks ahead of the MFMAs in two register sets (global -> VGPR -> LDS);
+//   * ONE LDS stage of (BM + BN) rows x (KB + 8) bf16 (row stride 144 B / 80 B: conflict-free ds_read_b128), two barriers per chunk --
+//     46 KB for the 128 x 192 tile, so two 4-wave blocks share a CU and one block's prologue, barriers and epilogue can run under the
+//     other's MFMAs;
+//   * blocks are persistent (grid = resident blocks, tiles dealt round-robin; a block keeps its XCD class, so the column tiles of one
+//     row block meet in one L2).
+// What bounds it (in-kernel clocks, tools/bx_exp.sh, COCO level-2 fc1, per 128 x 192 x 384 tile): ~10k clocks in the MFMA section
+// (4.6k of matrix-pipe time per wave, two waves per SIMD), 3.5k waiting for loads, ~12k in the epilogue -- 96 GELUs per lane cost as
+// many VALU clocks as the tile's MFMAs at K = 384, and the stores are HBM-bound by themselves; the proj / fc2 / C = 96 shapes sit at
+// 3.5-4.3 TB/s of their minimum HBM traffic.  Tried and measured without gain (profiles/r3/bx_experiments.txt): prefetching across
+// the tile boundary (spills: both register sets live through the epilogue), starting one of a CU's two blocks half a tile late.
 // -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int KB>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_bx_kernel(BxGemm g, int tiles_m, int tiles_n) {
+// RES: a residual is added; MOD: 0 no modulate, 1 batch-uniform (scale, shift) staged in LDS, 2 per-sample rows read in the epilogue
+// (test / training-time forwards) -- compile-time so that the common epilogue has no load behind a branch.
+#ifndef DSG_BX_EXP
+#define DSG_BX_EXP 0   // timing experiments of tools/bx_exp.sh (wrong results): 1 no epilogue, 2 no global loads / LDS refills, 3 no MFMAs
+#endif
+template <int WM, int WN, int KB, bool RES, int MOD>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gemm_bx_kernel(BxGemm g, int tiles_m, int tiles_n, int tiles_total) {
     constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 96 * WN, LDP = KB + 8;
     constexpr int CPR = KB / 8;                       // 16-byte pieces per tile row
     constexpr int RPP = NT / CPR;                     // tile rows covered by one pass of the block
     constexpr int PA = BM / RPP, PW = (BN + RPP - 1) / RPP;
+    constexpr int CV = (BN + NT - 1) / NT;            // column-vector entries per thread
     static_assert(NT % CPR == 0 && BM % RPP == 0, "staging layout");
-    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * (BM + BN) * LDP];
-    constexpr int STAGE = (BM + BN) * LDP;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, seq = bid >> 3;
-    const int tm = (seq / tiles_n) * 8 + xcd, tn = seq % tiles_n;
-    if (tm >= tiles_m) return;
-    const int m0 = tm * BM, n0 = tn * BN;
+    // tile stage | [3][BN] floats: the epilogue's per-column vectors (bias, 1 + scale, shift) | [BM][WN] row partials
+    __shared__ __attribute__((aligned(16))) __bf16 lds[(BM + BN) * LDP + 6 * BN + 4 * BM * WN];
+    float *colv = reinterpret_cast<float *>(lds + (BM + BN) * LDP);
+    f32x2 *part = reinterpret_cast<f32x2 *>(colv + 3 * BN);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lrow = lane & 31, lhalf = lane >> 5;
-    const int rows_m = min(BM, g.M - m0), rows_n = min(BN, g.N - n0);
     const __bf16 *Ap = static_cast<const __bf16 *>(g.A), *A2p = static_cast<const __bf16 *>(g.A2), *Wp = static_cast<const __bf16 *>(g.W);
-    const rsrc_t rsA1 = make_rsrc(Ap + (size_t)m0 * g.lda, (unsigned)rows_m * g.lda * 2u);
-    const rsrc_t rsA2 = make_rsrc(A2p ? A2p + (size_t)m0 * g.lda2 : Ap, A2p ? (unsigned)rows_m * g.lda2 * 2u : 0u);
-    const rsrc_t rsW = make_rsrc(Wp + (size_t)n0 * g.K, (unsigned)rows_n * g.K * 2u);
     const int sc = tid % CPR, sr = tid / CPR;         // this thread's 16-byte piece / first tile row
-    unsigned voffA1[PA], voffA2[PA], voffW[PW];
-#pragma unroll
-    for (int p = 0; p < PA; p++) {
-        voffA1[p] = ((unsigned)(sr + RPP * p) * g.lda + 8u * sc) * 2u;
-        voffA2[p] = ((unsigned)(sr + RPP * p) * g.lda2 + 8u * sc) * 2u;
-    }
-#pragma unroll
-    for (int p = 0; p < PW; p++) voffW[p] = (sr + RPP * p < BN) ? ((unsigned)(sr + RPP * p) * g.K + 8u * sc) * 2u : 0x7fffffffu;
-    const int nk = (g.K + KB - 1) / KB;
+    // per-thread byte offsets of pass 0; pass p adds p * RPP rows (a block-uniform stride)
+    const unsigned voffA1 = ((unsigned)sr * g.lda + 8u * sc) * 2u, voffA2 = ((unsigned)sr * g.lda2 + 8u * sc) * 2u;
+    const unsigned voffW = ((unsigned)sr * g.K + 8u * sc) * 2u;
+    const unsigned strA1 = (unsigned)RPP * g.lda * 2u, strA2 = (unsigned)RPP * g.lda2 * 2u, strW = (unsigned)RPP * g.K * 2u;
+    const int nk = (g.K + KB - 1) / KB;               // >= 2 (launcher)
     const int K1 = A2p ? g.K1 : g.K;
 
-    u32x4 sa[PA], sw[PW];
-    auto issue = [&](int kc) {
-        const int k0 = kc * KB;
-        const bool kvalid = k0 + 8 * sc < g.K;        // K may end inside a chunk (K = 96, KB = 64): the rest of the row is not zero
-        const bool second = k0 >= K1;
-        const unsigned soffA = (unsigned)(second ? k0 - K1 : k0) * 2u;
-#pragma unroll
-        for (int p = 0; p < PA; p++) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (kvalid) v = second ? buf_load_u4(rsA2, voffA2[p], soffA) : buf_load_u4(rsA1, voffA1[p], soffA);
-            sa[p] = v;
+    // a tile: padded id t -> (tm, tn) with the XCD-aware order of gemm4 (ids t and t + 8 share an XCD; tn runs fastest inside one)
+    struct Tile { int m0, n0, rows_m, valid; };
+    auto make_tile = [&](int t) -> Tile {
+        Tile c;
+        for (;; t += (int)gridDim.x) {   // skip the padding ids of the last row-block group
+            if (t >= tiles_total) { c.valid = 0; c.m0 = c.n0 = 0; c.rows_m = 0; break; }
+            const int xcd = t & 7, seq = t >> 3;
+            const int tm = (seq / tiles_n) * 8 + xcd, tn = seq % tiles_n;
+            if (tm < tiles_m) { c.valid = 1; c.m0 = tm * BM; c.n0 = tn * BN; c.rows_m = min(BM, g.M - c.m0); break; }
         }
-#pragma unroll
-        for (int p = 0; p < PW; p++) {
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (kvalid) v = buf_load_u4(rsW, voffW[p], (unsigned)k0 * 2u);
-            sw[p] = v;
+        return c;
+    };
+    auto next_id = [&](int t) -> int {   // the id make_tile(t) settled on is not returned; recompute the skip (cheap, scalar)
+        for (;; t += (int)gridDim.x) {
+            if (t >= tiles_total) return t;
+            const int xcd = t & 7, seq = t >> 3;
+            if ((seq / tiles_n) * 8 + xcd < tiles_m) return t;
         }
     };
-    auto write = [&](int buf) {
-        __bf16 *As = lds + buf * STAGE, *Ws = As + BM * LDP;
+
+    struct Stage { u32x4 a[PA], w[PW]; };
+    auto issue = [&](Stage &st, const Tile &c, int kc) {
+        if (DSG_BX_EXP == 2) return;
+        const int k0 = kc * KB;
+        // K may end inside a chunk (K = 96, KB = 64) and the rest of the row is not zero: pieces beyond K get an out-of-range offset
+        // (the descriptor returns zeros) -- no branch around a load
+        const unsigned kmask = (k0 + 8 * sc < g.K) ? 0u : 0x7fffffffu;
+        const bool second = k0 >= K1;                  // block-uniform
+        const unsigned soffA = (unsigned)(second ? k0 - K1 : k0) * 2u;
+        if (second) {
+            const rsrc_t rsA2 = make_rsrc(A2p + (size_t)c.m0 * g.lda2, (unsigned)c.rows_m * g.lda2 * 2u);
 #pragma unroll
-        for (int p = 0; p < PA; p++) *reinterpret_cast<u32x4 *>(As + (sr + RPP * p) * LDP + 8 * sc) = sa[p];
+            for (int p = 0; p < PA; p++) st.a[p] = buf_load_u4(rsA2, (voffA2 + p * strA2) | kmask, soffA);
+        } else {
+            const rsrc_t rsA1 = make_rsrc(Ap + (size_t)c.m0 * g.lda, (unsigned)c.rows_m * g.lda * 2u);
+#pragma unroll
+            for (int p = 0; p < PA; p++) st.a[p] = buf_load_u4(rsA1, (voffA1 + p * strA1) | kmask, soffA);
+        }
+        const rsrc_t rsW = make_rsrc(Wp + (size_t)c.n0 * g.K, (unsigned)min(BN, g.N - c.n0) * g.K * 2u);
 #pragma unroll
         for (int p = 0; p < PW; p++)
-            if (BN % RPP == 0 || sr + RPP * p < BN) *reinterpret_cast<u32x4 *>(Ws + (sr + RPP * p) * LDP + 8 * sc) = sw[p];
+            st.w[p] = buf_load_u4(rsW, (BN % RPP == 0 || sr + RPP * p < BN) ? ((voffW + p * strW) | kmask) : 0x7fffffffu, (unsigned)k0 * 2u);
+    };
+    auto write = [&](const Stage &st) {
+        if (DSG_BX_EXP == 2) return;
+        __bf16 *As = lds, *Ws = lds + BM * LDP;
+#pragma unroll
+        for (int p = 0; p < PA; p++) *reinterpret_cast<u32x4 *>(As + (sr + RPP * p) * LDP + 8 * sc) = st.a[p];
+#pragma unroll
+        for (int p = 0; p < PW; p++)
+            if (BN % RPP == 0 || sr + RPP * p < BN) *reinterpret_cast<u32x4 *>(Ws + (sr + RPP * p) * LDP + 8 * sc) = st.w[p];
     };
 
     f32x16 acc[2][3];
-#pragma unroll
-    for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-        for (int nt = 0; nt < 3; nt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
-
-    issue(0);
-    write(0);
-    __syncthreads();
-    for (int kc = 0; kc < nk; kc++) {
-        const int cur = kc & 1;
-        if (kc + 1 < nk) issue(kc + 1);
-        const __bf16 *As = lds + cur * STAGE + (wm * 64 + lrow) * LDP + 8 * lhalf;
-        const __bf16 *Ws = lds + cur * STAGE + (BM + wn * 96 + lrow) * LDP + 8 * lhalf;
+    const __bf16 *Afr = lds + (wm * 64 + lrow) * LDP + 8 * lhalf;
+    const __bf16 *Wfr = lds + (BM + wn * 96 + lrow) * LDP + 8 * lhalf;
+    auto compute = [&]() {
+        if (DSG_BX_EXP == 3) return;
 #pragma unroll
         for (int s = 0; s < KB / 16; s++) {
             bf16x8 af[2], wf[3];
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) af[mt] = *reinterpret_cast<const bf16x8 *>(As + 32 * mt * LDP + 16 * s);
+            for (int mt = 0; mt < 2; mt++) af[mt] = *reinterpret_cast<const bf16x8 *>(Afr + 32 * mt * LDP + 16 * s);
 #pragma unroll
-            for (int nt = 0; nt < 3; nt++) wf[nt] = *reinterpret_cast<const bf16x8 *>(Ws + 32 * nt * LDP + 16 * s);
+            for (int nt = 0; nt < 3; nt++) wf[nt] = *reinterpret_cast<const bf16x8 *>(Wfr + 32 * nt * LDP + 16 * s);
 #pragma unroll
             for (int mt = 0; mt < 2; mt++)
 #pragma unroll
                 for (int nt = 0; nt < 3; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
         }
-        if (kc + 1 < nk) write(1 - cur);
-        __syncthreads();
-    }
+    };
 
-    // ---- epilogue: lane (m = lrow, half) owns output rows m0 + 64 wm + 32 mt + lrow; accumulator quad q of tile nt holds its columns
-    // n0 + 96 wn + 32 nt + 8 q + 4 half + {0..3}
-    const unsigned OOB = 0x7fffffffu;
-    const rsrc_t rsC = make_rsrc(g.C ? g.C + (size_t)m0 * g.ldc : nullptr, g.C ? (unsigned)rows_m * g.ldc * 4u : 0u);
-    const rsrc_t rsR = make_rsrc(g.res ? g.res + (size_t)m0 * g.ldres : nullptr, g.res ? (unsigned)rows_m * g.ldres * 4u : 0u);
-    __bf16 *Cbp = static_cast<__bf16 *>(g.Cb), *C2p = static_cast<__bf16 *>(g.C2b);
-    const rsrc_t rsCb = make_rsrc(Cbp ? Cbp + (size_t)m0 * g.ldcb : nullptr, Cbp ? (unsigned)rows_m * g.ldcb * 2u : 0u);
-    const rsrc_t rsC2 = make_rsrc(C2p ? C2p + (size_t)m0 * g.ldc2b : nullptr, C2p ? (unsigned)rows_m * g.ldc2b * 2u : 0u);
-    f32x2 *part = reinterpret_cast<f32x2 *>(lds);   // [BM][WN] (sum, sumsq) of a row over one wave's 96 columns; the tiles are dead
-    const bool ln = g.ln_out != 0;
+    // ---- epilogue of one tile: lane (m = lrow, half) owns output rows m0 + 64 wm + 32 mt + lrow; accumulator quad q of tile nt holds
+    // its columns n0 + 96 wn + 32 nt + 8 q + 4 half + {0..3}.  No per-element branches (they would cut the code into basic blocks with
+    // one exposed memory round trip each): columns >= N carry zeros (W rows beyond N read as zero, the column vectors are zero / one
+    // there) and are dropped by out-of-range store offsets; the residual of group i + 1 is in flight while group i is processed.
+    // (The reference adds the residual AFTER bias and activation; here it joins the accumulator first -- only the fp32 rounding of
+    // the three-term sum changes; GELU outputs never carry a residual.)
+    auto epilogue = [&](const Tile &c) {
+        const int m0 = c.m0, n0 = c.n0;
+        const unsigned OOB = 0x7fffffffu;
+        const rsrc_t rsC = make_rsrc(g.C ? g.C + (size_t)m0 * g.ldc : nullptr, g.C ? (unsigned)c.rows_m * g.ldc * 4u : 0u);
+        const rsrc_t rsR = make_rsrc(g.res ? g.res + (size_t)m0 * g.ldres : nullptr, g.res ? (unsigned)c.rows_m * g.ldres * 4u : 0u);
+        __bf16 *Cbp = static_cast<__bf16 *>(g.Cb), *C2p = static_cast<__bf16 *>(g.C2b);
+        const rsrc_t rsCb = make_rsrc(Cbp ? Cbp + (size_t)m0 * g.ldcb : nullptr, Cbp ? (unsigned)c.rows_m * g.ldcb * 2u : 0u);
+        const rsrc_t rsC2 = make_rsrc(C2p ? C2p + (size_t)m0 * g.ldc2b : nullptr, C2p ? (unsigned)c.rows_m * g.ldc2b * 2u : 0u);
+        const bool ln = g.ln_out != 0, gelu = g.act == ACT_GELU;
+        const int ncol0 = wn * 96 + 4 * lhalf;          // + 32 nt + 8 q: this lane's column inside the tile
+        // group = (mt, nt, qh): two accumulator quads = 8 values per lane at a time (register pressure: the next chunk is in flight)
+        auto load_res = [&](f32x4 (&rr)[2], int grp) {
+            const unsigned mrow = (unsigned)(wm * 64 + 32 * (grp / 6) + lrow);
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-        const unsigned mrow = (unsigned)(wm * 64 + 32 * mt + lrow);
-        const float *aff_row = nullptr;
-        if (g.mod_aff) aff_row = g.mod_aff + (size_t)(g.mod_ld ? min(m0 + (int)mrow, g.M - 1) / g.mod_T : 0) * g.mod_ld + g.mod_off;
-        float ssum = 0.f, ssq = 0.f;
+            for (int q = 0; q < 2; q++) {
+                const int n = n0 + ncol0 + 32 * ((grp >> 1) % 3) + 8 * (2 * (grp & 1) + q);
+                rr[q] = buf_load4(rsR, n < g.N ? (mrow * g.ldres + (unsigned)n) * 4u : OOB, 0u);
+            }
+        };
+        f32x4 rra[2], rrb[2];
+        if (RES) load_res(rra, 0);
+        float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < 3; nt++)
+        for (int grp = 0; grp < 12; grp++) {
+            const int mt = grp / 6, nt = (grp >> 1) % 3, q0 = 2 * (grp & 1);
+            const unsigned mrow = (unsigned)(wm * 64 + 32 * mt + lrow);
+            if (RES && grp + 1 < 12) { if (grp & 1) load_res(rra, grp + 1); else load_res(rrb, grp + 1); }
+            f32x4 v[2], scl[2], sft[2];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int n = n0 + wn * 96 + 32 * nt + 8 * q + 4 * lhalf;
-                const bool nok = n < g.N;
-                f32x4 v;
+            for (int q = 0; q < 2; q++) {
+                const int nc = ncol0 + 32 * nt + 8 * (q0 + q);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(colv + nc);
 #pragma unroll
-                for (int t = 0; t < 4; t++) v[t] = acc[mt][nt][4 * q + t];
-                if (g.bias && nok) v += *reinterpret_cast<const f32x4 *>(g.bias + n);
-                if (g.act == ACT_GELU) {
-#pragma unroll
-                    for (int t = 0; t < 4; t++) v[t] = gelu_f(v[t]);
-                }
-                if (g.res) v += buf_load4(rsR, nok ? (mrow * g.ldres + (unsigned)n) * 4u : OOB, 0u);
-                if (C2p) buf_store2(pack_bf16x4(v), rsC2, nok ? (mrow * g.ldc2b + (unsigned)n) * 2u : OOB, 0u);
-                if (aff_row && nok) {
-                    const f32x4 scl = *reinterpret_cast<const f32x4 *>(aff_row + n), sft = *reinterpret_cast<const f32x4 *>(aff_row + g.N + n);
-#pragma unroll
-                    for (int t = 0; t < 4; t++) v[t] = silu_exact(fmaf(v[t], scl[t] + 1.0f, sft[t]));
-                }
-                if (g.C) buf_store4(v, rsC, nok ? (mrow * g.ldc + (unsigned)n) * 4u : OOB, 0u);
-                if (ln) {
-                    if (nok) {
-#pragma unroll
-                        for (int t = 0; t < 4; t++) { ssum += v[t]; ssq = fmaf(v[t], v[t], ssq); }
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; t++) acc[mt][nt][4 * q + t] = v[t];
-                } else if (Cbp) {
-                    buf_store2(pack_bf16x4(v), rsCb, nok ? (mrow * g.ldcb + (unsigned)n) * 2u : OOB, 0u);
+                for (int t = 0; t < 4; t++) v[q][t] = acc[mt][nt][4 * (q0 + q) + t] + b4[t];
+                if (MOD == 1) {
+                    scl[q] = *reinterpret_cast<const f32x4 *>(colv + BN + nc);
+                    sft[q] = *reinterpret_cast<const f32x4 *>(colv + 2 * BN + nc);
                 }
             }
-        if (ln) {
-            ssum += __shfl_xor(ssum, 32, 64);
-            ssq += __shfl_xor(ssq, 32, 64);
-            if (lhalf == 0) part[mrow * WN + wn] = (f32x2){ssum, ssq};
+            if (MOD == 2) {   // per-sample (scale, shift): test / training-time forwards only (the sampler's sigma is batch-uniform)
+                const float *aff_row = g.mod_aff + (size_t)(min(m0 + (int)mrow, g.M - 1) / g.mod_T) * g.mod_ld + g.mod_off;
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int n = min(n0 + ncol0 + 32 * nt + 8 * (q0 + q), g.N - 4);
+                    scl[q] = *reinterpret_cast<const f32x4 *>(aff_row + n) + 1.0f;
+                    sft[q] = *reinterpret_cast<const f32x4 *>(aff_row + g.N + n);
+                }
+            }
+            if (gelu) {
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) v[q][t] = gelu_f(v[q][t]);
+            }
+            if (RES) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) v[q] += (grp & 1) ? rrb[q] : rra[q];
+            }
+            if (C2p) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int n = n0 + ncol0 + 32 * nt + 8 * (q0 + q);
+                    buf_store2(pack_bf16x4(v[q]), rsC2, n < g.N ? (mrow * g.ldc2b + (unsigned)n) * 2u : OOB, 0u);
+                }
+            }
+            if (MOD != 0) {
+#pragma unroll
+                for (int q = 0; q < 2; q++)
+#pragma unroll
+                    for (int t = 0; t < 4; t++) v[q][t] = silu_exact(fmaf(v[q][t], scl[q][t], sft[q][t]));
+            }
+            if (g.C) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int n = n0 + ncol0 + 32 * nt + 8 * (q0 + q);
+                    buf_store4(v[q], rsC, n < g.N ? (mrow * g.ldc + (unsigned)n) * 4u : OOB, 0u);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    ssum[mt] += v[q][t]; ssq[mt] = fmaf(v[q][t], v[q][t], ssq[mt]);
+                    acc[mt][nt][4 * (q0 + q) + t] = v[q][t];
+                }
+            if (Cbp && !ln) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int n = n0 + ncol0 + 32 * nt + 8 * (q0 + q);
+                    buf_store2(pack_bf16x4(v[q]), rsCb, n < g.N ? (mrow * g.ldcb + (unsigned)n) * 2u : OOB, 0u);
+                }
+            }
         }
-    }
-    if (ln) {
-        __syncthreads();
-        const float invn = 1.0f / (float)g.N;
+        if (ln) {
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
-            const unsigned mrow = (unsigned)(wm * 64 + 32 * mt + lrow);
-            float sm = 0.f, sq = 0.f;
+            for (int mt = 0; mt < 2; mt++) {
+                const unsigned mrow = (unsigned)(wm * 64 + 32 * mt + lrow);
+                ssum[mt] += __shfl_xor(ssum[mt], 32, 64);
+                ssq[mt] += __shfl_xor(ssq[mt], 32, 64);
+                if (lhalf == 0) part[mrow * WN + wn] = (f32x2){ssum[mt], ssq[mt]};
+            }
+            __syncthreads();
+            const float invn = 1.0f / (float)g.N;
 #pragma unroll
-            for (int w2 = 0; w2 < WN; w2++) { const f32x2 p2 = part[mrow * WN + w2]; sm += p2[0]; sq += p2[1]; }
-            const float mean = sm * invn, rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invn), 0.f) + LN_EPS), nmr = -mean * rstd;
+            for (int mt = 0; mt < 2; mt++) {
+                const unsigned mrow = (unsigned)(wm * 64 + 32 * mt + lrow);
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < WN; w2++) { const f32x2 p2 = part[mrow * WN + w2]; sm += p2[0]; sq += p2[1]; }
+                const float mean = sm * invn, rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * invn), 0.f) + LN_EPS), nmr = -mean * rstd;
+#pragma unroll
+                for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int n = n0 + ncol0 + 32 * nt + 8 * q;
+                        f32x4 v;
+#pragma unroll
+                        for (int t = 0; t < 4; t++) v[t] = fmaf(acc[mt][nt][4 * q + t], rstd, nmr);
+                        buf_store2(pack_bf16x4(v), rsCb, n < g.N ? (mrow * g.ldcb + (unsigned)n) * 2u : OOB, 0u);
+                    }
+            }
+        }
+    };
+
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};   // DSG_BX_EXP == 4: shader clocks in MFMA section / barrier 1 / wait + LDS refill / barrier 2 / epilogue, tiles
+#define BX_STAMP() (DSG_BX_EXP == 4 ? __builtin_amdgcn_s_memtime() : 0ull)
+    const unsigned long long tstart = BX_STAMP();
+    Stage s0, s1;
+    for (int t = next_id((int)blockIdx.x); t < tiles_total; t = next_id(t + (int)gridDim.x)) {
+        const Tile cur = make_tile(t);
+        issue(s0, cur, 0);
+        issue(s1, cur, 1);
+        float cv[3][CV];   // the tile's column vectors: loaded now, written to LDS just before the epilogue
+#pragma unroll
+        for (int i = 0; i < CV; i++) {
+            const int col = tid + NT * i, n = cur.n0 + col;
+            const bool ok = col < BN && n < g.N;
+            cv[0][i] = (g.bias && ok) ? g.bias[n] : 0.f;
+            cv[1][i] = (MOD == 1 && ok) ? g.mod_aff[g.mod_off + n] + 1.0f : 1.0f;
+            cv[2][i] = (MOD == 1 && ok) ? g.mod_aff[g.mod_off + g.N + n] : 0.f;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++)
 #pragma unroll
             for (int nt = 0; nt < 3; nt++)
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int n = n0 + wn * 96 + 32 * nt + 8 * q + 4 * lhalf;
-                    f32x4 v;
-#pragma unroll
-                    for (int t = 0; t < 4; t++) v[t] = fmaf(acc[mt][nt][4 * q + t], rstd, nmr);
-                    buf_store2(pack_bf16x4(v), rsCb, n < g.N ? (mrow * g.ldcb + (unsigned)n) * 2u : OOB, 0u);
+                for (int r = 0; r < 16; r++) acc[mt][nt][r] = 0.f;
+        write(s0);
+        __syncthreads();
+        // invariant at the top of an iteration: LDS holds chunk kc, s1 holds chunk kc + 1 (possibly still in flight), s0 is free
+        for (int kc = 0; kc < nk; kc += 2) {
+            unsigned long long ta = BX_STAMP();
+            if (kc + 2 < nk) issue(s0, cur, kc + 2);
+            compute();
+            unsigned long long tb = BX_STAMP();
+            __syncthreads();                 // every wave is done reading chunk kc
+            unsigned long long tc = BX_STAMP();
+            ph[0] += tb - ta; ph[1] += tc - tb;
+            if (kc + 1 < nk) {
+                write(s1);
+                if (DSG_BX_EXP == 4) __builtin_amdgcn_s_waitcnt(0xc07f);
+                ta = BX_STAMP();
+                __syncthreads();
+                tb = BX_STAMP();
+                ph[2] += ta - tc; ph[3] += tb - ta;
+                if (kc + 3 < nk) issue(s1, cur, kc + 3);
+                compute();
+                tc = BX_STAMP();
+                __syncthreads();
+                ta = BX_STAMP();
+                ph[0] += tc - tb; ph[1] += ta - tc;
+                if (kc + 2 < nk) {
+                    write(s0);
+                    if (DSG_BX_EXP == 4) __builtin_amdgcn_s_waitcnt(0xc07f);
+                    tb = BX_STAMP();
+                    __syncthreads();
+                    ph[2] += tb - ta; ph[3] += BX_STAMP() - tb;
                 }
+            }
         }
+        const unsigned long long te = BX_STAMP();
+        if (DSG_BX_EXP == 1) {           // keep the accumulators alive, store nothing of substance
+            float keep = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+                for (int nt = 0; nt < 3; nt++) keep += acc[mt][nt][0];
+            if (keep == 123.456f && g.C) g.C[0] = keep;
+        } else {
+#pragma unroll
+            for (int i = 0; i < CV; i++) {
+                const int col = tid + NT * i;
+                if (col < BN) { colv[col] = cv[0][i]; colv[BN + col] = cv[1][i]; colv[2 * BN + col] = cv[2][i]; }
+            }
+            __syncthreads();
+            epilogue(cur);
+            __syncthreads();             // colv / part / the tile stage are rewritten by the next tile
+        }
+        if (DSG_BX_EXP == 4) { __builtin_amdgcn_s_waitcnt(0x0070); ph[4] += BX_STAMP() - te; ph[5] += 1; }
     }
+    if (DSG_BX_EXP == 4 && g.dbg && tid == 0) {
+        unsigned long long *d = g.dbg + 8 * (size_t)blockIdx.x;
+#pragma unroll
+        for (int i = 0; i < 6; i++) d[i] = ph[i];
+        d[6] = BX_STAMP() - tstart;
+        d[7] = __builtin_amdgcn_s_memrealtime();
+    }
+#undef BX_STAMP
 }
 
 static int round_up8(int x) { return (x + 7) / 8 * 8; }
 
+static int bx_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+
 bool launch_gemm_bx(const BxGemm &g, hipStream_t s) {
     if (!g.A || !g.W || g.M < 1 || g.N < 1 || g.K < 8 || g.K % 8 != 0 || g.N % 4 != 0 || (g.act != ACT_NONE && g.act != ACT_GELU)) return false;
     if (g.lda % 8 != 0 || (g.A2 && (g.lda2 % 8 != 0 || g.K1 <= 0))) return false;
-    // geometry: the tile spans the whole row when a LayerNorm output is asked for; otherwise 256 x 192 where N splits into 192s,
-    // 512 x 96 for the narrow / odd widths (N = 96, 288)
-    int geo;   // 0: <4,2,64> 256x192   1: <2,4,64> 128x384   2: <8,1,32> 512x96
+    if (g.act == ACT_GELU && g.res) return false;   // the epilogue adds the residual before bias / activation (fc1 has none)
+    // geometry (wave grid WM x WN, block tile 64 WM x 96 WN): the tile spans the whole row when a LayerNorm output is asked for;
+    // otherwise 128 x 192 where N splits into 192s, 256 x 96 for the narrow / odd widths (N = 96, 288)
+    //   0: <2,2,64> 128x192 (4 waves, 2 blocks / CU)   2: <4,1,32> 256x96 (4 waves, 2 blocks / CU)   3: <2,4,64> 128x384 (8 waves)
+    // (measured against 64x384 on 4 waves with 64- and 32-deep chunks and 256x192 on 8 waves: profiles/r3/bx_experiments.txt)
+    int geo;
     if (g.ln_out) {
         if (!g.Cb) return false;
-        if (g.N == 96) geo = 2; else if (g.N == 192) geo = 0; else if (g.N == 384) geo = 1; else return false;
+        if (g.N == 96) geo = 2; else if (g.N == 192) geo = 0; else if (g.N == 384) geo = 3; else return false;
     } else {
         geo = (g.N % 192 == 0) ? 0 : 2;
     }
     const int kb = geo == 2 ? 32 : 64;
     if (g.A2 && g.K1 % kb != 0) return false;
     if (geo == 2 && g.K % 32 != 0) return false;
-    const int bm = geo == 0 ? 256 : (geo == 1 ? 128 : 512), bn = geo == 0 ? 192 : (geo == 1 ? 384 : 96);
+    if ((g.K + kb - 1) / kb < 2) return false;      // the chunk loop assumes at least two chunks per tile
+    const int bm = geo == 0 ? 128 : (geo == 2 ? 256 : 128), bn = geo == 0 ? 192 : (geo == 2 ? 96 : 384);
     const int tiles_m = (g.M + bm - 1) / bm, tiles_n = (g.N + bn - 1) / bn;
-    const dim3 grid(round_up8(tiles_m) * tiles_n), block(512);
-    if (geo == 0) hipLaunchKernelGGL((gemm_bx_kernel<4, 2, 64>), grid, block, 0, s, g, tiles_m, tiles_n);
-    else if (geo == 1) hipLaunchKernelGGL((gemm_bx_kernel<2, 4, 64>), grid, block, 0, s, g, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm_bx_kernel<8, 1, 32>), grid, block, 0, s, g, tiles_m, tiles_n);
+    const int tiles_total = round_up8(tiles_m) * tiles_n;
+    // persistent grid: the blocks that are resident at once (2 per CU for the 4-wave geometries), a multiple of 8 so that a block's
+    // tiles t, t + grid, ... stay in one XCD class
+    const int resident = std::max(8, bx_cu_count() * (geo == 3 ? 1 : 2) / 8 * 8);
+    const dim3 grid(std::min(tiles_total, resident));
+    const int mod = !g.mod_aff ? 0 : (g.mod_ld == 0 ? 1 : 2);
+#define BX_LAUNCH(WM_, WN_, KB_, NT_)                                                                                                      \
+    do {                                                                                                                                   \
+        if (g.res) {                                                                                                                       \
+            if (mod == 0) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 0>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);        \
+            else if (mod == 1) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 1>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);   \
+            else hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 2>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);                 \
+        } else {                                                                                                                           \
+            if (mod == 0) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 0>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);       \
+            else if (mod == 1) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 1>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);  \
+            else hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 2>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);                \
+        }                                                                                                                                  \
+    } while (0)
+    switch (geo) {
+        case 0: BX_LAUNCH(2, 2, 64, 256); break;
+        case 2: BX_LAUNCH(4, 1, 32, 256); break;
+        default: BX_LAUNCH(2, 4, 64, 512); break;
+    }
+#undef BX_LAUNCH
     return true;
 }
 
@@ -298,7 +480,7 @@ void launch_ln_bx(float *x, const float *aff, int aff_ld, int aff_off, void *xn,
 
 // -------------------------------------------------------------------------------------------------
 // Window attention on bf16 q, k, v (diffusesg.py:108-139; window partition / cyclic shift / reverse folded into the token index as in
-// window_attn_kernel).  One wave per (sample, window, head); Wp = 32 KT >= WS^2 positions.
+// window_attn_kernel).  One wave per (sample, window, head) unit; Wp = 32 KT >= WS^2 positions.
 //   S^T[key][query] = K Q^T + bias   A operand = K rows, B operand = Q rows (q pre-scaled by d^-1/2 log2 e in the QKV weights): a lane
 //                                    owns one query column, so the softmax is lane-local (+ one exchange between the half-waves);
 //   O^T[d][query]  = V^T P^T         B operand = the S^T accumulators themselves, converted pairwise to bf16 (an accumulator tile's
@@ -308,22 +490,35 @@ void launch_ln_bx(float *x, const float *aff, int aff_ld, int aff_off, void *xn,
 //                                    -- the k order in which registers 8 s' .. 8 s' + 7 of a 32x32 accumulator enumerate its rows.
 // The result is a lane's 4 consecutive head dims per accumulator quad: 8-byte bf16 stores.
 // -------------------------------------------------------------------------------------------------
+// A block works on ONE (window position, head) pair and walks through samples: the pair's bias tile -- relative-position bias +
+// shift mask, 64 KB of fp32 for 100-token windows, which a wave-per-unit kernel re-read from L2 for every sample (2.5x the kernel's
+// HBM traffic) -- is converted once into LDS as fp16 pairs (keys 2j, 2j + 1 of one query share a dword: 32 KB, conflict-free
+// ds_read_b32 along the query lanes; fp16 keeps 11 bits of the O(1) bias values, below what rounding P to bf16 costs) and every
+// sample's scores start from there.  Each of the 4 waves takes every 4th sample of the block's share.
 template <int KT, int WS>
-__global__ __launch_bounds__(256) void attn_bx_kernel(const __bf16 *__restrict__ qkv, const float *__restrict__ biasT, __bf16 *__restrict__ out,
-                                                      int B, WinGeom g, int n_units) {
+__global__ __launch_bounds__(256, 2) void attn_bx_kernel(const __bf16 *__restrict__ qkv, const float *__restrict__ biasT, __bf16 *__restrict__ out,
+                                                         int B, WinGeom g, int split) {
     constexpr int Wp = 32 * KT, Wt = WS * WS, VLD = Wp + 8;   // vt row stride in bf16 (16-B aligned, conflict-free b128 reads)
     __shared__ __attribute__((aligned(16))) __bf16 vt_lds[4][32 * VLD];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) unsigned bias_lds[(Wp / 2) * Wp];   // [key pair][query] fp16x2
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, lhalf = lane >> 5;
-    int unit = blockIdx.x * 4 + wave;
-    const bool active = unit < n_units;
-    if (!active) unit = n_units - 1;
     const int heads = g.heads, C = g.C, res = g.res;
-    const int nwr = res / WS, nW = nwr * nwr, T = res * res;
-    const int head = unit % heads;
-    const int bw = unit / heads;
-    const int w = bw % nW, b = bw / nW;
+    const int nwr = res / WS, T = res * res;
+    const int pair = blockIdx.x / split, part = blockIdx.x % split;   // pair = (window position, head)
+    const int head = pair % heads, w = pair / heads;
     const int wi = w / nwr, wj = w % nwr;
+    {   // bias tile -> LDS (fp16 pairs along the key dimension); -1e30 of the padded key slots saturates to a finite fp16
+        const float *src = biasT + ((size_t)(g.shift > 0 ? w : 0) * heads + head) * Wp * Wp;
+        for (int idx = tid; idx < (Wp / 2) * Wp; idx += 256) {
+            const int kp = idx / Wp, q = idx % Wp;
+            const float lo = fmaxf(src[(2 * kp) * Wp + q], -60000.f), hi = fmaxf(src[(2 * kp + 1) * Wp + q], -60000.f);
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 pk = {(_Float16)lo, (_Float16)hi};
+            bias_lds[idx] = __builtin_bit_cast(unsigned, pk);
+        }
+    }
+    __syncthreads();
     auto token_of = [&](int p) -> int {   // window position -> token of the sample (padded positions: token 0)
         if (p >= Wt) return 0;
         int ti = wi * WS + p / WS + g.shift, tj = wj * WS + p % WS + g.shift;
@@ -331,9 +526,6 @@ __global__ __launch_bounds__(256) void attn_bx_kernel(const __bf16 *__restrict__
         if (tj >= res) tj -= res;
         return ti * res + tj;
     };
-    const rsrc_t rsQ = make_rsrc(qkv + (size_t)b * T * 3 * C, (unsigned)T * 3u * C * 2u);
-    const rsrc_t rsB = make_rsrc(biasT + ((size_t)(g.shift > 0 ? w : 0) * heads + head) * Wp * Wp, (unsigned)(Wp * Wp) * 4u);
-    const rsrc_t rsO = make_rsrc(out + (size_t)b * T * C, active ? (unsigned)T * C * 2u : 0u);
     int tokr[KT];
     unsigned rowoff[KT];
 #pragma unroll
@@ -341,95 +533,117 @@ __global__ __launch_bounds__(256) void attn_bx_kernel(const __bf16 *__restrict__
         tokr[kt] = token_of(32 * kt + lrow);
         rowoff[kt] = (unsigned)tokr[kt] * (unsigned)(3 * C) * 2u + 16u * lhalf;   // this lane's 8 head dims of k-step s: + 32 s bytes
     }
-    const unsigned hq = (unsigned)head * 64u, hk = (unsigned)(C + head * 32) * 2u, hv = (unsigned)(2 * C + head * 32) * 2u;
-    // K fragments (lane = key row), both k-steps
-    bf16x8 kf[KT][2];
+    // V^T staging items of this lane: (key pair kp, group of 8 head dims dg); token offsets are sample-independent
+    unsigned vtoff_a[KT], vtoff_b[KT];
+    int vtdst[KT];
 #pragma unroll
-    for (int kt = 0; kt < KT; kt++)
-#pragma unroll
-        for (int s = 0; s < 2; s++) kf[kt][s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsQ, rowoff[kt], hk + 32u * s));
-    // V^T -> LDS: item = (key pair kp, group of 8 head dims dg); the two keys' values of one head dim share a dword
-    __bf16 *vt = vt_lds[wave];
-#pragma unroll
-    for (int it = 0; it < (Wp / 2) * 4 / 64; it++) {
+    for (int it = 0; it < KT; it++) {
         const int item = lane + 64 * it, kp = item >> 2, dg = item & 3;
         const int k0 = 2 * kp;
-        const u32x4 va = buf_load_u4(rsQ, (unsigned)token_of(k0) * (unsigned)(3 * C) * 2u + 16u * dg, hv);
-        const u32x4 vb = buf_load_u4(rsQ, (unsigned)token_of(k0 + 1) * (unsigned)(3 * C) * 2u + 16u * dg, hv);
+        vtoff_a[it] = (unsigned)token_of(k0) * (unsigned)(3 * C) * 2u + 16u * dg;
+        vtoff_b[it] = (unsigned)token_of(k0 + 1) * (unsigned)(3 * C) * 2u + 16u * dg;
         const int o = k0 & 15, pos = (k0 & ~15) + 8 * ((o >> 2) & 1) + 4 * (o >> 3) + (o & 3);
-        unsigned *dst = reinterpret_cast<unsigned *>(vt + (8 * dg) * VLD + pos);
-#pragma unroll
-        for (int e = 0; e < 4; e++) {   // dword e of va / vb holds head dims 8 dg + 2 e, + 1
-            dst[(2 * e) * (VLD / 2)] = __builtin_amdgcn_perm(vb[e], va[e], 0x05040100u);       // (va.lo, vb.lo)
-            dst[(2 * e + 1) * (VLD / 2)] = __builtin_amdgcn_perm(vb[e], va[e], 0x07060302u);   // (va.hi, vb.hi)
-        }
+        vtdst[it] = (8 * dg) * VLD + pos;
     }
-    __builtin_amdgcn_wave_barrier();
-    // V^T fragments: lane (d = lrow, half), k-step (kt, s): positions 32 kt + 16 s + 8 half .. + 7
-    bf16x8 vf[KT][2];
+    const unsigned hq = (unsigned)head * 64u, hk = (unsigned)(C + head * 32) * 2u, hv = (unsigned)(2 * C + head * 32) * 2u;
+    __bf16 *vt = vt_lds[wave];
+    // the block's share of the batch: samples [b_lo, b_hi), this wave takes b_lo + wave, + 4, ...
+    const int per = (B + split - 1) / split, b_lo = part * per, b_hi = min(B, b_lo + per);
+    for (int b = b_lo + wave; b < b_hi; b += 4) {
+        const rsrc_t rsQ = make_rsrc(qkv + (size_t)b * T * 3 * C, (unsigned)T * 3u * C * 2u);
+        const rsrc_t rsO = make_rsrc(out + (size_t)b * T * C, (unsigned)T * C * 2u);
+        // K fragments (lane = key row), both k-steps
+        bf16x8 kf[KT][2];
 #pragma unroll
-    for (int kt = 0; kt < KT; kt++)
+        for (int kt = 0; kt < KT; kt++)
 #pragma unroll
-        for (int s = 0; s < 2; s++) vf[kt][s] = *reinterpret_cast<const bf16x8 *>(vt + lrow * VLD + 32 * kt + 16 * s + 8 * lhalf);
-
-    const unsigned boff = (unsigned)(4 * lhalf * Wp + lrow) * 4u;
+            for (int s = 0; s < 2; s++) kf[kt][s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsQ, rowoff[kt], hk + 32u * s));
+        // V^T -> LDS: the two keys' values of one head dim share a dword
+        u32x4 va[KT], vb[KT];
 #pragma unroll
-    for (int qt = 0; qt < KT; qt++) {
-        if (32 * qt >= Wt) break;
-        bf16x8 qf[2];
+        for (int it = 0; it < KT; it++) { va[it] = buf_load_u4(rsQ, vtoff_a[it], hv); vb[it] = buf_load_u4(rsQ, vtoff_b[it], hv); }
+        __builtin_amdgcn_wave_barrier();   // (the previous sample's fragment reads of vt are done: same wave, in order)
 #pragma unroll
-        for (int s = 0; s < 2; s++) qf[s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsQ, rowoff[qt], hq + 32u * s));
-        f32x16 sacc[KT];
-        float mx = -3.0e38f;
+        for (int it = 0; it < KT; it++) {
+            unsigned *dst = reinterpret_cast<unsigned *>(vt + vtdst[it]);
 #pragma unroll
-        for (int kt = 0; kt < KT; kt++) {
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                sacc[kt][r] = buf_load1(rsB, boff, (unsigned)((32 * kt + (r & 3) + 8 * (r >> 2)) * Wp + 32 * qt) * 4u);
-#pragma unroll
-            for (int s = 0; s < 2; s++) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[s], sacc[kt], 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        float sum = 0.f;
-        f32x16 oacc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) oacc[r] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < KT; kt++) {
-            u32x4 pf[2];   // P^T as the B operand: registers 8 s .. 8 s + 7 pairwise -> k-step s
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const float e0 = __builtin_amdgcn_exp2f(sacc[kt][r] - mx), e1 = __builtin_amdgcn_exp2f(sacc[kt][r + 1] - mx);   // scores carry log2(e)
-                sum += e0 + e1;
-                pf[r >> 3][(r & 7) >> 1] = pack_bf16(e0, e1);
+            for (int e = 0; e < 4; e++) {   // dword e of va / vb holds head dims 8 dg + 2 e, + 1
+                dst[(2 * e) * (VLD / 2)] = __builtin_amdgcn_perm(vb[it][e], va[it][e], 0x05040100u);       // (va.lo, vb.lo)
+                dst[(2 * e + 1) * (VLD / 2)] = __builtin_amdgcn_perm(vb[it][e], va[it][e], 0x07060302u);   // (va.hi, vb.hi)
             }
-#pragma unroll
-            for (int s = 0; s < 2; s++)
-                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], __builtin_bit_cast(bf16x8, pf[s]), oacc, 0, 0, 0);
         }
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = fast_rcp(sum);
-        // O^T tile: lane = query 32 qt + lrow, quad q = head dims 8 q + 4 half + {0..3}
-        const unsigned eoff = ((unsigned)tokr[qt] * (unsigned)C + (unsigned)(head * 32 + 4 * lhalf)) * 2u;
-        const bool qok = 32 * qt + lrow < Wt;
+        __builtin_amdgcn_wave_barrier();
+        // V^T fragments: lane (d = lrow, half), k-step (kt, s): positions 32 kt + 16 s + 8 half .. + 7
+        bf16x8 vf[KT][2];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            f32x4 o;
+        for (int kt = 0; kt < KT; kt++)
 #pragma unroll
-            for (int t = 0; t < 4; t++) o[t] = oacc[4 * q + t] * inv;
-            buf_store2(pack_bf16x4(o), rsO, qok ? eoff + 16u * q : 0x7fffffffu, 0u);
+            for (int s = 0; s < 2; s++) vf[kt][s] = *reinterpret_cast<const bf16x8 *>(vt + lrow * VLD + 32 * kt + 16 * s + 8 * lhalf);
+#pragma unroll
+        for (int qt = 0; qt < KT; qt++) {
+            if (32 * qt >= Wt) break;
+            bf16x8 qf[2];
+#pragma unroll
+            for (int s = 0; s < 2; s++) qf[s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsQ, rowoff[qt], hq + 32u * s));
+            f32x16 sacc[KT];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int kt = 0; kt < KT; kt++) {
+                // registers r, r + 1 (r even) are keys 32 kt + 8 (r >> 2) + 4 half + (r & 3), + 1: one fp16 pair
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int kp = (32 * kt + 8 * (r >> 2) + (r & 3)) / 2 + 2 * lhalf;
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 pk = __builtin_bit_cast(h2, bias_lds[kp * Wp + 32 * qt + lrow]);
+                    sacc[kt][r] = (float)pk[0]; sacc[kt][r + 1] = (float)pk[1];
+                }
+#pragma unroll
+                for (int s = 0; s < 2; s++) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[s], sacc[kt], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float sum = 0.f;
+            f32x16 oacc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[r] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KT; kt++) {
+                u32x4 pf[2];   // P^T as the B operand: registers 8 s .. 8 s + 7 pairwise -> k-step s
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float e0 = __builtin_amdgcn_exp2f(sacc[kt][r] - mx), e1 = __builtin_amdgcn_exp2f(sacc[kt][r + 1] - mx);   // scores carry log2(e)
+                    sum += e0 + e1;
+                    pf[r >> 3][(r & 7) >> 1] = pack_bf16(e0, e1);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; s++)
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], __builtin_bit_cast(bf16x8, pf[s]), oacc, 0, 0, 0);
+            }
+            sum += __shfl_xor(sum, 32, 64);
+            const float inv = fast_rcp(sum);
+            // O^T tile: lane = query 32 qt + lrow, quad q = head dims 8 q + 4 half + {0..3}
+            const unsigned eoff = ((unsigned)tokr[qt] * (unsigned)C + (unsigned)(head * 32 + 4 * lhalf)) * 2u;
+            const bool qok = 32 * qt + lrow < Wt;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 o;
+#pragma unroll
+                for (int t = 0; t < 4; t++) o[t] = oacc[4 * q + t] * inv;
+                buf_store2(pack_bf16x4(o), rsO, qok ? eoff + 16u * q : 0x7fffffffu, 0u);
+            }
         }
     }
 }
 
 bool launch_attn_bx(const void *qkv, const float *biasT, void *out, int B, const WinGeom &g, hipStream_t s) {
     const int nW = (g.res / g.ws) * (g.res / g.ws);
-    const int n_units = B * nW * g.heads;
-    const dim3 grid((n_units + 3) / 4), block(256);
-    if (g.C != 32 * g.heads || g.C % 8 != 0) return false;
-#define AX(KT_, WS_) hipLaunchKernelGGL((attn_bx_kernel<KT_, WS_>), grid, block, 0, s, (const __bf16 *)qkv, biasT, (__bf16 *)out, B, g, n_units)
+    if (g.C != 32 * g.heads || g.C % 8 != 0 || g.res % g.ws != 0) return false;
+    // one block per (window position, head, share of the batch): enough shares to fill the chip twice over, at least 4 samples each
+    const int pairs = nW * g.heads;
+    int split = std::max(1, std::min((B + 3) / 4, (2 * bx_cu_count() + pairs - 1) / pairs));
+    const dim3 grid(pairs * split), block(256);
+#define AX(KT_, WS_) hipLaunchKernelGGL((attn_bx_kernel<KT_, WS_>), grid, block, 0, s, (const __bf16 *)qkv, biasT, (__bf16 *)out, B, g, split)
     switch (g.ws) {
         case 4: AX(1, 4); break;
         case 5: AX(1, 5); break;

@@ -103,6 +103,17 @@ __device__ __forceinline__ void buf_store_bf16(float v, rsrc_t r, unsigned voff,
 }
 
 
+// fp32 -> bf16 (round to nearest even) two / four at a time with the hardware conversion (v_cvt_pk_bf16_f32): same values as
+// bf16_rne_hi for every finite input
+typedef unsigned u32x2_c __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {   // a in the low half
+    typedef __bf16 bf16x2_c __attribute__((ext_vector_type(2)));
+    typedef float f32x2_c __attribute__((ext_vector_type(2)));
+    const f32x2_c v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_c));
+}
+__device__ __forceinline__ u32x2_c pack_bf16x4(const f32x4 v) { u32x2_c r; r[0] = pack_bf16(v[0], v[1]); r[1] = pack_bf16(v[2], v[3]); return r; }
+
 // implemented in kernels_lp.hip: the bf16-MFMA GEMMs (g.Ws3: split-bf16, fp32-accurate; g.Wb: plain bf16 operands).
 // Returns false if the arguments do not select / fit one of them (the caller then runs the fp32 kernel).
 bool launch_gemm_lp(const GemmArgs &g, hipStream_t s);

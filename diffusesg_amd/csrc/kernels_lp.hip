@@ -508,6 +508,14 @@ void launch_f32_to_bf16(const float *src, void *dst, size_t n, hipStream_t s) {
 }
 
 
+__global__ void bf16_to_f32_kernel(const unsigned short *src, float *dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = __uint_as_float((unsigned)src[i] << 16);
+}
+void launch_bf16_to_f32(const void *src, float *dst, size_t n, hipStream_t s) {   // test / debug entries only
+    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned short *)src, dst, n);
+}
+
 static int round_up8(int x) { return (x + 7) / 8 * 8; }
 
 bool launch_gemm_lp(const GemmArgs &g_in, hipStream_t s) {

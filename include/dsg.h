@@ -199,6 +199,20 @@ int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node
 int dsg_debug_gemm(int32_t M, int32_t N, int32_t K, const float *A, const float *W, const float *bias, const float *ln_stats,
                    const float *res, int32_t act, int32_t mode, float *C, void *stream);
 
+/* The bf16 block pipeline's kernels on their own (test hooks, csrc/kernels_bx.hip; device pointers, synchronise `stream`).
+ * dsg_debug_gemm_bx: A [M,K], W [N,K] given as fp32 and rounded to bf16 inside; epilogue pieces as in the forward: bias [N], fp32
+ *   residual res [M,N], act (0 | 1 GELU), mod = (scale [N] | shift [N]) of a batch-uniform modulate+SiLU, ln_out (LayerNorm of the
+ *   stored row into out_Cb; N in {96,192,384}).  out_C [M,N] fp32 store; out_Cb / out_C2b [M,N]: the bf16 stores widened to fp32
+ *   (any may be NULL, not both of out_C / out_Cb).  DSG_ERR_INVALID when the shape is not covered.
+ * dsg_debug_attn_bx: window attention on qkv [B*res*res, 3*32*heads] (rounded to bf16 inside; q pre-scaled) with the key-major
+ *   log2(e)-scaled bias table [nW|1][heads][Wp][Wp] -> out [B*res*res, 32*heads] (the bf16 result widened).
+ * time_iters > 0 with out_ms (host): also the mean HIP-event time of that many back-to-back launches of the kernel (tools/bx_bench.py). */
+int dsg_debug_gemm_bx(int32_t M, int32_t N, int32_t K, const float *A, const float *W, const float *bias, const float *res, int32_t act,
+                      const float *mod, int32_t ln_out, float *out_C, float *out_Cb, float *out_C2b, int32_t time_iters, float *out_ms,
+                      void *stream);
+int dsg_debug_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int32_t heads, const float *qkv, const float *biasT, float *out,
+                      int32_t time_iters, float *out_ms, void *stream);
+
 /* The noise-conditioning path on its own (test / inspection hook for SURVEY fixture G1): PositionalEmbedding -> map_layer0/1 with
  * SiLU (R/model/diffusesg/diffusesg.py:507-513, :768-771) -> every `affine` linear (:238, :574) for `rows` noise labels c_noise
  * (device, [rows]).  out_pe [rows, embed_dim], out_emb [rows, 512], out_aff [rows, dsg_affine_width(h)] (any may be NULL):

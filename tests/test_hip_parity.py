@@ -522,21 +522,26 @@ def rms_rel(a, ref):
 
 @pytest.mark.parametrize("name", ["tiny", "small", "vg", "coco"])
 @pytest.mark.parametrize("fused", [1, 0])
-def test_bf16_gemm_mode_vs_reference(name, fused):
-    """opt-in precision mode (BASELINE config 5): bf16-MFMA GEMMs, fp32 accumulate -- looser, stated tolerance"""
+@pytest.mark.parametrize("pipe", [1, 0])
+def test_bf16_gemm_mode_vs_reference(name, fused, pipe):
+    """opt-in precision mode (BASELINE config 5): bf16-MFMA GEMMs, fp32 accumulate -- looser, stated tolerance.
+    pipe = 1: the bf16 block pipeline (csrc/kernels_bx.hip: bf16 tensors between kernels, LayerNorm in the producing GEMM's epilogue,
+    bf16-MFMA attention; the default of the mode); pipe = 0: round 2's kernels (csrc/kernels_lp.hip)"""
     from diffusesg_amd.model import build_network
     cfg, flags, adj, node, sc_adj, sc_node = Y.fwd_case(name)
     g = load(f"fwd_{name}.npz")
     net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda").model
     h = net._ensure_handle()
     h.set_option("gemm_bf16", 1)
+    h.set_option("bf16_pipe", pipe)
+    assert h.get_option("bf16_pipe") == pipe
     for opt in ("fused_attn", "fused_mlp", "fused_readout", "fused_patch_embed"):
         h.set_option(opt, fused)
     oa, on = net(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
     ea = assert_close(oa.cpu().numpy(), g["sc_adj_out"], BF16_MAX_RTOL, f"{name} adj (bf16 GEMMs)")
     en = assert_close(on.cpu().numpy(), g["sc_node_out"], BF16_MAX_RTOL, f"{name} node (bf16 GEMMs)")
     ra_, rn_ = rms_rel(oa.cpu().numpy(), g["sc_adj_out"]), rms_rel(on.cpu().numpy(), g["sc_node_out"])
-    print(f"bf16 {name} fused={fused}: max {ea:.2e}/{en:.2e} rms {ra_:.2e}/{rn_:.2e}")
+    print(f"bf16 {name} fused={fused} pipe={pipe}: max {ea:.2e}/{en:.2e} rms {ra_:.2e}/{rn_:.2e}")
     assert ra_ <= BF16_RMS_RTOL and rn_ <= BF16_RMS_RTOL
     if not fused:
         assert max(ea, en) > 1e-5, "bf16 mode did not engage (error is at the fp32 level)"
@@ -548,8 +553,42 @@ def test_bf16_gemm_mode_vs_reference(name, fused):
     assert_close(oa2.cpu().numpy(), g["sc_adj_out"], BF16_MAX_RTOL, f"{name} adj (bf16 GEMMs, row kernels)")
     h.set_option("fused_rowstats", 1)
     h.set_option("gemm_bf16", 0)
+    assert h.get_option("bf16_pipe") == 0   # reports what runs: nothing of it outside bf16 mode
     oa, on = net(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
     assert_close(oa.cpu().numpy(), g["sc_adj_out"], FWD_RTOL, f"{name} adj (back to fp32)")
+
+
+@pytest.mark.parametrize("name", ["small", "vg", "coco"])
+def test_bf16_pipeline_module_rows(name):
+    """The bf16 block pipeline block by block: with debug taps on, every block / PatchMerging / PatchBreakup output of the full-size
+    nets (and of the small net with its shifted 16-token windows) against the rows hooked from the reference's fp32 modules, at the
+    bf16 bar measured per tensor (5e-2 max / 1.5e-2 RMS of the tensor's scale).  Taps switch the producer-side modulate off, so this
+    also runs the pipeline's row-pass form (ln_bx with modulate) that the default forward only uses after PatchEmbed."""
+    cfg, flags, adj, node, sc_adj, sc_node = Y.fwd_case(name)
+    g = load(f"fwd_{name}.npz")
+    from diffusesg_amd.model import build_network
+    net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda").model
+    h = net._ensure_handle()
+    h.set_option("gemm_bf16", 1)
+    assert h.get_option("bf16_pipe") == 1
+    shapes = Y.tap_shapes(cfg)
+    full = name == "small"
+    keys = [k.split("/", 1)[1] for k in g.files if k.startswith("inter/" if full else "rows/")]
+    _, bufs = net.debug_forward(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node),
+                                taps={k: shapes[k][0] * shapes[k][1] for k in keys})
+    worst = 0.0
+    for k in keys:
+        Tk, Ck = shapes[k]
+        got = bufs[k].cpu().numpy().reshape(2 * Tk, Ck)
+        if full:
+            ref = g["inter/" + k]
+            ref = (ref.transpose(0, 2, 3, 1) if k == "read_out" else ref).reshape(2 * Tk, Ck)
+        else:
+            got, ref = got[Y.inter_rows(2 * Tk)], g["rows/" + k]
+        e, r = rel_err(got, ref), rms_rel(got, ref)
+        worst = max(worst, e)
+        assert e <= BF16_MAX_RTOL and r <= BF16_RMS_RTOL, f"{name} {k}: max {e:.2e} rms {r:.2e}"
+    assert worst > 1e-5, "bf16 mode did not engage"
 
 
 @pytest.mark.parametrize("name", ["tiny", "small", "nosc", "vg", "coco"])
@@ -848,6 +887,7 @@ def test_bf16_stored_activations_are_bit_identical(name):
     net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda").model
     h = net._ensure_handle()
     h.set_option("gemm_bf16", 1)
+    h.set_option("bf16_pipe", 0)   # (round 2's bf16 path; the bf16 block pipeline keeps every inter-kernel tensor in bf16 by construction)
     args = (T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
     for fused in (1, 0):
         for opt in ("fused_attn", "fused_mlp", "fused_qkv_attn"):
