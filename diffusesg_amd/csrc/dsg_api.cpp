@@ -136,6 +136,10 @@ struct dsg_handle_s {
     float *tab_sig = nullptr, *tab_cn = nullptr, *tab_pe = nullptr, *tab_e0 = nullptr, *tab_e1 = nullptr, *tab_aff = nullptr;
     StepRow *tab_step = nullptr;   // per-step scalars of the loop, read by the table-driven sampler kernels
     std::vector<Tap> taps;
+    // training form (dsg_train_*): saved-activation arena and backward scratch, owned by the handle and kept between calls
+    // (hipMalloc / hipFree of ~10 GB per iteration cost more than a tenth of it); they only grow
+    float *train_arena = nullptr, *train_scr = nullptr;
+    size_t train_arena_cap = 0, train_scr_cap = 0;
     dsg_sample_stats last_stats{};
     // per-kernel-class timing (dsg_profile_forward): HIP events bracketing every launch on the launch stream
     bool prof_on = false;          // HIP-event brackets around every launch
@@ -550,6 +554,8 @@ void dsg_destroy(dsg_handle h) {
     for (float *q : {h->tab_sig, h->tab_cn, h->tab_pe, h->tab_e0, h->tab_e1, h->tab_aff}) if (q) (void)hipFree(q);
     drop_graphs(h);
     if (h->tab_step) (void)hipFree(h->tab_step);
+    if (h->train_arena) (void)hipFree(h->train_arena);
+    if (h->train_scr) (void)hipFree(h->train_scr);
     for (auto &kv : h->ws) {
         if (kv.second->cap_stream) (void)hipStreamDestroy(kv.second->cap_stream);
         for (void *p : kv.second->allocs) (void)hipFree(p);
@@ -977,7 +983,7 @@ void embed_rows(dsg_handle h, const float *c_noise, int rows, float *pe, float *
 // input assembly + PatchEmbed (diffusesg.py:784-802, 562-577) -> w->x.  Returns true when the first block's modulate+SiLU rode
 // along (fused kernel only).  fp32 path: only when that block is the fused C = 96 attention kernel (which then skips it);
 // any_first_block: whatever the first block is (the bf16 block pipeline normalises the modulated tensor in its own row pass).
-bool patch_embed_stage(dsg_handle h, Workspace *w, bool fp32_rule, hipStream_t s) {
+bool patch_embed_stage(dsg_handle h, Workspace *w, bool fp32_rule, hipStream_t s, bool *xn_done = nullptr) {
     const dsg_config &c = h->cfg;
     const int B = w->B, N = h->N, E = h->E, T0 = N * N;
     GemmArgs g;
@@ -990,8 +996,9 @@ bool patch_embed_stage(dsg_handle h, Workspace *w, bool fp32_rule, hipStream_t s
         pe_done = launch_fused_patch_embed96(w->in_adj, w->in_node, w->cur_sc_adj, w->cur_sc_node, w->cur_has_sc, w->flags, h->pe_wp,
                                              WT(h, "patch_embed.proj.bias"), WT(h, "patch_embed.norm.weight"),
                                              WT(h, "patch_embed.norm.bias"), w->aff, w->aff_ld, h->pe_aff_off, pe_premod ? b0->aff_off : -1,
-                                             w->x, B, N, h->Ca, h->Cn, c.self_condition, h->Kp, s);
+                                             w->x, B, N, h->Ca, h->Cn, c.self_condition, h->Kp, s, (xn_done && pe_premod) ? w->xn : nullptr);
         pe_premod = pe_premod && pe_done;
+        if (xn_done) *xn_done = pe_premod;
     }
     if (!pe_done) {
         P_KERN(PK_ELEM, 0.0, launch_assemble(w->in_adj, w->in_node, w->cur_sc_adj, w->cur_sc_node, w->cur_has_sc, w->flags, w->tok_in, B, N, h->Ca, h->Cn,
@@ -1131,7 +1138,8 @@ void forward_fixed_bx(dsg_handle h, Workspace *w, hipStream_t s) {
     BxGemm g;
     w->aff_ld = w->uniform ? 0 : h->aff_n;
     if (!w->uniform) embed_rows(h, w->c_noise, B, w->pe, w->emb0, w->emb, w->aff, s);
-    BxState st = patch_embed_stage(h, w, false, s) ? BX_MOD : BX_RAW;
+    bool xn_done = false;   // the fused PatchEmbed kernel also leaves block 0's LayerNorm-1 input when it applies that block's modulate
+    BxState st = patch_embed_stage(h, w, false, s, &xn_done) ? (xn_done ? BX_READY : BX_MOD) : BX_RAW;
     tap(h, "patch_embed", w->x, (size_t)B * T0 * E, s);
     // encoder (diffusesg.py:745-748); skips are stored as bf16 (their only reader is PatchBreakup's pre_linear)
     for (int l = 0; l < L; l++) {
@@ -1196,7 +1204,6 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     // the fused PatchMerging writes the coarser level into the other activation buffer and swaps the two names; put them back
     // on every exit so that each forward (and each captured graph) starts from the same assignment
     struct SwapGuard { Workspace *w; float *x, *y; ~SwapGuard() { w->x = x; w->y = y; } } swap_guard{w, w->x, w->y};
-    const dsg_config &c = h->cfg;
     const int B = w->B, N = h->N, E = h->E, L = h->L, T0 = N * N;
     char name[64];
     GemmArgs g;
@@ -1968,6 +1975,7 @@ int dsg_block_train(dsg_handle h, const char *block, int32_t B, const float *x_i
     const hipError_t e = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(scratch);
     HIP_TRY(h, e);
+    if (t_scratch_failed((hipStream_t)stream, true)) return fail(h, DSG_ERR_HIP, "out of memory (training scratch of this stream)");
     if (!ok) return fail(h, DSG_ERR_HIP, "train_block failed (window larger than 128 tokens or a launch error)");
     return DSG_OK;
 }
@@ -2072,39 +2080,35 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
             if (!missing.empty()) return fail(h, DSG_ERR_INVALID, "missing tensor '%s'", missing.c_str());
             // scratch for the backward: the widest [M, 4C] tensors of any stage, three of them, + block scratch
             A.cap = A.off;
-            // the saved-activation arena and the backward scratch are kept between calls (hipMalloc / hipFree of ~10 GB per
-            // iteration cost more than a tenth of it); one training stream per process
-            static float *arena_keep = nullptr; static size_t arena_cap = 0;
-            if (A.cap + 16 > arena_cap) {
-                if (arena_keep) (void)hipFree(arena_keep);
-                arena_keep = nullptr; arena_cap = 0;
-                HIP_TRY(h, hipMalloc((void **)&arena_keep, sizeof(float) * (A.cap + 16)));
-                arena_cap = A.cap + 16;
+            // the saved-activation arena and the backward scratch belong to the handle and are kept between calls
+            if (A.cap + 16 > h->train_arena_cap) {
+                if (h->train_arena) { (void)hipStreamSynchronize(s); (void)hipFree(h->train_arena); }
+                h->train_arena = nullptr; h->train_arena_cap = 0;
+                HIP_TRY(h, hipMalloc((void **)&h->train_arena, sizeof(float) * (A.cap + 16)));
+                h->train_arena_cap = A.cap + 16;
             }
-            A.base = arena_keep;
+            A.base = h->train_arena;
             HIP_TRY(h, hipMalloc((void **)&has_sc_dev, sizeof(int)));
             HIP_TRY(h, hipMemcpy(has_sc_dev, &has_sc_host, sizeof(int), hipMemcpyHostToDevice));
         }
     }
     // widest scratch tensors (backward): sized for level 0's [M0, 4E]; every level has M C constant up to the 2x of merging
     size_t wide = M0 * (size_t)(4 * E);
-    static float *scr_keep = nullptr; static size_t scr_cap = 0;
     const size_t scr_need = wide * 3 + M0 * (size_t)E * 8 + 4096;
-    if (scr_need > scr_cap) {
-        if (scr_keep) (void)hipFree(scr_keep);
-        scr_keep = nullptr; scr_cap = 0;
-        if (hipMalloc((void **)&scr_keep, sizeof(float) * scr_need) != hipSuccess) { (void)hipFree(has_sc_dev); return fail(h, DSG_ERR_HIP, "out of memory"); }
-        scr_cap = scr_need;
+    if (scr_need > h->train_scr_cap) {
+        if (h->train_scr) { (void)hipStreamSynchronize(s); (void)hipFree(h->train_scr); }
+        h->train_scr = nullptr; h->train_scr_cap = 0;
+        if (hipMalloc((void **)&h->train_scr, sizeof(float) * scr_need) != hipSuccess) { (void)hipFree(has_sc_dev); return fail(h, DSG_ERR_HIP, "out of memory"); }
+        h->train_scr_cap = scr_need;
     }
-    float *scr = scr_keep;
+    float *scr = h->train_scr;
     float *t_mh = scr, *t_m3c = scr + wide, *t_w = scr + 2 * wide, *t_mc = scr + 3 * wide, *t_mc2 = t_mc + M0 * E * 2, *d_x = t_mc2 + M0 * E * 2,
           *d_y = d_x + M0 * E * 2;
     auto lin_fwd = [&](const float *x, const float *Wm, const float *bias, float *y, size_t M, int in, int out) {
         t_gemm(false, true, x, in, Wm, in, bias, y, out, (int)M, out, in, false, s);
     };
     auto lin_bwd = [&](const float *x, const float *Wm, const float *dy, float *dx, float *dW, float *db, size_t M, int in, int out) {
-        t_gemm(true, false, dy, out, x, in, nullptr, dW, in, out, in, (int)M, false, s);           // dW [out,in] = dy^T x
-        if (db) t_colsum(dy, out, db, (int)M, out, s);
+        t_gemm(true, false, dy, out, x, in, nullptr, dW, in, out, in, (int)M, false, s, db);       // dW [out,in] = dy^T x, db = colsum(dy)
         if (dx) t_gemm(false, false, dy, out, Wm, in, nullptr, dx, in, (int)M, in, out, false, s);   // dx = dy W
     };
     bool ok = true;
@@ -2287,6 +2291,7 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
     HIP_TRY(h, e);
     HIP_TRY(h, e2);
     if (!ok) return fail(h, DSG_ERR_HIP, "a training kernel failed to launch");
+    if (t_scratch_failed(s, true)) return fail(h, DSG_ERR_HIP, "out of memory (training scratch of this stream)");
     return DSG_OK;
 }
 

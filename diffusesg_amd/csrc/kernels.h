@@ -99,7 +99,8 @@ void launch_fused_mlp(float *x, const float *gam, const float *bet, const float 
 bool launch_fused_patch_embed96(const float *adj, const float *node, const float *sc_adj, const float *sc_node, const int *has_sc,
                                 const uint8_t *flags, const float *Wp, const float *bias, const float *gam, const float *bet,
                                 const float *aff, int aff_ld, int aff_off, int aff_off2, float *x, int B, int N, int Ca, int Cn,
-                                int self_cond, int Kp, hipStream_t s);   // aff_off2 >= 0: also apply that block's modulate+SiLU
+                                int self_cond, int Kp, hipStream_t s, void *xn = nullptr);   // aff_off2 >= 0: also apply that block's
+                                // modulate+SiLU; xn (bf16 [B*N*N, 96]): also the LayerNorm (no affine) of the stored row (bf16 pipeline)
 // final LN + folded read_out/adj-head chain + masked adjacency output, and the LN(x) pooling for the node head (E = 96)
 // pool_part [B*N][readout_pool_segments(N)][96]: per-tile partial sums, reduced in fixed order into pool_ext [B*N,128]
 int readout_pool_segments(int N);
@@ -201,8 +202,12 @@ struct TrainBlockArgs {
 bool train_block(const TrainBlockArgs &a, hipStream_t s);            // forward; + backward when a.grad_out is set
 bool train_block_backward(const TrainBlockArgs &a, hipStream_t s);   // backward alone, from the tensors the forward left in `a`
 // building blocks of the whole-network training step (same file): C (+)= op(A) op(B) (+ bias), column sums, elementwise / row ops
+// a_colsum (weight-gradient products, ta && !tb): also out[m] = sum_k A[k][m], the bias gradient that goes with dW = dy^T x
 void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K,
-            bool accumulate, hipStream_t s);
+            bool accumulate, hipStream_t s, float *a_colsum = nullptr);
+// scratch of the training kernels is kept per stream (train_kernels.hip); a failed allocation is reported here, once
+bool t_scratch_failed(hipStream_t s, bool clear);
+void t_scratch_release();
 void t_colsum(const float *X, int ld, float *out, int M, int N, hipStream_t s);
 void t_silu(const float *x, const float *dy, float *out, size_t n, bool bwd, hipStream_t s);
 void t_gelu(const float *x, const float *dy, float *out, size_t n, bool bwd, hipStream_t s);

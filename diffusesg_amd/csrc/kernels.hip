@@ -1121,7 +1121,8 @@ __global__ __launch_bounds__(256, 2) void fused_patch_embed96_kernel(const float
                                                                     const float *__restrict__ Wp, const float *__restrict__ bias,
                                                                     const float *__restrict__ gam, const float *__restrict__ bet,
                                                                     const float *__restrict__ aff, int aff_ld, int aff_off, int aff_off2,
-                                                                    float *__restrict__ x, int B, int N, int Ca_rt, int Cn_rt, int self_cond) {
+                                                                    float *__restrict__ x, int B, int N, int Ca_rt, int Cn_rt, int self_cond,
+                                                                    void *__restrict__ xn) {
     constexpr int C = 96, S = KP / 8;
     const int Ca = CA > 0 ? CA : Ca_rt, Cn = CN > 0 ? CN : Cn_rt;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1188,6 +1189,7 @@ __global__ __launch_bounds__(256, 2) void fused_patch_embed96_kernel(const float
     if (!ok) return;
     const float *scale = aff + (size_t)b * aff_ld + aff_off + 4 * lhalf, *shift = scale + C;
     float *xr = x + (size_t)m * C + 4 * lhalf;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 3; nt++)
 #pragma unroll
@@ -1210,16 +1212,35 @@ __global__ __launch_bounds__(256, 2) void fused_patch_embed96_kernel(const float
                 for (int t = 0; t < 4; t++) o[t] = silu_exact(sh2[t] + o[t] * (sc2[t] + 1.0f));
             }
             *reinterpret_cast<f32x4 *>(xr + e) = o;
+            if (xn) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) { acc[nt][4 * g + t] = o[t]; s1 += o[t]; s2 = fmaf(o[t], o[t], s2); }
+            }
         }
+    if (xn) {   // bf16 block pipeline: LayerNorm-1 (no affine) of the stored row as the bf16 tensor the first QKV GEMM reads
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float mu = s1 * (1.0f / C), rs = fast_rsqrt(fmaxf(fmaf(-mu, mu, s2 * (1.0f / C)), 0.f) + LN_EPS), nmr = -mu * rs;
+        u32x2_c *dst = reinterpret_cast<u32x2_c *>(reinterpret_cast<unsigned short *>(xn) + (size_t)m * C + 4 * lhalf);
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                f32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = fmaf(acc[nt][4 * g + t], rs, nmr);
+                dst[(32 * nt + 8 * g) / 4] = pack_bf16x4(v);
+            }
+    }
 }
 
 bool launch_fused_patch_embed96(const float *adj, const float *node, const float *sc_adj, const float *sc_node, const int *has_sc,
                                 const uint8_t *flags, const float *Wp, const float *bias, const float *gam, const float *bet,
                                 const float *aff, int aff_ld, int aff_off, int aff_off2, float *x, int B, int N, int Ca, int Cn,
-                                int self_cond, int Kp, hipStream_t s) {
+                                int self_cond, int Kp, hipStream_t s, void *xn) {
     const int M = B * N * N;
     const dim3 grid((M + 127) / 128), block(256);
-#define PE_ARGS adj, node, sc_adj, sc_node, has_sc, flags, Wp, bias, gam, bet, aff, aff_ld, aff_off, aff_off2, x, B, N, Ca, Cn, self_cond
+#define PE_ARGS adj, node, sc_adj, sc_node, has_sc, flags, Wp, bias, gam, bet, aff, aff_ld, aff_off, aff_off2, x, B, N, Ca, Cn, self_cond, xn
     if (Kp == 64 && Ca == 6 && Cn == 12) hipLaunchKernelGGL((fused_patch_embed96_kernel<64, 6, 12>), grid, block, 0, s, PE_ARGS);       // VG bits
     else if (Kp == 64 && Ca == 3 && Cn == 12) hipLaunchKernelGGL((fused_patch_embed96_kernel<64, 3, 12>), grid, block, 0, s, PE_ARGS);  // COCO bits
     else if (Kp == 32) hipLaunchKernelGGL((fused_patch_embed96_kernel<32>), grid, block, 0, s, PE_ARGS);

@@ -12,8 +12,53 @@
 
 #include <stdio.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace dsg {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Scratch of the training kernels (split-K partials, transposed weights, column-sum partials): one set PER STREAM.  Work
+// on a stream is serialised, so launches that share a set never overlap; two streams (or two handles driven from two
+// streams) get two sets.  Buffers only grow; a failed allocation marks the stream's set (t_scratch_failed) and the launch
+// that needed it is skipped -- the C entry point then returns DSG_ERR_HIP instead of producing garbage.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TScratch {
+    float *sk = nullptr;  size_t sk_cap = 0;    // split-K partial products / transposed slices
+    float *wt = nullptr;  size_t wt_cap = 0;    // transposed weight of a dx product
+    double *cs = nullptr; size_t cs_cap = 0;    // column-sum / modulate-gradient partials
+    void *opt = nullptr;  size_t opt_cap = 0;   // optimiser step: tensor table + partial sums
+    bool failed = false;
+};
+static std::mutex g_ts_mutex;
+static std::map<hipStream_t, TScratch> g_ts;
+static TScratch &t_scratch(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_ts_mutex);
+    return g_ts[s];
+}
+template <typename T>
+static T *t_scratch_get(hipStream_t s, T *&buf, size_t &cap, size_t need, TScratch &ts) {
+    if (need > cap) {
+        // the previous buffer may still be read by work queued on this stream: drain it before freeing
+        if (buf) { (void)hipStreamSynchronize(s); (void)hipFree(buf); }
+        buf = nullptr; cap = 0;
+        if (hipMalloc((void **)&buf, sizeof(T) * need) == hipSuccess) cap = need;
+        else { buf = nullptr; ts.failed = true; }
+    }
+    return buf;
+}
+bool t_scratch_failed(hipStream_t s, bool clear) {
+    TScratch &ts = t_scratch(s);
+    const bool f = ts.failed;
+    if (clear) ts.failed = false;
+    return f;
+}
+void t_scratch_release() {   // dsg_destroy of the last handle / tests
+    std::lock_guard<std::mutex> lk(g_ts_mutex);
+    for (auto &kv : g_ts) { (void)hipFree(kv.second.sk); (void)hipFree(kv.second.wt); (void)hipFree(kv.second.cs); (void)hipFree(kv.second.opt); }
+    g_ts.clear();
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // C[M,N] (+)= op(A) op(B) (+ bias[n]);  op(A)(m,k) = TA ? A[k*lda+m] : A[m*lda+k];  op(B)(k,n) = TB ? B[n*ldb+k] : B[k*ldb+n]
@@ -74,9 +119,6 @@ __global__ void t_splitk_reduce_kernel(const float *part, float *C, int ldc, int
     for (int z = 0; z < S; z++) v += part[(size_t)z * M * N + i];
     C[(size_t)m * ldc + n] = v;
 }
-static float *g_sk_scratch = nullptr;
-static size_t g_sk_cap = 0;
-
 // [R][Cc] -> [Cc][R] (weights on their way into the MFMA GEMM, which wants both operands K-contiguous)
 __global__ __launch_bounds__(256) void t_transpose_kernel(const float *src, int ld, float *dst, int R, int Cc) {
     __shared__ float tile[32][33];
@@ -100,11 +142,114 @@ __global__ __launch_bounds__(256) void t_transpose_sliced_kernel(const float *sr
     for (int i = ty; i < 32; i += 8)
         if (c0 + i < Cc && k0 + tx < kslice) dst[((size_t)z * Cc + c0 + i) * kslice + k0 + tx] = tile[tx][i];
 }
-static float *g_wt_scratch = nullptr;
-static size_t g_wt_cap = 0;
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradients on the f32 matrix pipe without transposes:  C[M,N] = sum_k A[k][m] B[k][n]  (dW = dy^T x: A = dy [tokens, out],
+// B = x [tokens, in], both as the forward left them, K = tokens).  v_mfma_f32_32x32x2_f32 takes ONE value per lane and operand
+// (lane l: A[row l&31][k l>>5], B[k l>>5][col l&31]), so with K-major tiles in LDS ([k][m] / [k][n]) a fragment is one
+// conflict-free ds_read_b32 of 32 consecutive floats per k -- the operand layout the token-major activations already have.
+// Block tile 128 (m) x 96 (n), wave tile 32 x 96, k chunks of 32, register-staged double buffer; split-K over blockIdx (slice z
+// writes its partial product to Cp + z M N, added in slice order afterwards: deterministic).  CS: the block column tn == 0 also
+// leaves the column sums of its A slice, sum_k A[k][m] (the bias gradient db = colsum(dy)), in cs_part[z][m].
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool CS>
+__global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                             float *__restrict__ Cp, int M, int N, int K, int kslice, int tiles_m, int tiles_n,
+                                                             float *__restrict__ cs_part) {
+    constexpr int BM = 128, BN = 96, BK = 32;
+    __shared__ __attribute__((aligned(16))) float lds[2][BK * (BM + BN)];
+    const int tiles = tiles_m * tiles_n;
+    const int z = blockIdx.x / tiles, t = blockIdx.x % tiles, tm = t / tiles_n, tn = t % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kb = z * kslice, ke = min(K, kb + kslice);
+    const int nk = (ke - kb + BK - 1) / BK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    // rows [kb, ke) of A / B; rows past the slice and columns past M / N read as zero
+    const rsrc_t rsA = make_rsrc(A + (size_t)kb * lda, (unsigned)(ke - kb) * lda * 4u);
+    const rsrc_t rsB = make_rsrc(B + (size_t)kb * ldb, (unsigned)(ke - kb) * ldb * 4u);
+    unsigned voffA[4], voffB[3];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int idx = tid + 256 * p, kr = idx >> 5, c4 = idx & 31;
+        voffA[p] = (m0 + 4 * c4 < M) ? ((unsigned)kr * lda + (unsigned)(m0 + 4 * c4)) * 4u : 0x7fffffffu;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        const int idx = tid + 256 * p, kr = idx / 24, c4 = idx % 24;
+        voffB[p] = (n0 + 4 * c4 < N) ? ((unsigned)kr * ldb + (unsigned)(n0 + 4 * c4)) * 4u : 0x7fffffffu;
+    }
+    f32x4 sa[4], sb[3];
+    auto issue = [&](int kc) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) sa[p] = buf_load4(rsA, voffA[p], (unsigned)kc * BK * lda * 4u);
+#pragma unroll
+        for (int p = 0; p < 3; p++) sb[p] = buf_load4(rsB, voffB[p], (unsigned)kc * BK * ldb * 4u);
+    };
+    auto write = [&](int buf) {
+        float *As = lds[buf], *Bs = As + BK * BM;
+#pragma unroll
+        for (int p = 0; p < 4; p++) { const int idx = tid + 256 * p; *reinterpret_cast<f32x4 *>(As + (idx >> 5) * BM + 4 * (idx & 31)) = sa[p]; }
+#pragma unroll
+        for (int p = 0; p < 3; p++) { const int idx = tid + 256 * p; *reinterpret_cast<f32x4 *>(Bs + (idx / 24) * BN + 4 * (idx % 24)) = sb[p]; }
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
+    float asum = 0.f;
+    if (nk > 0) {
+        issue(0);
+        write(0);
+        __syncthreads();
+    }
+    for (int kc = 0; kc < nk; kc++) {
+        const int cur = kc & 1;
+        if (kc + 1 < nk) issue(kc + 1);
+        const float *As = lds[cur] + lhalf * BM + wave * 32 + lrow, *Bs = lds[cur] + BK * BM + lhalf * BN + lrow;
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 2; s2++) {
+            const float a = As[2 * s2 * BM];
+            if (CS) asum += a;
+#pragma unroll
+            for (int j = 0; j < 3; j++) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[2 * s2 * BN + 32 * j], acc[j], 0, 0, 0);
+        }
+        if (kc + 1 < nk) write(1 - cur);
+        __syncthreads();
+    }
+    // partial product of this slice: rows m0 + 32 wave + (r&3) + 8 (r>>2) + 4 half, columns n0 + 32 j + lrow
+    float *Cz = Cp + (size_t)z * M * N;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int n = n0 + 32 * j + lrow;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            if (m < M && n < N) Cz[(size_t)m * N + n] = acc[j][r];
+        }
+    }
+    if (CS && tn == 0) {
+        asum += __shfl_xor(asum, 32, 64);
+        const int m = m0 + 32 * wave + lrow;
+        if (lhalf == 0 && m < M) cs_part[(size_t)z * M + m] = asum;
+    }
+}
+// out[i] = sum_z part[z][i]  (fixed order)
+__global__ void t_slices_sum_kernel(const float *part, float *out, int n, int S) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int z = 0; z < S; z++) v += part[(size_t)z * n + i];
+    out[i] = v;
+}
 
 void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K,
-            bool accumulate, hipStream_t s) {
+            bool accumulate, hipStream_t s, float *a_colsum) {
+    TScratch &ts = t_scratch(s);
+    bool colsum_done = false;
+    struct ColsumAfter { const float *A; int lda, M, K; float *out; hipStream_t s; bool *done; bool ta;
+        ~ColsumAfter() { if (out && !*done) t_colsum(A, lda, out, K, M, s); } } colsum_after{A, lda, M, K, a_colsum, s, &colsum_done, ta};
+    (void)colsum_after;   // a_colsum (dW products only: out[m] = sum_k A[k][m]) is produced by the MFMA kernel below or, on the fallbacks, by t_colsum
     // The activation-side products y = x W^T and dx = dy W have the sampling path's GEMM form (A [M,K] row-major, second operand
     // [N,K]): large ones go to gemm4_f32_kernel (dx after transposing the weight into a scratch tile).  The weight-gradient
     // products (ta: K = tokens) and everything small or oddly shaped stay on the plain kernel below.
@@ -114,16 +259,11 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
         bool ok = true;
         if (tb) ok = ldb == K;
         else {
-            const size_t need = (size_t)N * K;
-            if (need > g_wt_cap) {
-                if (g_wt_scratch) (void)hipFree(g_wt_scratch);   // (the stream has been drained by the callers' end-of-step sync before a larger model shows up)
-                g_wt_cap = 0; g_wt_scratch = nullptr;
-                if (hipMalloc((void **)&g_wt_scratch, sizeof(float) * need) == hipSuccess) g_wt_cap = need;
-            }
-            ok = g_wt_cap >= need;
+            float *wt = t_scratch_get(s, ts.wt, ts.wt_cap, (size_t)N * K, ts);
+            ok = wt != nullptr;
             if (ok) {
-                hipLaunchKernelGGL(t_transpose_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, s, B, ldb, g_wt_scratch, K, N);   // B [K][N] -> [N][K]
-                Wop = g_wt_scratch;
+                hipLaunchKernelGGL(t_transpose_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, s, B, ldb, wt, K, N);   // B [K][N] -> [N][K]
+                Wop = wt;
             }
         }
         if (ok) {
@@ -134,30 +274,25 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
             return;
         }
     }
-    // Weight gradients dW [M = out, N = in] = dy^T x with K = tokens: both operands are transposed into K-contiguous slices
-    // ([S][rows][kslice], zero-padded tail) and the S slice products run as ONE batched launch of the sampling path's MFMA GEMM
-    // (gemm4_f32_kernel AMODE 2); the partial products are then added in slice order.
-    if (use_mfma && ta && !tb && !bias && K >= 4096 && M % 32 == 0 && N % 32 == 0) {
-        int S = std::min(256, std::max(1, (int)(((size_t)K * 48) / ((size_t)M * N) + 1)));   // enough tiles to fill the chip, slices >= 512 long
-        S = std::min(S, K / 512);
+    // Weight gradients dW [M = out, N = in] = dy^T x with K = tokens: gemm_tn_f32_kernel reads both token-major operands as they
+    // are (no transposed copies), S slices of K in one launch, partial products added in slice order.
+    if (use_mfma && ta && !tb && !bias && K >= 2048 && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0) {
+        const int tiles_m = (M + 127) / 128, tiles_n = (N + 95) / 96;
+        int S = std::max(1, std::min(256, 1024 / (tiles_m * tiles_n)));   // ~1024 blocks: two rounds of the chip's 512 slots
+        S = std::max(1, std::min(S, K / 512));
         const int kslice = ((K + S - 1) / S + 31) / 32 * 32;
         S = (K + kslice - 1) / kslice;
-        const size_t nA = (size_t)S * M * kslice, nB = (size_t)S * N * kslice, nC = (size_t)S * M * N, need = nA + nB + nC;
-        if (need > g_sk_cap) {
-            if (g_sk_scratch) (void)hipFree(g_sk_scratch);
-            g_sk_cap = 0; g_sk_scratch = nullptr;
-            if (hipMalloc((void **)&g_sk_scratch, sizeof(float) * need) == hipSuccess) g_sk_cap = need;
-        }
-        if (g_sk_cap >= need) {
-            float *At = g_sk_scratch, *Bt = At + nA, *Cp = Bt + nB;
-            hipLaunchKernelGGL(t_transpose_sliced_kernel, dim3((M + 31) / 32, (kslice + 31) / 32, S), dim3(256), 0, s, A, lda, At, K, M, kslice);
-            hipLaunchKernelGGL(t_transpose_sliced_kernel, dim3((N + 31) / 32, (kslice + 31) / 32, S), dim3(256), 0, s, B, ldb, Bt, K, N, kslice);
-            GemmArgs g;
-            g.A = At; g.lda = kslice; g.K1 = kslice; g.K = kslice; g.M = M; g.N = N; g.W = Bt; g.C = Cp; g.ldc = N;
-            g.batch = S; g.batch_strideA = (size_t)M * kslice; g.batch_strideW = (size_t)N * kslice; g.batch_strideC = (size_t)M * N;
-            launch_gemm(g, s);
-            hipLaunchKernelGGL(t_splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, Cp, C, ldc, M, N, S,
-                               (int)accumulate);
+        const size_t nC = (size_t)S * M * N, nS = a_colsum ? (size_t)S * M : 0;
+        float *buf = t_scratch_get(s, ts.sk, ts.sk_cap, nC + nS, ts);
+        if (buf) {
+            const dim3 grid((unsigned)(tiles_m * tiles_n * S));
+            if (a_colsum) hipLaunchKernelGGL((gemm_tn_f32_kernel<true>), grid, dim3(256), 0, s, A, lda, B, ldb, buf, M, N, K, kslice, tiles_m, tiles_n, buf + nC);
+            else hipLaunchKernelGGL((gemm_tn_f32_kernel<false>), grid, dim3(256), 0, s, A, lda, B, ldb, buf, M, N, K, kslice, tiles_m, tiles_n, nullptr);
+            hipLaunchKernelGGL(t_splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, buf, C, ldc, M, N, S, (int)accumulate);
+            if (a_colsum) {
+                hipLaunchKernelGGL(t_slices_sum_kernel, dim3((M + 255) / 256), dim3(256), 0, s, buf + nC, a_colsum, M, S);
+                colsum_done = true;
+            }
             return;
         }
     }
@@ -171,13 +306,8 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
         S = min(64, K / 1024);
         kslice = ((K + S - 1) / S + 31) / 32 * 32;
         S = (K + kslice - 1) / kslice;
-        const size_t need = (size_t)S * M * N;
-        if (need > g_sk_cap) {
-            if (g_sk_scratch) (void)hipFree(g_sk_scratch);
-            g_sk_cap = 0; g_sk_scratch = nullptr;
-            if (hipMalloc((void **)&g_sk_scratch, sizeof(float) * need) == hipSuccess) g_sk_cap = need;
-        }
-        if (g_sk_cap >= need) { Cout = g_sk_scratch; ldo = N; grid.z = S; } else { S = 1; kslice = 0; }
+        float *buf = t_scratch_get(s, ts.sk, ts.sk_cap, (size_t)S * M * N, ts);
+        if (buf) { Cout = buf; ldo = N; grid.z = S; } else { S = 1; kslice = 0; }
     }
     const int acc1 = S > 1 ? 0 : (int)accumulate;
     if (!ta && !tb) hipLaunchKernelGGL((t_gemm_kernel<false, false>), grid, block, 0, s, A, lda, B, ldb, bias, Cout, ldo, M, N, K, acc1, kslice);
@@ -185,11 +315,12 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
     else if (ta && !tb) hipLaunchKernelGGL((t_gemm_kernel<true, false>), grid, block, 0, s, A, lda, B, ldb, bias, Cout, ldo, M, N, K, acc1, kslice);
     else hipLaunchKernelGGL((t_gemm_kernel<true, true>), grid, block, 0, s, A, lda, B, ldb, bias, Cout, ldo, M, N, K, acc1, kslice);
     if (S > 1)
-        hipLaunchKernelGGL(t_splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, g_sk_scratch, C, ldc, M, N, S,
+        hipLaunchKernelGGL(t_splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, ts.sk, C, ldc, M, N, S,
                            (int)accumulate);
 }
 
-// out[n] = sum_m X[m*ld + n]: row chunks summed by separate blocks (double, fixed order inside a chunk), then the chunks in order
+// out[n] = sum_m X[m*ld + n]: row chunks summed by separate blocks (double, fixed order inside a chunk), then the chunks in order.
+// Stage 1: block = 64 columns x 4 row lanes over one chunk of rows; stage 2: block = 64 columns x 4 lanes over the chunks.
 __global__ __launch_bounds__(256) void t_colsum_part_kernel(const float *X, int ld, double *part, int M, int N, int rows_per) {
     __shared__ double red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
@@ -200,26 +331,27 @@ __global__ __launch_bounds__(256) void t_colsum_part_kernel(const float *X, int 
     __syncthreads();
     if (q == 0 && c < N) part[(size_t)blockIdx.y * N + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void t_colsum_final_kernel(const double *part, float *out, int N, int R) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+__global__ __launch_bounds__(256) void t_colsum_final_kernel(const double *part, float *out, int N, int R) {
+    __shared__ double red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
     double sacc = 0.0;
-    for (int r = 0; r < R; r++) sacc += part[(size_t)r * N + n];
-    out[n] = (float)sacc;
+    if (c < N) for (int r = q; r < R; r += 4) sacc += part[(size_t)r * N + c];
+    red[q][threadIdx.x & 63] = sacc;
+    __syncthreads();
+    if (q == 0 && c < N) out[c] = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
-static double *g_cs_scratch = nullptr;
-static size_t g_cs_cap = 0;
 void t_colsum(const float *X, int ld, float *out, int M, int N, hipStream_t s) {
-    const int rows_per = max(64, (M + 255) / 256), R = (M + rows_per - 1) / rows_per;
-    const size_t need = (size_t)R * N;
-    if (need > g_cs_cap) {
-        if (g_cs_scratch) (void)hipFree(g_cs_scratch);
-        g_cs_cap = 0; g_cs_scratch = nullptr;
-        if (hipMalloc((void **)&g_cs_scratch, sizeof(double) * need) == hipSuccess) g_cs_cap = need;
-    }
-    if (g_cs_cap < need) { fprintf(stderr, "dsg: t_colsum: out of memory\n"); abort(); }
-    hipLaunchKernelGGL(t_colsum_part_kernel, dim3((N + 63) / 64, R), dim3(256), 0, s, X, ld, g_cs_scratch, M, N, rows_per);
-    hipLaunchKernelGGL(t_colsum_final_kernel, dim3((N + 63) / 64), dim3(64), 0, s, g_cs_scratch, out, N, R);
+    // ~2048 blocks in stage 1 (the pass is HBM-bound: it needs the whole chip), at least 32 rows and at most 512 chunks
+    const int colblocks = (N + 63) / 64;
+    int R = std::max(1, std::min(512, 2048 / colblocks));
+    R = std::max(1, std::min(R, (M + 31) / 32));
+    const int rows_per = (M + R - 1) / R;
+    R = (M + rows_per - 1) / rows_per;
+    TScratch &ts = t_scratch(s);
+    double *buf = t_scratch_get(s, ts.cs, ts.cs_cap, (size_t)R * N, ts);
+    if (!buf) return;   // (the stream's scratch is marked failed)
+    hipLaunchKernelGGL(t_colsum_part_kernel, dim3(colblocks, R), dim3(256), 0, s, X, ld, buf, M, N, rows_per);
+    hipLaunchKernelGGL(t_colsum_final_kernel, dim3(colblocks), dim3(256), 0, s, buf, out, N, R);
 }
 
 __device__ __forceinline__ float t_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -548,25 +680,21 @@ bool train_block_backward(const TrainBlockArgs &a, hipStream_t s) {
     TAttnGeom g{a.res, a.ws, a.shift, a.heads, C};
     const float *dY = a.grad_out;
     // MLP: x_out = x1 + hid W2^T + b2
-    t_gemm(true, false, dY, C, a.hid, H, nullptr, a.G.fc2_w, H, C, H, M, false, s);            // dW2 [C,H] = dY^T hid
-    t_colsum(dY, C, a.G.fc2_b, M, C, s);
+    t_gemm(true, false, dY, C, a.hid, H, nullptr, a.G.fc2_w, H, C, H, M, false, s, a.G.fc2_b);  // dW2 [C,H] = dY^T hid, db2 = colsum(dY)
     t_gemm(false, false, dY, C, a.W.fc2_w, H, nullptr, a.t_mh, H, M, H, C, false, s);          // d_hid = dY W2
     hipLaunchKernelGGL(t_gelu_bwd_kernel, dim3(t_blocks(nMH)), dim3(256), 0, s, a.pre, a.t_mh, a.t_mh, nMH);   // d_pre
-    t_gemm(true, false, a.t_mh, H, a.xn2, C, nullptr, a.G.fc1_w, C, H, C, M, false, s);         // dW1 [H,C] = d_pre^T xn2
-    t_colsum(a.t_mh, H, a.G.fc1_b, M, H, s);
+    t_gemm(true, false, a.t_mh, H, a.xn2, C, nullptr, a.G.fc1_w, C, H, C, M, false, s, a.G.fc1_b);   // dW1 [H,C] = d_pre^T xn2, db1
     t_gemm(false, false, a.t_mh, H, a.W.fc1_w, C, nullptr, a.t_mc, C, M, C, H, false, s);       // d_xn2 = d_pre W1
     if (hipMemcpyAsync(a.d_x1, dY, sizeof(float) * nMC, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;   // residual branch
     hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x1, a.W.n2_w, a.stats2, a.t_mc, a.d_x1, a.t_mc2, M, C);
     t_colsum(a.t_mc2, C, a.G.n2_w, M, C, s);                                                     // d_gamma2 = colsum(d_xn2 * xhat)
     t_colsum(a.t_mc, C, a.G.n2_b, M, C, s);                                                      // d_beta2 = colsum(d_xn2)
     // attention half: x1 = x_mod + att Wp^T + bp
-    t_gemm(true, false, a.d_x1, C, a.att, C, nullptr, a.G.proj_w, C, C, C, M, false, s);
-    t_colsum(a.d_x1, C, a.G.proj_b, M, C, s);
+    t_gemm(true, false, a.d_x1, C, a.att, C, nullptr, a.G.proj_w, C, C, C, M, false, s, a.G.proj_b);
     t_gemm(false, false, a.d_x1, C, a.W.proj_w, C, nullptr, a.t_mc, C, M, C, C, false, s);      // d_att
     if (hipMemsetAsync(a.G.rpb, 0, sizeof(float) * (size_t)(2 * a.ws - 1) * (2 * a.ws - 1) * a.heads, s) != hipSuccess) return false;
     if (!t_attn_launch(true, a.qkv, a.W.rpb, nullptr, a.t_mc, a.t_m3c, a.G.rpb, B, g, s)) return false;   // d_qkv, d_table
-    t_gemm(true, false, a.t_m3c, 3 * C, a.xn1, C, nullptr, a.G.qkv_w, C, 3 * C, C, M, false, s);
-    t_colsum(a.t_m3c, 3 * C, a.G.qkv_b, M, 3 * C, s);
+    t_gemm(true, false, a.t_m3c, 3 * C, a.xn1, C, nullptr, a.G.qkv_w, C, 3 * C, C, M, false, s, a.G.qkv_b);
     t_gemm(false, false, a.t_m3c, 3 * C, a.W.qkv_w, C, nullptr, a.t_mc, C, M, C, 3 * C, false, s);   // d_xn1
     // d_xmod = d_x1 (shortcut) + LN1 backward
     hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x_mod, a.W.n1_w, a.stats1, a.t_mc, a.d_x1, a.t_mc2, M, C);
@@ -599,15 +727,11 @@ void t_ln_bwd(const float *x, const float *gam, const float *stats, const float 
 void t_modulate(const float *x, const float *aff, const float *dy, float *out, float *d_aff, int B, int T, int C, bool bwd, hipStream_t s) {
     if (bwd) {
         const int rows_per = max(64, (T + 63) / 64), chunks = (T + rows_per - 1) / rows_per;
-        const size_t need = (size_t)B * chunks * 2 * C;
-        if (need > g_cs_cap) {
-            if (g_cs_scratch) (void)hipFree(g_cs_scratch);
-            g_cs_cap = 0; g_cs_scratch = nullptr;
-            if (hipMalloc((void **)&g_cs_scratch, sizeof(double) * need) == hipSuccess) g_cs_cap = need;
-        }
-        if (g_cs_cap < need) { fprintf(stderr, "dsg: t_modulate: out of memory\n"); abort(); }
-        hipLaunchKernelGGL(t_modulate_bwd_kernel, dim3((C + 63) / 64, chunks, B), dim3(256), 0, s, x, aff, dy, out, g_cs_scratch, T, C, rows_per, chunks);
-        hipLaunchKernelGGL(t_modulate_bwd_final_kernel, dim3((B * 2 * C + 255) / 256), dim3(256), 0, s, g_cs_scratch, d_aff, B, C, chunks);
+        TScratch &ts = t_scratch(s);
+        double *buf = t_scratch_get(s, ts.cs, ts.cs_cap, (size_t)B * chunks * 2 * C, ts);
+        if (!buf) return;   // (the stream's scratch is marked failed)
+        hipLaunchKernelGGL(t_modulate_bwd_kernel, dim3((C + 63) / 64, chunks, B), dim3(256), 0, s, x, aff, dy, out, buf, T, C, rows_per, chunks);
+        hipLaunchKernelGGL(t_modulate_bwd_final_kernel, dim3((B * 2 * C + 255) / 256), dim3(256), 0, s, buf, d_aff, B, C, chunks);
     } else hipLaunchKernelGGL(t_modulate_fwd_kernel, dim3(t_blocks((size_t)B * T * C)), dim3(256), 0, s, x, aff, out, T, C, (size_t)B * T * C);
 }
 void t_regroup(const float *src, float *dst, int B, int res, int C, bool gather, hipStream_t s) {
@@ -631,71 +755,119 @@ void t_rowmask(const float *x, const uint8_t *flags, float *y, size_t M, int C, 
 }
 
 // ---- optimiser step (torch.optim.Adam, R/utils/learning_utils.py:137-140) with nn.utils.clip_grad_norm_ in front (trainer_node_adj.py:170) ----
-// partial[b] = sum of squares of this block's grid-stride share (double); fixed block count -> deterministic
-__global__ __launch_bounds__(256) void t_sumsq_kernel(const float *g, size_t n, double *partial) {
+// Multi-tensor: ONE launch per phase over all parameter tensors (a model has 233-314 of them; one launch per tensor and phase was
+// ~2800 launches per iteration).  The tensors are cut into chunks of OPT_CHUNK elements, one block per chunk; tab[t] describes
+// tensor t, blk[b] = (tensor, first element) of block b.  Fixed chunking -> deterministic sums.
+constexpr int OPT_CHUNK = 4096;
+struct OptTensor { float *p, *g, *m, *v; unsigned long long n; unsigned first_blk, n_blk; };
+struct OptBlock { unsigned tensor, start; };
+// partial[b] = sum of squares of block b's chunk (double)
+__global__ __launch_bounds__(256) void t_mt_sumsq_kernel(const OptTensor *tab, const OptBlock *blk, double *partial) {
     __shared__ double red[256];
+    const OptBlock bk = blk[blockIdx.x];
+    const OptTensor t = tab[bk.tensor];
+    const unsigned long long i0 = (unsigned long long)bk.start, i1 = min(t.n, i0 + OPT_CHUNK);
     double s = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += (double)g[i] * (double)g[i];
+    for (unsigned long long i = i0 + threadIdx.x; i < i1; i += 256) s += (double)t.g[i] * (double)t.g[i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
-// norms[t] = sqrt(sum of tensor t's partials) as fp32 (torch: per-tensor fp32 norms, then the norm of the norms); out[0] = total norm,
-// out[1] = clip coefficient min(1, max_norm / (total + 1e-6))
-__global__ void t_clip_coef_kernel(const double *partial, int n_tensors, int per, float max_norm, float *out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// per tensor: fp32 norm = sqrt(sum of its chunks' partials, in chunk order) (torch: per-tensor fp32 norms, then the norm of the norms);
+// out[0] = total norm, out[1] = clip coefficient min(1, max_norm / (total + 1e-6)).  One block; thread i takes tensors i, i + 256, ...;
+// the per-thread sums are then added in thread order.
+__global__ __launch_bounds__(256) void t_clip_coef_kernel(const OptTensor *tab, const double *partial, int n_tensors, float max_norm, float *out) {
+    __shared__ double red[256];
     double tot = 0.0;
-    for (int t = 0; t < n_tensors; t++) {
+    for (int t = threadIdx.x; t < n_tensors; t += 256) {
         double s = 0.0;
-        for (int b = 0; b < per; b++) s += partial[(size_t)t * per + b];
+        for (unsigned b = 0; b < tab[t].n_blk; b++) s += partial[tab[t].first_blk + b];
         const float nt = sqrtf((float)s);
         tot += (double)nt * (double)nt;
     }
-    const float total = sqrtf((float)tot);
-    out[0] = total;
-    out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (total + 1e-6f)) : 1.0f;
+    red[threadIdx.x] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double all = 0.0;
+        for (int i = 0; i < 256; i++) all += red[i];
+        const float total = sqrtf((float)all);
+        out[0] = total;
+        out[1] = max_norm > 0.f ? fminf(1.0f, max_norm / (total + 1e-6f)) : 1.0f;
+    }
 }
-__global__ void t_adam_kernel(float *p, float *g, float *m, float *v, size_t n, const float *clip, float lr, float b1, float b2, float eps, float wd,
-                              float bc1, float bc2_sqrt) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float gr = g[i] * clip[1];
-    g[i] = gr;   // clip_grad_norm_ scales the gradients in place
-    if (wd != 0.f) gr = fmaf(wd, p[i], gr);
-    const float mi = m[i] + (gr - m[i]) * (1.0f - b1);               // exp_avg.lerp_(grad, 1 - beta1)
-    const float vi = v[i] * b2 + (1.0f - b2) * gr * gr;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
-    m[i] = mi; v[i] = vi;
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i] = p[i] - (lr / bc1) * (mi / denom);
+__global__ __launch_bounds__(256) void t_mt_adam_kernel(const OptTensor *tab, const OptBlock *blk, const float *clip, float lr, float b1, float b2,
+                                                        float eps, float wd, float bc1, float bc2_sqrt) {
+    const OptBlock bk = blk[blockIdx.x];
+    const OptTensor t = tab[bk.tensor];
+    const unsigned long long i0 = (unsigned long long)bk.start, i1 = min(t.n, i0 + OPT_CHUNK);
+    const float cl = clip[1];
+    for (unsigned long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        float gr = t.g[i] * cl;
+        t.g[i] = gr;   // clip_grad_norm_ scales the gradients in place
+        const float pi = t.p[i];
+        if (wd != 0.f) gr = fmaf(wd, pi, gr);
+        const float mi = t.m[i] + (gr - t.m[i]) * (1.0f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = t.v[i] * b2 + (1.0f - b2) * gr * gr;              // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+        t.m[i] = mi; t.v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        t.p[i] = pi - (lr / bc1) * (mi / denom);
+    }
 }
-__global__ void t_ema_kernel(float *ema, const float *p, size_t n, float decay) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ema[i] = ema[i] + (p[i] - ema[i]) * (1.0f - decay);   // ma.lerp_(current, 1 - decay)
+// ema <- ema + (p - ema)(1 - decay) (ma.lerp_(current, 1 - decay)); tab[t].p = ema tensor, tab[t].g = parameter tensor
+__global__ __launch_bounds__(256) void t_mt_ema_kernel(const OptTensor *tab, const OptBlock *blk, float decay) {
+    const OptBlock bk = blk[blockIdx.x];
+    const OptTensor t = tab[bk.tensor];
+    const unsigned long long i0 = (unsigned long long)bk.start, i1 = min(t.n, i0 + OPT_CHUNK);
+    for (unsigned long long i = i0 + threadIdx.x; i < i1; i += 256) t.p[i] = t.p[i] + (t.g[i] - t.p[i]) * (1.0f - decay);
+}
+// device tables for a tensor list, in the stream's scratch: [OptTensor n | OptBlock nb | double partial nb | float coef 2]
+struct OptTables { OptTensor *tab; OptBlock *blk; double *partial; float *coef; unsigned nb; };
+static bool t_opt_tables(int n, float *const *p, float *const *g, float *const *m, float *const *v, const int64_t *numel, hipStream_t s, OptTables &o) {
+    std::vector<OptTensor> tab((size_t)n);
+    std::vector<OptBlock> blk;
+    for (int t = 0; t < n; t++) {
+        if (numel[t] < 0 || numel[t] > 0xffffffffll) return false;
+        tab[t] = OptTensor{p[t], g ? g[t] : nullptr, m ? m[t] : nullptr, v ? v[t] : nullptr, (unsigned long long)numel[t], (unsigned)blk.size(), 0u};
+        for (int64_t i = 0; i < numel[t]; i += OPT_CHUNK) blk.push_back(OptBlock{(unsigned)t, (unsigned)i});
+        tab[t].n_blk = (unsigned)blk.size() - tab[t].first_blk;
+    }
+    const size_t b_tab = (sizeof(OptTensor) * n + 255) / 256 * 256, b_blk = (sizeof(OptBlock) * blk.size() + 255) / 256 * 256,
+                 b_par = (sizeof(double) * blk.size() + 255) / 256 * 256;
+    TScratch &ts = t_scratch(s);
+    char *base = nullptr;
+    {
+        char *cur = static_cast<char *>(ts.opt);
+        base = t_scratch_get(s, cur, ts.opt_cap, b_tab + b_blk + b_par + 256, ts);
+        ts.opt = cur;
+    }
+    if (!base) return false;
+    o.tab = reinterpret_cast<OptTensor *>(base); o.blk = reinterpret_cast<OptBlock *>(base + b_tab);
+    o.partial = reinterpret_cast<double *>(base + b_tab + b_blk); o.coef = reinterpret_cast<float *>(base + b_tab + b_blk + b_par);
+    o.nb = (unsigned)blk.size();
+    // (the stream is synchronised at the end of every optimiser / EMA call, so the previous call's tables are no longer read)
+    if (hipMemcpyAsync(o.tab, tab.data(), sizeof(OptTensor) * n, hipMemcpyHostToDevice, s) != hipSuccess) return false;
+    if (o.nb && hipMemcpyAsync(o.blk, blk.data(), sizeof(OptBlock) * blk.size(), hipMemcpyHostToDevice, s) != hipSuccess) return false;
+    return hipStreamSynchronize(s) == hipSuccess;   // the host vectors go out of scope
 }
 bool t_adam_step(int n, float *const *params, float *const *grads, float *const *m, float *const *v, const int64_t *numel, int step, float lr,
                  float b1, float b2, float eps, float wd, float max_norm, float *host_total_norm, hipStream_t s) {
-    constexpr int PER = 64;
-    double *partial = nullptr;
-    float *coef = nullptr;
-    if (hipMalloc((void **)&partial, sizeof(double) * (size_t)n * PER) != hipSuccess) return false;
-    if (hipMalloc((void **)&coef, sizeof(float) * 2) != hipSuccess) { (void)hipFree(partial); return false; }
-    for (int t = 0; t < n; t++) hipLaunchKernelGGL(t_sumsq_kernel, dim3(PER), dim3(256), 0, s, grads[t], (size_t)numel[t], partial + (size_t)t * PER);
-    hipLaunchKernelGGL(t_clip_coef_kernel, dim3(1), dim3(1), 0, s, partial, n, PER, max_norm, coef);
+    OptTables o;
+    if (!t_opt_tables(n, params, grads, m, v, numel, s, o)) return false;
+    if (o.nb) hipLaunchKernelGGL(t_mt_sumsq_kernel, dim3(o.nb), dim3(256), 0, s, o.tab, o.blk, o.partial);
+    hipLaunchKernelGGL(t_clip_coef_kernel, dim3(1), dim3(256), 0, s, o.tab, o.partial, n, max_norm, o.coef);
     const float bc1 = 1.0f - powf(b1, (float)step), bc2s = sqrtf(1.0f - powf(b2, (float)step));
-    for (int t = 0; t < n; t++)
-        hipLaunchKernelGGL(t_adam_kernel, dim3(t_blocks((size_t)numel[t])), dim3(256), 0, s, params[t], grads[t], m[t], v[t], (size_t)numel[t], coef, lr,
-                           b1, b2, eps, wd, bc1, bc2s);
+    if (o.nb) hipLaunchKernelGGL(t_mt_adam_kernel, dim3(o.nb), dim3(256), 0, s, o.tab, o.blk, o.coef, lr, b1, b2, eps, wd, bc1, bc2s);
     bool ok = hipGetLastError() == hipSuccess;
-    if (host_total_norm) ok = ok && hipMemcpyAsync(host_total_norm, coef, sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess;
+    if (host_total_norm) ok = ok && hipMemcpyAsync(host_total_norm, o.coef, sizeof(float), hipMemcpyDeviceToHost, s) == hipSuccess;
     ok = ok && hipStreamSynchronize(s) == hipSuccess;
-    (void)hipFree(partial); (void)hipFree(coef);
     return ok;
 }
 bool t_ema_update(int n, float *const *ema, const float *const *params, const int64_t *numel, float decay, hipStream_t s) {
-    for (int t = 0; t < n; t++)
-        hipLaunchKernelGGL(t_ema_kernel, dim3(t_blocks((size_t)numel[t])), dim3(256), 0, s, ema[t], params[t], (size_t)numel[t], decay);
-    return hipGetLastError() == hipSuccess;
+    OptTables o;
+    if (!t_opt_tables(n, ema, const_cast<float *const *>(params), nullptr, nullptr, numel, s, o)) return false;
+    if (o.nb) hipLaunchKernelGGL(t_mt_ema_kernel, dim3(o.nb), dim3(256), 0, s, o.tab, o.blk, decay);
+    return hipGetLastError() == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
 }
 
 }  // namespace dsg

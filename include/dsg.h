@@ -20,6 +20,9 @@
  *   - the caller owns every I/O buffer; the library owns packed weights and its workspace and
  *     never mutates an input.  One handle per device, not re-entrant.  All work is enqueued on
  *     the caller's stream (`stream` is a hipStream_t passed as void*; NULL = default stream).
+ *     Training entries: the saved-activation arena and backward scratch belong to the handle; the small scratch of the
+ *     handle-less kernels (split-K partials, column sums, the optimiser's tables) is kept per STREAM, so two streams never
+ *     share a buffer; an allocation failure anywhere is reported as DSG_ERR_HIP, never by terminating the process.
  *   - there is no CPU fallback: every entry point fails with DSG_ERR_HIP if the device is missing.
  */
 #ifndef DSG_H
