@@ -563,10 +563,227 @@ __global__ void t_attn_kernel(const float *qkv, const float *table, float *out, 
             dq[g.C + d] = c * scale;
         }
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// The same forward / backward on the f32 matrix pipe (v_mfma_f32_32x32x2_f32: exact f32 products, so the gradient fixtures hold at
+// the same bars).  One block per (sample, window, head), one wave per 32 window positions; q, k, v (and dO) of the window sit in
+// LDS as [position][33] (conflict-free ds_read_b32 along rows and along head dims); Wp = 32 KT padded positions.
+//   phase 1, lane = QUERY i (a wave's 32 queries x all keys):
+//       S^T[j][i] = k_j . q_i  ->  P^T = softmax over the keys: lane-local (+ one exchange between the half-waves); (m_i, l_i) -> LDS
+//       forward:  O^T[d][i] = sum_j V^T[d][j] P^T[j][i]   -- the P^T accumulators ARE the B operand: register r of a 32x32 tile is
+//                 key (r&3) + 8 (r>>2) + 4 half of the tile, and the A operand is simply fetched for that key
+//       backward: dP^T[j][i] = v_j . dO_i;  t_i = sum_j dP P;  dS^T = P (dP - t);  t_i -> LDS;  bias gradient (LDS atomics);
+//                 dQ^T[d][i] = scale sum_j K^T[d][j] dS^T[j][i]
+//   phase 2 (backward), lane = KEY j (a wave's 32 keys x all queries), because dV and dK sum over the queries -- the LANE index of
+//   phase 1 -- and turning the accumulators would need Wp x Wp floats of LDS for P and for dS (132 KB at 100 tokens):
+//       S[i][j], dP[i][j] again (2 of the 7 products are recomputed), P from (m_i, l_i), dS from t_i;
+//       dV^T[d][j] = sum_i dO^T[d][i] P[i][j];   dK^T[d][j] = scale sum_i Q^T[d][i] dS[i][j]
+// Results leave as 4 consecutive head dims per lane (16-byte stores).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KT, bool BWD>
+__global__ __launch_bounds__(64 * KT) void t_attn_mfma_kernel(const float *__restrict__ qkv, const float *__restrict__ table, float *__restrict__ out,
+                                                              const float *__restrict__ d_out, float *__restrict__ d_qkv, float *__restrict__ d_table,
+                                                              TAttnGeom g) {
+    constexpr int Wp = 32 * KT, LD = 33, NT = 64 * KT;
+    extern __shared__ float sm[];
+    float *qs = sm, *ks = qs + Wp * LD, *vs = ks + Wp * LD, *dos = vs + Wp * LD;      // dos only with BWD
+    float *stat = dos + (BWD ? Wp * LD : 0);                                           // [Wp][4]: m, 1/l, t
+    float *tabh = stat + Wp * 4;                                                       // this head's bias column [(2 ws - 1)^2 <= 448]
+    float *dtab = tabh + 448;                                                          // its gradient (BWD)
+    int *ypos = reinterpret_cast<int *>(dtab + (BWD ? 448 : 0)), *xpos = ypos + Wp, *regs = xpos + Wp, *toks = regs + Wp;
+    const int Wt = g.ws * g.ws, C = g.C;
+    const int nW = (g.res / g.ws) * (g.res / g.ws), T = g.res * g.res;
+    const int h = blockIdx.x % g.heads, w = (blockIdx.x / g.heads) % nW, b = blockIdx.x / (g.heads * nW);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const float scale = 1.0f / sqrtf(32.0f);
+    const int ntab = (2 * g.ws - 1) * (2 * g.ws - 1);
+    for (int t = tid; t < 448; t += NT) { tabh[t] = t < ntab ? table[(size_t)t * g.heads + h] : 0.f; if (BWD) dtab[t] = 0.f; }
+    for (int p = tid; p < Wp; p += NT) {
+        int ri = 0, rj = 0, tok = 0;
+        if (p < Wt) tok = t_token_of(g, w, p, ri, rj);
+        ypos[p] = p / g.ws; xpos[p] = p % g.ws; toks[p] = tok;
+        regs[p] = (g.shift > 0 && p < Wt) ? 3 * t_region(g, ri) + t_region(g, rj) : 0;
+    }
+    __syncthreads();
+    // q | k | v | dO rows -> LDS (float4 loads; padded positions are zero)
+    for (int idx = tid; idx < Wp * 8; idx += NT) {
+        const int p = idx >> 3, c4 = idx & 7;
+        f32x4 q4 = {0.f, 0.f, 0.f, 0.f}, k4 = q4, v4 = q4, o4 = q4;
+        if (p < Wt) {
+            const float *row = qkv + ((size_t)b * T + toks[p]) * 3 * C + h * 32 + 4 * c4;
+            q4 = *reinterpret_cast<const f32x4 *>(row); k4 = *reinterpret_cast<const f32x4 *>(row + C); v4 = *reinterpret_cast<const f32x4 *>(row + 2 * C);
+            if (BWD) o4 = *reinterpret_cast<const f32x4 *>(d_out + ((size_t)b * T + toks[p]) * C + h * 32 + 4 * c4);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            qs[p * LD + 4 * c4 + t] = q4[t]; ks[p * LD + 4 * c4 + t] = k4[t]; vs[p * LD + 4 * c4 + t] = v4[t];
+            if (BWD) dos[p * LD + 4 * c4 + t] = o4[t];
+        }
+    }
+    __syncthreads();
+    // bias + mask of the pair (query position pi, key position pj); -1e30 for a padded key
+    auto bias_of = [&](int pi, int pj) -> float {
+        if (pj >= Wt) return -1.0e30f;
+        const int idx = (ypos[pi] - ypos[pj] + g.ws - 1) * (2 * g.ws - 1) + (xpos[pi] - xpos[pj] + g.ws - 1);
+        float bv = tabh[idx];
+        if (g.shift > 0 && regs[pi] != regs[pj]) bv += -100.0f;
+        return bv;
+    };
+    auto tab_idx = [&](int pi, int pj) -> int { return (ypos[pi] - ypos[pj] + g.ws - 1) * (2 * g.ws - 1) + (xpos[pi] - xpos[pj] + g.ws - 1); };
+    // X^T[j][i] = sum_d Arow[j][d] Brow[i][d] for this wave's 32 columns i = 32 wave + lrow and key tile kt (rows j = 32 kt + ...)
+    auto prod_T = [&](const float *Arows, const float *Brows, int kt) -> f32x16 {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        const float *ap = Arows + (32 * kt + lrow) * LD + lhalf, *bp = Brows + (32 * wave + lrow) * LD + lhalf;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; s2++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2], bp[2 * s2], acc, 0, 0, 0);
+        return acc;
+    };
+    // Y^T[d][c] += sum over the 32 rows of tile rt of Mrow[row][d] * X[row][c], X = an accumulator tile (rows = its register index)
+    auto prod_acc = [&](const float *Mrows, int rt, const f32x16 &X, f32x16 &Y) {
+        const float *mp = Mrows + (32 * rt + 4 * lhalf) * LD + lrow;
+#pragma unroll
+        for (int r = 0; r < 16; r++) Y = __builtin_amdgcn_mfma_f32_32x32x2f32(mp[((r & 3) + 8 * (r >> 2)) * LD], X[r], Y, 0, 0, 0);
+    };
+    auto store_T = [&](const f32x16 &Y, float mul, float *dst_row) {   // Y^T[d][.]: this lane's 16 head dims -> dst_row[h*32 + d]
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4 o;
+#pragma unroll
+            for (int t = 0; t < 4; t++) o[t] = Y[4 * q + t] * mul;
+            *reinterpret_cast<f32x4 *>(dst_row + 8 * q + 4 * lhalf) = o;
+        }
+    };
+    const int pi = 32 * wave + lrow;   // phase 1: this lane's query position; phase 2: its key position
+    const bool pi_ok = pi < Wt;
+    // ---------------- phase 1 ----------------
+    f32x16 P[KT];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        P[kt] = prod_T(ks, qs, kt);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int pj = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+            P[kt][r] = fmaf(P[kt][r], scale, bias_of(pi, pj));
+            mx = fmaxf(mx, P[kt][r]);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { P[kt][r] = __expf(P[kt][r] - mx); sum += P[kt][r]; }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) P[kt][r] *= inv;
+    if (!BWD) {
+        f32x16 O;
+#pragma unroll
+        for (int r = 0; r < 16; r++) O[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) prod_acc(vs, kt, P[kt], O);
+        if (pi_ok) store_T(O, 1.0f, out + ((size_t)b * T + toks[pi]) * C + h * 32);
+        return;
+    }
+    f32x16 dS[KT];
+    float tsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        dS[kt] = prod_T(vs, dos, kt);   // dP^T[j][i] = v_j . dO_i
+#pragma unroll
+        for (int r = 0; r < 16; r++) tsum = fmaf(dS[kt][r], P[kt][r], tsum);
+    }
+    tsum += __shfl_xor(tsum, 32, 64);
+    if (lhalf == 0) { stat[pi * 4 + 0] = mx; stat[pi * 4 + 1] = inv; stat[pi * 4 + 2] = tsum; }
+    {
+        f32x16 dQ;
+#pragma unroll
+        for (int r = 0; r < 16; r++) dQ[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float ds = P[kt][r] * (dS[kt][r] - tsum);
+                dS[kt][r] = ds;
+                const int pj = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lhalf;
+                if (pi_ok && pj < Wt) atomicAdd(&dtab[tab_idx(pi, pj)], ds);   // LDS atomics; one global atomic per table entry and block below
+            }
+            prod_acc(ks, kt, dS[kt], dQ);
+        }
+        if (pi_ok) store_T(dQ, scale, d_qkv + ((size_t)b * T + toks[pi]) * 3 * C + h * 32);
+    }
+    __syncthreads();   // (m, 1/l, t) of every query are in LDS; dtab is complete
+    for (int t = tid; t < ntab; t += NT) atomicAdd(d_table + (size_t)t * g.heads + h, dtab[t]);
+    // ---------------- phase 2: lane = key pi ----------------
+    f32x16 dV, dK;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dV[r] = 0.f; dK[r] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < KT; it++) {
+        // S[i][j]: rows = queries of tile it (A = q rows), columns = this wave's keys (B = k rows)
+        f32x16 Pq, dSq;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { Pq[r] = 0.f; dSq[r] = 0.f; }
+        {
+            const float *ap = qs + (32 * it + lrow) * LD + lhalf, *bp = ks + (32 * wave + lrow) * LD + lhalf;
+            const float *ap2 = dos + (32 * it + lrow) * LD + lhalf, *bp2 = vs + (32 * wave + lrow) * LD + lhalf;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; s2++) {
+                Pq = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * s2], bp[2 * s2], Pq, 0, 0, 0);
+                dSq = __builtin_amdgcn_mfma_f32_32x32x2f32(ap2[2 * s2], bp2[2 * s2], dSq, 0, 0, 0);   // dP[i][j] = dO_i . v_j
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int qi = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * lhalf;   // query position of this register
+            const float m = stat[qi * 4 + 0], il = stat[qi * 4 + 1], tq = stat[qi * 4 + 2];
+            float pv = __expf(fmaf(Pq[r], scale, bias_of(qi, pi)) - m) * il;
+            if (qi >= Wt) pv = 0.f;   // a padded query row (its statistics are those of an all-padding softmax): contributes nothing
+            Pq[r] = pv;
+            dSq[r] = pv * (dSq[r] - tq);
+        }
+        prod_acc(dos, it, Pq, dV);    // dV^T[d][j] += sum_i dO[i][d] P[i][j]
+        prod_acc(qs, it, dSq, dK);    // dK^T[d][j] += sum_i Q[i][d] dS[i][j]
+    }
+    if (pi_ok) {
+        float *row = d_qkv + ((size_t)b * T + toks[pi]) * 3 * C + h * 32;
+        store_T(dK, scale, row + C);
+        store_T(dV, 1.0f, row + 2 * C);
+    }
+}
+
+template <int KT>
+static bool t_attn_mfma_launch(bool bwd, const float *qkv, const float *table, float *out, const float *d_out, float *d_qkv, float *d_table,
+                               int B, TAttnGeom g, hipStream_t s) {
+    constexpr int Wp = 32 * KT;
+    const size_t lds = sizeof(float) * ((size_t)(bwd ? 4 : 3) * Wp * 33 + (size_t)Wp * 4 + 448 + (bwd ? 448 : 0) + 4 * (size_t)Wp);
+    const int nW = (g.res / g.ws) * (g.res / g.ws);
+    const dim3 grid(B * nW * g.heads), block(64 * KT);
+    if (bwd) {
+        if (hipFuncSetAttribute((const void *)t_attn_mfma_kernel<KT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        hipLaunchKernelGGL((t_attn_mfma_kernel<KT, true>), grid, block, lds, s, qkv, table, out, d_out, d_qkv, d_table, g);
+    } else {
+        if (hipFuncSetAttribute((const void *)t_attn_mfma_kernel<KT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        hipLaunchKernelGGL((t_attn_mfma_kernel<KT, false>), grid, block, lds, s, qkv, table, out, d_out, d_qkv, d_table, g);
+    }
+    return true;
+}
+
 static bool t_attn_launch(bool bwd, const float *qkv, const float *table, float *out, const float *d_out, float *d_qkv, float *d_table,
                           int B, TAttnGeom g, hipStream_t s) {
     const int Wt = g.ws * g.ws, HD = g.C / g.heads, LD = HD + 1;
     if (Wt > 128 || HD % 4 != 0) return false;
+    static const bool plain = getenv("DSG_TRAIN_PLAIN_ATTN") != nullptr;   // dev knob: the scalar kernel below
+    if (!plain && HD == 32 && g.C % 4 == 0) {
+        if (Wt <= 32) return t_attn_mfma_launch<1>(bwd, qkv, table, out, d_out, d_qkv, d_table, B, g, s);
+        if (Wt <= 64) return t_attn_mfma_launch<2>(bwd, qkv, table, out, d_out, d_qkv, d_table, B, g, s);
+        return t_attn_mfma_launch<4>(bwd, qkv, table, out, d_out, d_qkv, d_table, B, g, s);
+    }
     const size_t lds = sizeof(float) * ((size_t)(bwd ? 4 : 3) * Wt * LD + (size_t)(bwd ? 2 : 1) * Wt * (Wt + 1));
     const int nW = (g.res / g.ws) * (g.res / g.ws);
     const dim3 grid(B * nW * g.heads), block((4 * Wt + 63) / 64 * 64);
