@@ -126,6 +126,7 @@ struct dsg_handle_s {
     bool opt_gemm_bf16 = false;                                   // bf16-MFMA GEMMs (fp32 accumulate), opt-in precision mode
     int opt_bf16_act = 2;                                         // in that mode: 1 hidden / attention-output tensors stored as bf16 (bit-identical), 2 also qkv
     bool opt_bf16_pipe = true;                                    // in that mode: the bf16 block pipeline of kernels_bx.hip (0: round 2's kernels_lp.hip path)
+    int opt_bf16_mlp = 1;                                         // in that pipeline: the fused fc1-GELU-fc2 kernel at C <= 192 (0: two GEMMs with a bf16 hidden tensor; 2: also at C = 384)
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
     bool opt_gemm_split = false;                                  // split-bf16 GEMMs (3 planes, 6 products): fp32-accurate, opt-in
@@ -1117,6 +1118,23 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
     if (full) { g.ln_out = 1; g.Cb = w->xn; g.ldcb = C; }   // LayerNorm-2 of x + proj(...) (gamma / beta folded into fc1_wf / fc1_bf)
     P_BX(g, "proj");
     if (!full) P_KERN(PK_ROW, 0.0, launch_ln_bx(w->x, nullptr, 0, 0, w->xn, B, T, C, true, s));
+    // fc1 -> GELU -> fc2 -> + residual (-> the next block's modulate / LayerNorm-1) in one kernel, no hidden tensor: at C = 96 / 192,
+    // where the pair of GEMMs is bound by the hidden tensor's HBM round trip (measured at COCO B = 512, tools/bx_bench.py: 324 us
+    // against 302 + 325 at C = 96, 270 against 193 + 196 at C = 192).  At C = 384 the fused kernel needs 230 + 192 registers, runs one
+    // wave per SIMD and is slower than the two GEMMs (312 us against 115 + 156): option value 2 forces it there too (tests).
+    if (h->opt_bf16_mlp && h->cfg.mlp_ratio == 4 && (C == 96 || C == 192 || (C == 384 && h->opt_bf16_mlp >= 2))) {
+        BxMlp m;
+        m.xn = w->xn; m.x = w->x; m.W1 = bf16_of(h, b.fc1_wf); m.b1 = b.fc1_bf;
+        m.W2 = bf16_of(h, WT(h, p + ".mlp.fc2.weight")); m.b2 = WT(h, p + ".mlp.fc2.bias"); m.M = M; m.C = C;
+        BxState out = BX_RAW;
+        if (next && h->taps.empty()) {
+            m.mod_aff = w->aff; m.mod_ld = w->aff_ld; m.mod_off = next->aff_off; m.mod_T = next->res * next->res;
+            m.xn_out = w->xn; m.out_mode = 1; out = BX_READY;
+        } else if (!next && want_copy) { m.xn_out = w->xn; m.out_mode = 2; }
+        ProfScope ps_(h, s, PK_FUSED, 4.0 * (double)M * (double)C * (double)Hd, "mlp_bx");
+        if (!launch_mlp_bx(m, s)) { fprintf(stderr, "dsg: mlp_bx: shape not covered (M=%d C=%d)\n", M, C); abort(); }
+        return out;
+    }
     g = BxGemm();
     g.A = w->xn; g.lda = C; g.K = C; g.M = M; g.N = Hd;
     g.W = bf16_of(h, b.fc1_wf); g.bias = b.fc1_bf; g.act = ACT_GELU; g.Cb = w->hid; g.ldcb = Hd;
@@ -1479,6 +1497,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "loop_graph") h->opt_loop_graph = value != 0;
     else if (n == "bf16_act") h->opt_bf16_act = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "bf16_pipe") h->opt_bf16_pipe = value != 0;
+    else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "fused_merge") { h->opt_fused_merge = value != 0; h->opt_fused_merge_small = value > 1; }   // 2: at every size
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
@@ -1506,6 +1525,7 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "loop_graph") *value = h->opt_loop_graph;
     else if (n == "bf16_act") *value = (h->opt_gemm_bf16 && !h->opt_gemm_split && !h->opt_bf16_pipe) ? h->opt_bf16_act : 0;   // acts in round 2's bf16 path only
     else if (n == "bf16_pipe") *value = bx_on(h);   // the bf16 block pipeline runs (bf16 mode only)
+    else if (n == "bf16_mlp") *value = bx_on(h) ? h->opt_bf16_mlp : 0;
     else if (n == "fused_merge") *value = h->opt_fused_merge ? (h->opt_fused_merge_small ? 2 : 1) : 0;
     else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
     else if (n == "gemm_split") *value = h->opt_gemm_split;
@@ -1863,6 +1883,30 @@ int dsg_debug_gemm_bx(int32_t M, int32_t N, int32_t K, const float *A, const flo
             }
         }
     }
+    const hipError_t e = hipStreamSynchronize(s);
+    cleanup();
+    if (!ok) return DSG_ERR_INVALID;
+    return (e == hipSuccess && hipGetLastError() == hipSuccess) ? DSG_OK : DSG_ERR_HIP;
+}
+
+int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const float *W1, const float *b1, const float *W2, const float *b2,
+                     const float *mod, int32_t out_mode, float *out_xn, int32_t time_iters, float *out_ms, void *stream) {
+    if (M < 1 || !xn || !x || !W1 || !b1 || !W2 || !b2 || (out_mode && !out_xn)) return DSG_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    void *xb = nullptr, *w1b = nullptr, *w2b = nullptr, *ob = nullptr;
+    auto cleanup = [&]() { (void)hipFree(xb); (void)hipFree(w1b); (void)hipFree(w2b); (void)hipFree(ob); };
+    if (hipMalloc(&xb, (size_t)M * C * 2) != hipSuccess || hipMalloc(&w1b, (size_t)4 * C * C * 2) != hipSuccess ||
+        hipMalloc(&w2b, (size_t)4 * C * C * 2) != hipSuccess || hipMalloc(&ob, (size_t)M * C * 2) != hipSuccess) { cleanup(); return DSG_ERR_HIP; }
+    launch_f32_to_bf16(xn, xb, (size_t)M * C, s);
+    launch_f32_to_bf16(W1, w1b, (size_t)4 * C * C, s);
+    launch_f32_to_bf16(W2, w2b, (size_t)4 * C * C, s);
+    BxMlp g;
+    g.xn = xb; g.x = x; g.W1 = w1b; g.b1 = b1; g.W2 = w2b; g.b2 = b2; g.M = M; g.C = C;
+    if (out_mode) { g.xn_out = ob; g.out_mode = out_mode; }
+    if (mod) { g.mod_aff = mod; g.mod_ld = 0; g.mod_off = 0; g.mod_T = 1; }
+    const bool ok = launch_mlp_bx(g, s);
+    if (ok && out_mode) launch_bf16_to_f32(ob, out_xn, (size_t)M * C, s);
+    if (ok && time_iters > 0 && out_ms) *out_ms = time_launches(s, time_iters, [&]() { (void)launch_mlp_bx(g, s); });   // (x keeps accumulating: timing only)
     const hipError_t e = hipStreamSynchronize(s);
     cleanup();
     if (!ok) return DSG_ERR_INVALID;

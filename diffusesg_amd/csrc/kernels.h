@@ -81,6 +81,17 @@ struct BxGemm {
     unsigned long long *dbg = nullptr;            // DSG_BX_EXP == 4 builds only: per-block phase clocks [grid][8] (tools/bx_exp.sh)
 };
 bool launch_gemm_bx(const BxGemm &g, hipStream_t s);   // false: shape not covered (nothing launched)
+// x <- [modulate_next] (x + fc2(GELU(fc1(xn)))) in one kernel (mlp_ratio 4, C in {96, 192, 384}); xn = LayerNorm-2 of x as bf16
+// (gamma / beta folded into W1 / b1), W1 [4C, C] and W2 [C, 4C] bf16; xn_out (optional) receives the LayerNorm (out_mode 1) or the
+// plain bf16 copy (out_mode 2) of the stored row; mod_* as BxGemm.  false: width not covered.
+struct BxMlp {
+    const void *xn = nullptr; float *x = nullptr;
+    const void *W1 = nullptr; const float *b1 = nullptr; const void *W2 = nullptr; const float *b2 = nullptr;
+    void *xn_out = nullptr; int out_mode = 0;
+    const float *mod_aff = nullptr; int mod_ld = 0, mod_off = 0, mod_T = 1;
+    int M = 0, C = 0;
+};
+bool launch_mlp_bx(const BxMlp &g, hipStream_t s);
 // x fp32 [B*T, C] -> optional in-place modulate+SiLU (aff != null) -> xn bf16: LayerNorm without affine (ln) or the plain copy
 void launch_ln_bx(float *x, const float *aff, int aff_ld, int aff_off, void *xn, int B, int T, int C, bool ln, hipStream_t s);
 // window attention on bf16 qkv [B*T, 3C] -> bf16 out [B*T, C]; biasT as launch_window_attn; false: window size not covered

@@ -425,6 +425,168 @@ bool launch_gemm_bx(const BxGemm &g, hipStream_t s) {
 }
 
 // -------------------------------------------------------------------------------------------------
+// Fused MLP half of a Swin block (diffusesg.py:275, :19-25):  x <- x + fc2(GELU(fc1(LayerNorm2(x))))  with the 4C-wide hidden tensor
+// never leaving the register file -- unfused, fc1 writes and fc2 re-reads 2 x M x 4C bytes of it (more than everything else the two
+// GEMMs move) and fc1's epilogue is as long as its MFMAs.
+//   * one wave owns 32 tokens and keeps their normalised rows (the B operand of fc1: lane = token) in registers for the whole kernel;
+//   * the hidden dimension is walked in chunks of 32: H^T = W1[chunk] . Xn^T on the matrix pipe (lane = token, register = hidden unit),
+//     + b1, GELU and the bf16 rounding on the accumulator, which is then -- register pairs as they stand -- the B operand of
+//     O^T += W2[:, chunk] . H^T (an accumulator tile's rows are a k-step's k index in the permuted order hidden 16 s + 8 (j >> 2) +
+//     4 half + (j & 3); the W2 chunk is laid out in LDS in that order);
+//   * the two weight chunks (32 x C and C x 32 bf16) stream through a double-buffered LDS stage shared by the block's 4 waves, the
+//     next chunk's global loads in flight during the current chunk's MFMAs;
+//   * a lane ends up with whole rows (its token's C outputs, split between the half-waves), so bias, residual, the next block's
+//     modulate+SiLU and the LayerNorm of the stored row are lane-local: the same epilogue options as gemm_bx at any width.
+// Registers: C/4 for Xn, C/2 for O^T (+ staging): C = 384 runs one wave per SIMD (512 registers), C = 192 two, C = 96 three.
+// -------------------------------------------------------------------------------------------------
+template <int C, int MOD>
+__global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_bx_kernel(BxMlp g) {
+    constexpr int H = 4 * C, NCH = H / 32, KS = C / 16, CT = C / 32;
+    constexpr int LD1 = C + 8, LD2 = 40;                       // LDS row strides (bf16) of the W1 chunk [32][C] and the W2 chunk [C][32]
+    constexpr int STAGE = 32 * LD1 + C * LD2 + 64;             // + 32 floats of b1
+    constexpr int NP = (4 * C + 255) / 256;                    // 16-byte pieces per thread and chunk, for each of the two weights
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int m0 = blockIdx.x * 128;
+    const int rows = min(128, g.M - m0);
+    const unsigned mrow = (unsigned)(32 * wave + lrow);        // this lane's token inside the block
+    const __bf16 *W1 = static_cast<const __bf16 *>(g.W1), *W2 = static_cast<const __bf16 *>(g.W2);
+    const rsrc_t rsW1 = make_rsrc(W1, (unsigned)H * C * 2u), rsW2 = make_rsrc(W2, (unsigned)C * H * 2u);
+    // staging: piece q = tid + 256 p;  W1 chunk: row q / (C/8), 16-byte column q % (C/8);  W2 chunk: row q / 4, column q % 4
+    u32x4 s1[NP], s2[NP];
+    float s_b1 = 0.f;
+    auto issue = [&](int hc) {
+        if (tid < 32) s_b1 = g.b1[32 * hc + tid];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int q = tid + 256 * p;
+            const bool ok = q < 4 * C;
+            const unsigned o1 = ((unsigned)(32 * hc + q / (C / 8)) * C + 8u * (q % (C / 8))) * 2u;
+            const unsigned o2 = ((unsigned)(q / 4) * H + 32u * hc + 8u * (q % 4)) * 2u;
+            s1[p] = buf_load_u4(rsW1, ok ? o1 : 0x7fffffffu, 0u);
+            s2[p] = buf_load_u4(rsW2, ok ? o2 : 0x7fffffffu, 0u);
+        }
+    };
+    auto write = [&](int buf) {
+        __bf16 *w1s = lds + buf * STAGE, *w2s = w1s + 32 * LD1;
+        float *b1s = reinterpret_cast<float *>(w2s + C * LD2);
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int q = tid + 256 * p;
+            if (q < 4 * C) {
+                *reinterpret_cast<u32x4 *>(w1s + (q / (C / 8)) * LD1 + 8 * (q % (C / 8))) = s1[p];
+                // the 8 hidden units 8 c .. 8 c + 7 of the chunk go to positions 16 s + 8 (e >> 2) + 4 (c & 1) + (e & 3), s = c >> 1
+                const int c = q % 4;
+                __bf16 *dst = w2s + (q / 4) * LD2 + 16 * (c >> 1) + 4 * (c & 1);
+                *reinterpret_cast<u32x2 *>(dst) = (u32x2){s2[p][0], s2[p][1]};
+                *reinterpret_cast<u32x2 *>(dst + 8) = (u32x2){s2[p][2], s2[p][3]};
+            }
+        }
+        if (tid < 32) b1s[tid] = s_b1;
+    };
+    issue(0);
+    // the wave's normalised rows: lane (token, half) holds channels 16 s + 8 half .. + 7 of k-step s
+    const rsrc_t rsXn = make_rsrc(static_cast<const __bf16 *>(g.xn) + (size_t)m0 * C, (unsigned)rows * C * 2u);
+    bf16x8 xf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) xf[s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsXn, (mrow * C + 16u * s + 8u * lhalf) * 2u, 0u));
+    f32x16 oacc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
+    write(0);
+    __syncthreads();
+    for (int hc = 0; hc < NCH; hc++) {
+        const int cur = hc & 1;
+        if (hc + 1 < NCH) issue(hc + 1);
+        const __bf16 *w1s = lds + cur * STAGE, *w2s = w1s + 32 * LD1;
+        const float *b1s = reinterpret_cast<const float *>(w2s + C * LD2);
+        f32x16 hacc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) hacc[r] = b1s[(r & 3) + 8 * (r >> 2) + 4 * lhalf];
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w1s + lrow * LD1 + 16 * s + 8 * lhalf), xf[s], hacc, 0, 0, 0);
+        u32x4 hf[2];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) hf[r >> 3][(r & 7) >> 1] = pack_bf16(gelu_f(hacc[r]), gelu_f(hacc[r + 1]));
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int s2i = 0; s2i < 2; s2i++)
+                oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w2s + (32 * ct + lrow) * LD2 + 16 * s2i + 8 * lhalf),
+                                                                   __builtin_bit_cast(bf16x8, hf[s2i]), oacc[ct], 0, 0, 0);
+        if (hc + 1 < NCH) write(1 - cur);
+        __syncthreads();
+    }
+    // ---- epilogue: lane (token, half) holds channels 32 ct + 8 q + 4 half + {0..3} in oacc[ct][4 q ..]
+    const rsrc_t rsX = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
+    __bf16 *xo = static_cast<__bf16 *>(g.xn_out);
+    const rsrc_t rsO = make_rsrc(xo ? xo + (size_t)m0 * C : nullptr, xo ? (unsigned)rows * C * 2u : 0u);
+    const float *aff_row = nullptr;
+    if (MOD != 0) aff_row = g.mod_aff + (size_t)(MOD == 2 ? min(m0 + (int)mrow, g.M - 1) / g.mod_T : 0) * g.mod_ld + g.mod_off;
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        f32x4 rr[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) rr[q] = buf_load4(rsX, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = 32 * ct + 8 * q + 4 * lhalf;
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.b2 + c);
+            f32x4 v;
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[t] = oacc[ct][4 * q + t] + b4[t] + rr[q][t];
+            if (MOD != 0) {
+                const f32x4 scl = *reinterpret_cast<const f32x4 *>(aff_row + c), sft = *reinterpret_cast<const f32x4 *>(aff_row + C + c);
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = silu_exact(fmaf(v[t], scl[t] + 1.0f, sft[t]));
+            }
+            buf_store4(v, rsX, (mrow * C + (unsigned)c) * 4u, 0u);
+#pragma unroll
+            for (int t = 0; t < 4; t++) { ssum += v[t]; ssq = fmaf(v[t], v[t], ssq); oacc[ct][4 * q + t] = v[t]; }
+            if (g.out_mode == 2) buf_store2(pack_bf16x4(v), rsO, (mrow * C + (unsigned)c) * 2u, 0u);
+        }
+    }
+    if (g.out_mode == 1) {
+        ssum += __shfl_xor(ssum, 32, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        const float mean = ssum * (1.0f / C), rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, ssq * (1.0f / C)), 0.f) + LN_EPS), nmr = -mean * rstd;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = fmaf(oacc[ct][4 * q + t], rstd, nmr);
+                buf_store2(pack_bf16x4(v), rsO, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 2u, 0u);
+            }
+    }
+}
+
+bool launch_mlp_bx(const BxMlp &g, hipStream_t s) {
+    if (!g.xn || !g.x || !g.W1 || !g.b1 || !g.W2 || !g.b2 || g.M < 1 || (g.out_mode && !g.xn_out)) return false;
+    const dim3 grid((g.M + 127) / 128), block(256);
+    const int mod = !g.mod_aff ? 0 : (g.mod_ld == 0 ? 1 : 2);
+#define MLP_LAUNCH(C_)                                                                                   \
+    do {                                                                                                 \
+        if (mod == 0) hipLaunchKernelGGL((mlp_bx_kernel<C_, 0>), grid, block, 0, s, g);                  \
+        else if (mod == 1) hipLaunchKernelGGL((mlp_bx_kernel<C_, 1>), grid, block, 0, s, g);             \
+        else hipLaunchKernelGGL((mlp_bx_kernel<C_, 2>), grid, block, 0, s, g);                           \
+    } while (0)
+    switch (g.C) {
+        case 96: MLP_LAUNCH(96); break;
+        case 192: MLP_LAUNCH(192); break;
+        case 384: MLP_LAUNCH(384); break;
+        default: return false;
+    }
+#undef MLP_LAUNCH
+    return true;
+}
+
+// -------------------------------------------------------------------------------------------------
 // Row pass: x fp32 [M, C] -> optional modulate+SiLU in place (diffusesg.py:238-243: the modulated tensor is also the shortcut) ->
 // xn bf16 = LayerNorm of the row without affine (gamma / beta live in the consuming GEMM's weights), or, with ln == 0, the plain bf16
 // copy.  One wave per row, 16 B per lane per access.

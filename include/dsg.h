@@ -215,6 +215,11 @@ int dsg_debug_gemm_bx(int32_t M, int32_t N, int32_t K, const float *A, const flo
                       void *stream);
 int dsg_debug_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int32_t heads, const float *qkv, const float *biasT, float *out,
                       int32_t time_iters, float *out_ms, void *stream);
+/* dsg_debug_mlp_bx: the fused MLP half of a block, x [M,C] <- [modulate] (x + fc2(GELU(fc1(xn)))) in place, with xn [M,C], W1 [4C,C],
+ *   W2 [C,4C] given as fp32 and rounded to bf16 inside; mod = (scale [C] | shift [C]) or NULL; out_mode 0 none, 1 LayerNorm of the
+ *   stored row, 2 its plain copy -> out_xn [M,C] (the bf16 store widened).  C in {96, 192, 384}. */
+int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const float *W1, const float *b1, const float *W2, const float *b2,
+                     const float *mod, int32_t out_mode, float *out_xn, int32_t time_iters, float *out_ms, void *stream);
 
 /* The noise-conditioning path on its own (test / inspection hook for SURVEY fixture G1): PositionalEmbedding -> map_layer0/1 with
  * SiLU (R/model/diffusesg/diffusesg.py:507-513, :768-771) -> every `affine` linear (:238, :574) for `rows` noise labels c_noise

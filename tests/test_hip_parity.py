@@ -535,6 +535,9 @@ def test_bf16_gemm_mode_vs_reference(name, fused, pipe):
     h.set_option("gemm_bf16", 1)
     h.set_option("bf16_pipe", pipe)
     assert h.get_option("bf16_pipe") == pipe
+    # the fused MLP kernel: at every width it covers when the other kernels are "fused", not at all otherwise (the GEMM pair)
+    h.set_option("bf16_mlp", 2 if fused else 0)
+    assert h.get_option("bf16_mlp") == ((2 if fused else 0) if pipe else 0)
     for opt in ("fused_attn", "fused_mlp", "fused_readout", "fused_patch_embed"):
         h.set_option(opt, fused)
     oa, on = net(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
