@@ -53,9 +53,11 @@ __device__ __forceinline__ u32x4 buf_load_u4(rsrc_t r, unsigned voff, unsigned s
 #ifndef DSG_BX_EXP
 #define DSG_BX_EXP 0   // timing experiments of tools/bx_exp.sh (wrong results): 1 no epilogue, 2 no global loads / LDS refills, 3 no MFMAs
 #endif
-template <int WM, int WN, int KB, bool RES, int MOD>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gemm_bx_kernel(BxGemm g, int tiles_m, int tiles_n, int tiles_total) {
-    constexpr int NT = 64 * WM * WN, BM = 64 * WM, BN = 96 * WN, LDP = KB + 8;
+// MT: 32-row accumulator tiles per wave (wave tile 32 MT x 96).  MT = 1 halves a wave's registers (~125): twice the waves per SIMD on the
+// same block tile and LDS stage, at 1.6x the LDS fragment bytes per MFMA.
+template <int WM, int WN, int KB, bool RES, int MOD, int MT = 2>
+__global__ __launch_bounds__(64 * WM * WN, (MT == 2 ? 2 : 4)) void gemm_bx_kernel(BxGemm g, int tiles_m, int tiles_n, int tiles_total) {
+    constexpr int NT = 64 * WM * WN, WR = 32 * MT, BM = WR * WM, BN = 96 * WN, LDP = KB + 8;
     constexpr int CPR = KB / 8;                       // 16-byte pieces per tile row
     constexpr int RPP = NT / CPR;                     // tile rows covered by one pass of the block
     constexpr int PA = BM / RPP, PW = (BN + RPP - 1) / RPP;
@@ -130,20 +132,20 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gemm_bx_
             if (BN % RPP == 0 || sr + RPP * p < BN) *reinterpret_cast<u32x4 *>(Ws + (sr + RPP * p) * LDP + 8 * sc) = st.w[p];
     };
 
-    f32x16 acc[2][3];
-    const __bf16 *Afr = lds + (wm * 64 + lrow) * LDP + 8 * lhalf;
+    f32x16 acc[MT][3];
+    const __bf16 *Afr = lds + (wm * WR + lrow) * LDP + 8 * lhalf;
     const __bf16 *Wfr = lds + (BM + wn * 96 + lrow) * LDP + 8 * lhalf;
     auto compute = [&]() {
         if (DSG_BX_EXP == 3) return;
 #pragma unroll
         for (int s = 0; s < KB / 16; s++) {
-            bf16x8 af[2], wf[3];
+            bf16x8 af[MT], wf[3];
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) af[mt] = *reinterpret_cast<const bf16x8 *>(Afr + 32 * mt * LDP + 16 * s);
+            for (int mt = 0; mt < MT; mt++) af[mt] = *reinterpret_cast<const bf16x8 *>(Afr + 32 * mt * LDP + 16 * s);
 #pragma unroll
             for (int nt = 0; nt < 3; nt++) wf[nt] = *reinterpret_cast<const bf16x8 *>(Wfr + 32 * nt * LDP + 16 * s);
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++)
+            for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < 3; nt++) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
         }
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gemm_bx_
         const int ncol0 = wn * 96 + 4 * lhalf;          // + 32 nt + 8 q: this lane's column inside the tile
         // group = (mt, nt, qh): two accumulator quads = 8 values per lane at a time (register pressure: the next chunk is in flight)
         auto load_res = [&](f32x4 (&rr)[2], int grp) {
-            const unsigned mrow = (unsigned)(wm * 64 + 32 * (grp / 6) + lrow);
+            const unsigned mrow = (unsigned)(wm * WR + 32 * (grp / 6) + lrow);
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const int n = n0 + ncol0 + 32 * ((grp >> 1) % 3) + 8 * (2 * (grp & 1) + q);
@@ -176,12 +178,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gemm_bx_
         };
         f32x4 rra[2], rrb[2];
         if (RES) load_res(rra, 0);
-        float ssum[2] = {0.f, 0.f}, ssq[2] = {0.f, 0.f};
+        float ssum[MT], ssq[MT];
 #pragma unroll
-        for (int grp = 0; grp < 12; grp++) {
+        for (int mt = 0; mt < MT; mt++) { ssum[mt] = 0.f; ssq[mt] = 0.f; }
+#pragma unroll
+        for (int grp = 0; grp < 6 * MT; grp++) {
             const int mt = grp / 6, nt = (grp >> 1) % 3, q0 = 2 * (grp & 1);
-            const unsigned mrow = (unsigned)(wm * 64 + 32 * mt + lrow);
-            if (RES && grp + 1 < 12) { if (grp & 1) load_res(rra, grp + 1); else load_res(rrb, grp + 1); }
+            const unsigned mrow = (unsigned)(wm * WR + 32 * mt + lrow);
+            if (RES && grp + 1 < 6 * MT) { if (grp & 1) load_res(rra, grp + 1); else load_res(rrb, grp + 1); }
             f32x4 v[2], scl[2], sft[2];
 #pragma unroll
             for (int q = 0; q < 2; q++) {
@@ -250,8 +254,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gemm_bx_
         }
         if (ln) {
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) {
-                const unsigned mrow = (unsigned)(wm * 64 + 32 * mt + lrow);
+            for (int mt = 0; mt < MT; mt++) {
+                const unsigned mrow = (unsigned)(wm * WR + 32 * mt + lrow);
                 ssum[mt] += __shfl_xor(ssum[mt], 32, 64);
                 ssq[mt] += __shfl_xor(ssq[mt], 32, 64);
                 if (lhalf == 0) part[mrow * WN + wn] = (f32x2){ssum[mt], ssq[mt]};
@@ -259,8 +263,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gemm_bx_
             __syncthreads();
             const float invn = 1.0f / (float)g.N;
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++) {
-                const unsigned mrow = (unsigned)(wm * 64 + 32 * mt + lrow);
+            for (int mt = 0; mt < MT; mt++) {
+                const unsigned mrow = (unsigned)(wm * WR + 32 * mt + lrow);
                 float sm = 0.f, sq = 0.f;
 #pragma unroll
                 for (int w2 = 0; w2 < WN; w2++) { const f32x2 p2 = part[mrow * WN + w2]; sm += p2[0]; sq += p2[1]; }
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gemm_bx_
             cv[2][i] = (MOD == 1 && ok) ? g.mod_aff[g.mod_off + g.N + n] : 0.f;
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++)
+        for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int nt = 0; nt < 3; nt++)
 #pragma unroll
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 ? 2 : 1)) void gemm_bx_
         if (DSG_BX_EXP == 1) {           // keep the accumulators alive, store nothing of substance
             float keep = 0.f;
 #pragma unroll
-            for (int mt = 0; mt < 2; mt++)
+            for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int nt = 0; nt < 3; nt++) keep += acc[mt][nt][0];
             if (keep == 123.456f && g.C) g.C[0] = keep;
@@ -403,22 +407,24 @@ bool launch_gemm_bx(const BxGemm &g, hipStream_t s) {
     const int resident = std::max(8, bx_cu_count() * (geo == 3 ? 1 : 2) / 8 * 8);
     const dim3 grid(std::min(tiles_total, resident));
     const int mod = !g.mod_aff ? 0 : (g.mod_ld == 0 ? 1 : 2);
-#define BX_LAUNCH(WM_, WN_, KB_, NT_)                                                                                                      \
+#define BX_LAUNCH(WM_, WN_, KB_, NT_, MT_)                                                                                                 \
     do {                                                                                                                                   \
         if (g.res) {                                                                                                                       \
-            if (mod == 0) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 0>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);        \
-            else if (mod == 1) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 1>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);   \
-            else hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 2>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);                 \
+            if (mod == 0) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 0, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);        \
+            else if (mod == 1) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 1, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);   \
+            else hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 2, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);                 \
         } else {                                                                                                                           \
-            if (mod == 0) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 0>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);       \
-            else if (mod == 1) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 1>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);  \
-            else hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 2>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);                \
+            if (mod == 0) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 0, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);       \
+            else if (mod == 1) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 1, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);  \
+            else hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 2, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);                \
         }                                                                                                                                  \
     } while (0)
+    // (MT = 1 -- 32 x 96 wave tiles, ~125 registers, four waves per SIMD on the same block tiles -- measured within 3 % of these on
+    //  every shape, slower on the long-K ones: profiles/r3/bx_experiments.txt; not instantiated)
     switch (geo) {
-        case 0: BX_LAUNCH(2, 2, 64, 256); break;
-        case 2: BX_LAUNCH(4, 1, 32, 256); break;
-        default: BX_LAUNCH(2, 4, 64, 512); break;
+        case 0: BX_LAUNCH(2, 2, 64, 256, 2); break;
+        case 2: BX_LAUNCH(4, 1, 32, 256, 2); break;
+        default: BX_LAUNCH(2, 4, 64, 512, 2); break;
     }
 #undef BX_LAUNCH
     return true;
