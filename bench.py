@@ -286,13 +286,17 @@ def worker(args):
         # the committed rocprofv3 --pmc passes over this same command (tools/pmc_traffic.sh -> profiles/*/pmc_traffic.json)
         traffic, traffic_src = None, None
         prof_root = os.path.join(ROOT, "profiles")
+        # (file, kernel family, condition): the committed PMC passes exist for the headline workload and for configs[4]'s per-GPU share
+        pmc_sets = [("pmc_traffic.json", "gemm4_f32_kernel", args.config == "vg" and B == 64 and mode == "f32"),
+                    ("pmc_traffic_coco_bf16.json", "gemm_bx_kernel", args.config == "coco" and B == 512 and mode == "bf16")]
         for rnd in sorted(os.listdir(prof_root), reverse=True) if os.path.isdir(prof_root) else []:
-            pj = os.path.join(prof_root, rnd, "pmc_traffic.json")
-            if os.path.exists(pj) and args.config == "vg" and B == 64 and mode == "f32":
-                tj = json.load(open(pj))
-                traffic = tj["kernels"]["gemm4_f32_kernel"]["hbm_bytes_per_launch"]
-                traffic_src = f"profiles/{rnd}/pmc_traffic.json"
-                break
+            for fname, fam, cond in pmc_sets:
+                pj = os.path.join(prof_root, rnd, fname)
+                if cond and traffic is None and os.path.exists(pj):
+                    tj = json.load(open(pj))
+                    if fam in tj.get("kernels", {}):
+                        traffic = tj["kernels"][fam]["hbm_bytes_per_launch"]
+                        traffic_src = f"profiles/{rnd}/{fname} (committed rocprofv3 --pmc passes of this command from an earlier run of this build's kernels, not this process)"
         # peak of the pipe the dominant kernel runs on, in ALGORITHMIC (2*M*N*K) FLOP/s: the split kernel issues six bf16
         # MFMA products per algorithmic product, so its ceiling is the bf16 dense peak / 6
         bf16_kern = "gemm_bx_kernel" if (mode == "bf16" and h.get_option("bf16_pipe")) else "gemm_bf16_kernel"
