@@ -139,8 +139,11 @@ struct dsg_handle_s {
     std::vector<Tap> taps;
     // training form (dsg_train_*): saved-activation arena and backward scratch, owned by the handle and kept between calls
     // (hipMalloc / hipFree of ~10 GB per iteration cost more than a tenth of it); they only grow
-    float *train_arena = nullptr, *train_scr = nullptr;
-    size_t train_arena_cap = 0, train_scr_cap = 0;
+    float *train_arena = nullptr, *train_scr = nullptr, *train_io = nullptr, *train_mid = nullptr;
+    size_t train_arena_cap = 0, train_scr_cap = 0, train_io_cap = 0, train_mid_cap = 0;
+    int *train_const = nullptr;                                   // device {0, 1}: the "self-conditioning present" switch of launch_assemble
+    // dsg_train_bind_params: parameters the training form reads in place (the optimiser's own device tensors) instead of the handle's copies
+    std::unordered_map<std::string, const float *> train_params;
     dsg_sample_stats last_stats{};
     // per-kernel-class timing (dsg_profile_forward): HIP events bracketing every launch on the launch stream
     bool prof_on = false;          // HIP-event brackets around every launch
@@ -557,6 +560,9 @@ void dsg_destroy(dsg_handle h) {
     if (h->tab_step) (void)hipFree(h->tab_step);
     if (h->train_arena) (void)hipFree(h->train_arena);
     if (h->train_scr) (void)hipFree(h->train_scr);
+    if (h->train_io) (void)hipFree(h->train_io);
+    if (h->train_mid) (void)hipFree(h->train_mid);
+    if (h->train_const) (void)hipFree(h->train_const);
     for (auto &kv : h->ws) {
         if (kv.second->cap_stream) (void)hipStreamDestroy(kv.second->cap_stream);
         for (void *p : kv.second->allocs) (void)hipFree(p);
@@ -2033,6 +2039,17 @@ struct TArena {   // bump allocator over one hipMalloc
 struct TLin { const float *x; float *y; };   // nothing else: linears keep their input pointer in the stage structs below
 }  // namespace
 
+// a handle-owned device buffer of at least `need` floats (grown after draining the stream that may still read the old one)
+static float *train_buf(dsg_handle h, float *&buf, size_t &cap, size_t need, hipStream_t s) {
+    if (need > cap) {
+        if (buf) { (void)hipStreamSynchronize(s); (void)hipFree(buf); }
+        buf = nullptr; cap = 0;
+        if (hipMalloc((void **)&buf, sizeof(float) * need) != hipSuccess) { buf = nullptr; return nullptr; }
+        cap = need;
+    }
+    return buf;
+}
+
 // `mid` (optional) runs between forward and backward on the same stream and fills dL/dF from the forward's outputs
 typedef std::function<int(const float *F_adj, const float *F_node, float *dF_adj, float *dF_node)> TrainMid;
 static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const float *in_node, const uint8_t *flags, const float *c_noise,
@@ -2052,14 +2069,21 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
     std::unordered_map<std::string, float *> gmap;
     if (bwd) for (int k = 0; k < n_params; k++) if (names[k] && grad_params[k]) gmap[names[k]] = grad_params[k];
     std::string missing;
-    auto Wt = [&](const std::string &k) -> float * { auto it = h->w.find(k); if (it == h->w.end()) { if (missing.empty()) missing = k; return nullptr; } return it->second.p; };
+    auto Wt = [&](const std::string &k) -> float * {
+        if (!h->train_params.empty()) { auto bt = h->train_params.find(k); if (bt != h->train_params.end()) return const_cast<float *>(bt->second); }
+        auto it = h->w.find(k); if (it == h->w.end()) { if (missing.empty()) missing = k; return nullptr; } return it->second.p; };
     auto Gd = [&](const std::string &k) -> float * { if (!bwd) return nullptr; auto it = gmap.find(k); if (it == gmap.end()) { if (missing.empty()) missing = "grad:" + k; return nullptr; } return it->second; };
     // collect the blocks in execution order
     struct Stage { const BlockPlan *bp; TrainBlockArgs a; float *x_in, *x_out, *d_emb; };
     std::vector<Stage> enc[8], dec[8];
     TArena A;
-    int has_sc_host = (h->cfg.self_condition && sc_adj) ? 1 : 0;
-    int *has_sc_dev = nullptr;
+    const int has_sc_host = (h->cfg.self_condition && sc_adj) ? 1 : 0;
+    if (!h->train_const) {
+        const int zo[2] = {0, 1};
+        HIP_TRY(h, hipMalloc((void **)&h->train_const, sizeof(zo)));
+        HIP_TRY(h, hipMemcpy(h->train_const, zo, sizeof(zo), hipMemcpyHostToDevice));
+    }
+    const int *has_sc_dev = h->train_const + has_sc_host;
     // everything below runs twice: a dry pass that only sizes the arena, then the real pass
     struct Bufs {
         float *pe, *m0, *s0, *m1, *emb, *d_emb, *tok, *pe_lin, *pe_ln, *pe_stats, *pe_aff, *pe_daff, *x0;
@@ -2132,8 +2156,6 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
                 h->train_arena_cap = A.cap + 16;
             }
             A.base = h->train_arena;
-            HIP_TRY(h, hipMalloc((void **)&has_sc_dev, sizeof(int)));
-            HIP_TRY(h, hipMemcpy(has_sc_dev, &has_sc_host, sizeof(int), hipMemcpyHostToDevice));
         }
     }
     // widest scratch tensors (backward): sized for level 0's [M0, 4E]; every level has M C constant up to the 2x of merging
@@ -2142,7 +2164,7 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
     if (scr_need > h->train_scr_cap) {
         if (h->train_scr) { (void)hipStreamSynchronize(s); (void)hipFree(h->train_scr); }
         h->train_scr = nullptr; h->train_scr_cap = 0;
-        if (hipMalloc((void **)&h->train_scr, sizeof(float) * scr_need) != hipSuccess) { (void)hipFree(has_sc_dev); return fail(h, DSG_ERR_HIP, "out of memory"); }
+        if (hipMalloc((void **)&h->train_scr, sizeof(float) * scr_need) != hipSuccess) return fail(h, DSG_ERR_HIP, "out of memory");
         h->train_scr_cap = scr_need;
     }
     float *scr = h->train_scr;
@@ -2165,7 +2187,22 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
     launch_assemble(in_adj, in_node, sc_adj, sc_node, has_sc_dev, flags, Bf.tok, B, N, Ca, Cn, h->cfg.self_condition, Cin, s);
     lin_fwd(Bf.tok, Wt("patch_embed.proj.weight"), Wt("patch_embed.proj.bias"), Bf.pe_lin, M0, Cin, E);
     t_ln_fwd(Bf.pe_lin, Wt("patch_embed.norm.weight"), Wt("patch_embed.norm.bias"), Bf.pe_ln, Bf.pe_stats, (int)M0, E, s);
-    lin_fwd(Bf.emb, Wt("patch_embed.affine.weight"), Wt("patch_embed.affine.bias"), Bf.pe_aff, B, NOISE_EMB, 2 * E);
+    // every `affine` linear of the network (PatchEmbed + all blocks) hangs off emb: one grouped launch
+    std::vector<Stage *> all_stages;
+    for (int l = 0; l < L; l++) for (auto &st : enc[l]) all_stages.push_back(&st);
+    for (int i = 0; i < L; i++) for (auto &st : dec[i]) all_stages.push_back(&st);
+    const bool grouped = (int)all_stages.size() + 1 <= T_GROUP_MAX;
+    if (grouped) {
+        TGemmGroup gf;
+        gf.p[gf.n++] = TGemmProb{Bf.emb, Wt("patch_embed.affine.weight"), Wt("patch_embed.affine.bias"), Bf.pe_aff, NOISE_EMB, NOISE_EMB, 2 * E, B, 2 * E, NOISE_EMB};
+        for (Stage *st : all_stages) {
+            st->a.aff_grouped = true;
+            gf.p[gf.n++] = TGemmProb{Bf.emb, st->a.W.aff_w, st->a.W.aff_b, st->a.aff, NOISE_EMB, NOISE_EMB, 2 * st->a.C, B, 2 * st->a.C, NOISE_EMB};
+        }
+        t_gemm_grouped(false, true, false, gf, s);
+    } else {
+        lin_fwd(Bf.emb, Wt("patch_embed.affine.weight"), Wt("patch_embed.affine.bias"), Bf.pe_aff, B, NOISE_EMB, 2 * E);
+    }
     t_modulate(Bf.pe_ln, Bf.pe_aff, nullptr, Bf.x0, nullptr, B, T0, E, false, s);
     const float *x = Bf.x0;
     int res = N, C = E;
@@ -2219,14 +2256,14 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
     lin_fwd(Bf.hn, Wt("readout_node_mlp.fc2.weight"), Wt("readout_node_mlp.fc2.bias"), Bf.on, (size_t)B * N, E, Cn);
     t_rowmask(Bf.on, flags, out_F_node, (size_t)B * N, Cn, s);
     // ================================ backward ================================
-    float *mid_buf = nullptr;
     if (bwd && ok && mid) {
         const size_t na = (size_t)B * Ca * N * N, nn = (size_t)B * N * Cn;
-        if (hipMalloc((void **)&mid_buf, sizeof(float) * (na + nn)) != hipSuccess) ok = false;
+        float *mid_buf = train_buf(h, h->train_mid, h->train_mid_cap, na + nn, s);
+        if (!mid_buf) ok = false;
         else { ok = (*mid)(out_F_adj, out_F_node, mid_buf, mid_buf + na) == DSG_OK; grad_F_adj = mid_buf; grad_F_node = mid_buf + na; }
     }
     if (bwd && ok) {
-        hipError_t e0 = hipMemsetAsync(Bf.d_emb, 0, sizeof(float) * (size_t)B * NOISE_EMB, s);
+        hipError_t e0 = grouped ? hipSuccess : hipMemsetAsync(Bf.d_emb, 0, sizeof(float) * (size_t)B * NOISE_EMB, s);
         for (int l = 0; l < L && e0 == hipSuccess; l++) e0 = hipMemsetAsync(Bf.d_skip[l], 0, sizeof(float) * (size_t)B * skip_res[l] * skip_res[l] * skip_C[l], s);
         ok = ok && e0 == hipSuccess;
         // heads
@@ -2249,10 +2286,7 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
         t_colsum(d_z1, E, Gd("read_out.0.bias"), (int)M0, E, s);
         t_gemm(false, true, d_z1, E, Wt("read_out.0.weight"), E, nullptr, d_fy, E, (int)M0, E, E, false, s);        // dy = dz W^T
         float *dx = d_x;   // running gradient wrt the current activation x (size up to M0*E*2)
-        ok = ok && hipMemsetAsync(dx, 0, sizeof(float) * M0 * E, s) == hipSuccess;
-        t_ln_bwd(xL, Wt("norm.weight"), Bf.fstats, d_fy, dx, t_mc2, (int)M0, E, s);
-        t_colsum(t_mc2, E, Gd("norm.weight"), (int)M0, E, s);
-        t_colsum(d_fy, E, Gd("norm.bias"), (int)M0, E, s);
+        t_ln_bwd(xL, Wt("norm.weight"), Bf.fstats, d_fy, nullptr, dx, Gd("norm.weight"), Gd("norm.bias"), (int)M0, E, s);
         // blocks / up / down in reverse
         float *dcur = dx, *dnext = d_y;   // ping-pong
         auto run_blocks_bwd = [&](std::vector<Stage> &v) {
@@ -2264,7 +2298,7 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
                 a.d_x1 = t_w; a.t_mc = t_mc; a.t_mc2 = t_mc2; a.t_m3c = t_m3c; a.t_mh = t_mh;
                 (void)M; (void)Cc; (void)H;
                 ok = ok && train_block_backward(a, s);
-                t_add(Bf.d_emb, st.d_emb, (size_t)B * NOISE_EMB, s);
+                if (!a.aff_grouped) t_add(Bf.d_emb, st.d_emb, (size_t)B * NOISE_EMB, s);
                 std::swap(dcur, dnext);
             }
         };
@@ -2278,15 +2312,10 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
                 const int rc = res / 2, Cc = 2 * C; const size_t Mi = (size_t)B * rc * rc; const int D = 2 * Cc, Co = D / 4;
                 float *d_upn = t_mh, *d_usc = t_m3c, *d_un = t_w, *d_uy = t_mh, *d_cat = t_m3c;
                 lin_bwd(Bf.upn[i], Wt(p + ".post_linear.weight"), dcur, d_upn, Gd(p + ".post_linear.weight"), nullptr, 4 * Mi, Co, Co);
-                ok = ok && hipMemsetAsync(d_usc, 0, sizeof(float) * 4 * Mi * Co, s) == hipSuccess;
-                t_ln_bwd(Bf.usc[i], Wt(p + ".post_norm.weight"), Bf.upstats[i], d_upn, d_usc, t_mc2, (int)(4 * Mi), Co, s);
-                t_colsum(t_mc2, Co, Gd(p + ".post_norm.weight"), (int)(4 * Mi), Co, s);
-                t_colsum(d_upn, Co, Gd(p + ".post_norm.bias"), (int)(4 * Mi), Co, s);
+                t_ln_bwd(Bf.usc[i], Wt(p + ".post_norm.weight"), Bf.upstats[i], d_upn, nullptr, d_usc, Gd(p + ".post_norm.weight"), Gd(p + ".post_norm.bias"),
+                         (int)(4 * Mi), Co, s);
                 t_regroup(d_usc, d_un, B, res, Co, true, s);   // transpose of the scatter = gather
-                ok = ok && hipMemsetAsync(d_uy, 0, sizeof(float) * Mi * D, s) == hipSuccess;
-                t_ln_bwd(Bf.uy[i], Wt(p + ".norm.weight"), Bf.ustats[i], d_un, d_uy, t_mc2, (int)Mi, D, s);
-                t_colsum(t_mc2, D, Gd(p + ".norm.weight"), (int)Mi, D, s);
-                t_colsum(d_un, D, Gd(p + ".norm.bias"), (int)Mi, D, s);
+                t_ln_bwd(Bf.uy[i], Wt(p + ".norm.weight"), Bf.ustats[i], d_un, nullptr, d_uy, Gd(p + ".norm.weight"), Gd(p + ".norm.bias"), (int)Mi, D, s);
                 lin_bwd(Bf.ucat[i], Wt(p + ".pre_linear.weight"), d_uy, d_cat, Gd(p + ".pre_linear.weight"), nullptr, Mi, D, D);
                 t_split(d_cat, dnext, Bf.d_skip[lvl], Mi, Cc, s);
                 std::swap(dcur, dnext);
@@ -2301,10 +2330,7 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
                 const int rf = res * 2, Cf = C / 2; const size_t M2 = (size_t)B * res * res;
                 float *d_nrm = t_mh, *d_cat = t_m3c;
                 lin_bwd(Bf.mnrm[l], Wt(p + ".reduction.weight"), dcur, d_nrm, Gd(p + ".reduction.weight"), nullptr, M2, 4 * Cf, 2 * Cf);
-                ok = ok && hipMemsetAsync(d_cat, 0, sizeof(float) * M2 * 4 * Cf, s) == hipSuccess;
-                t_ln_bwd(Bf.mcat[l], Wt(p + ".norm.weight"), Bf.mstats[l], d_nrm, d_cat, t_w, (int)M2, 4 * Cf, s);
-                t_colsum(t_w, 4 * Cf, Gd(p + ".norm.weight"), (int)M2, 4 * Cf, s);
-                t_colsum(d_nrm, 4 * Cf, Gd(p + ".norm.bias"), (int)M2, 4 * Cf, s);
+                t_ln_bwd(Bf.mcat[l], Wt(p + ".norm.weight"), Bf.mstats[l], d_nrm, nullptr, d_cat, Gd(p + ".norm.weight"), Gd(p + ".norm.bias"), (int)M2, 4 * Cf, s);
                 t_regroup(d_cat, dnext, B, rf, Cf, false, s);   // transpose of the gather = scatter back to the fine grid
                 std::swap(dcur, dnext);
                 res = rf; C = Cf;
@@ -2314,13 +2340,26 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
         // PatchEmbed: modulate <- LN <- 1x1 conv (the inputs are leaves)
         float *d_pe_ln = dnext, *d_pe_lin = t_mh;
         t_modulate(Bf.pe_ln, Bf.pe_aff, dcur, d_pe_ln, Bf.pe_daff, B, T0, E, true, s);
-        t_gemm(true, false, Bf.pe_daff, 2 * E, Bf.emb, NOISE_EMB, nullptr, Gd("patch_embed.affine.weight"), NOISE_EMB, 2 * E, NOISE_EMB, B, false, s);
-        t_colsum(Bf.pe_daff, 2 * E, Gd("patch_embed.affine.bias"), B, 2 * E, s);
-        t_gemm(false, false, Bf.pe_daff, 2 * E, Wt("patch_embed.affine.weight"), NOISE_EMB, nullptr, Bf.d_emb, NOISE_EMB, B, NOISE_EMB, 2 * E, true, s);
-        ok = ok && hipMemsetAsync(d_pe_lin, 0, sizeof(float) * M0 * E, s) == hipSuccess;
-        t_ln_bwd(Bf.pe_lin, Wt("patch_embed.norm.weight"), Bf.pe_stats, d_pe_ln, d_pe_lin, t_mc2, (int)M0, E, s);
-        t_colsum(t_mc2, E, Gd("patch_embed.norm.weight"), (int)M0, E, s);
-        t_colsum(d_pe_ln, E, Gd("patch_embed.norm.bias"), (int)M0, E, s);
+        if (grouped) {
+            // the affine linears' own backward, all at once: dWa_z = d_aff_z^T emb, d_ba_z = colsum(d_aff_z), d_emb = sum_z d_aff_z Wa_z
+            TGemmGroup gw, gb, ge;
+            auto add = [&](const float *d_aff, const float *Wa, float *dWa, float *dba, int C2) {
+                gw.p[gw.n++] = TGemmProb{d_aff, Bf.emb, nullptr, dWa, C2, NOISE_EMB, NOISE_EMB, C2, NOISE_EMB, B};
+                gb.p[gb.n++] = TGemmProb{d_aff, nullptr, nullptr, dba, C2, 0, 0, B, C2, 0};
+                ge.p[ge.n++] = TGemmProb{d_aff, Wa, nullptr, Bf.d_emb, C2, NOISE_EMB, NOISE_EMB, B, NOISE_EMB, C2};
+            };
+            add(Bf.pe_daff, Wt("patch_embed.affine.weight"), Gd("patch_embed.affine.weight"), Gd("patch_embed.affine.bias"), 2 * E);
+            for (Stage *st : all_stages) add(st->a.d_aff, st->a.W.aff_w, st->a.G.aff_w, st->a.G.aff_b, 2 * st->a.C);
+            t_gemm_grouped(true, false, false, gw, s);
+            t_colsum_grouped(gb, s);
+            t_gemm_grouped(false, false, true, ge, s);
+        } else {
+            t_gemm(true, false, Bf.pe_daff, 2 * E, Bf.emb, NOISE_EMB, nullptr, Gd("patch_embed.affine.weight"), NOISE_EMB, 2 * E, NOISE_EMB, B, false, s);
+            t_colsum(Bf.pe_daff, 2 * E, Gd("patch_embed.affine.bias"), B, 2 * E, s);
+            t_gemm(false, false, Bf.pe_daff, 2 * E, Wt("patch_embed.affine.weight"), NOISE_EMB, nullptr, Bf.d_emb, NOISE_EMB, B, NOISE_EMB, 2 * E, true, s);
+        }
+        t_ln_bwd(Bf.pe_lin, Wt("patch_embed.norm.weight"), Bf.pe_stats, d_pe_ln, nullptr, d_pe_lin, Gd("patch_embed.norm.weight"), Gd("patch_embed.norm.bias"),
+                 (int)M0, E, s);
         lin_bwd(Bf.tok, Wt("patch_embed.proj.weight"), d_pe_lin, nullptr, Gd("patch_embed.proj.weight"), Gd("patch_embed.proj.bias"), M0, Cin, E);
         // noise embedding: emb = silu(map1(silu(map0(pe))))
         float *d_m1 = t_mc, *d_s0 = t_mc2;
@@ -2329,11 +2368,9 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
         t_silu(Bf.m0, d_s0, d_s0, (size_t)B * NOISE_EMB, true, s);
         lin_bwd(Bf.pe, Wt("map_layer0.weight"), d_s0, nullptr, Gd("map_layer0.weight"), Gd("map_layer0.bias"), B, E, NOISE_EMB);
     }
-    const hipError_t e = hipStreamSynchronize(s);
-    const hipError_t e2 = hipGetLastError();
-    (void)hipFree(has_sc_dev); (void)hipFree(mid_buf);
-    HIP_TRY(h, e);
-    HIP_TRY(h, e2);
+    // everything is queued on the caller's stream and every buffer involved outlives the call (caller's or the handle's): no
+    // synchronisation here -- the host runs ahead into the optimiser step's launches
+    HIP_TRY(h, hipGetLastError());
     if (!ok) return fail(h, DSG_ERR_HIP, "a training kernel failed to launch");
     if (t_scratch_failed(s, true)) return fail(h, DSG_ERR_HIP, "out of memory (training scratch of this stream)");
     return DSG_OK;
@@ -2359,9 +2396,10 @@ int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const 
     hipStream_t s = (hipStream_t)stream;
     const Dims d = dims_of(h, B);
     const size_t na = (size_t)B * h->Ca * h->N * h->N, nn = (size_t)B * h->N * h->Cn;
-    float *buf = nullptr;   // in_adj | in_node | c_noise | F_adj | F_node
-    HIP_TRY(h, hipMalloc((void **)&buf, sizeof(float) * (2 * na + 2 * nn + (size_t)B + 64)));
-    float *in_a = buf, *in_n = in_a + na, *cn = in_n + nn, *F_a = cn + ((B + 63) / 64) * 64, *F_n = F_a + na;
+    // in_adj | in_node | c_noise | F_adj | F_node | dL/dD (adj, node): handle-owned, kept between calls
+    float *buf = train_buf(h, h->train_io, h->train_io_cap, 3 * na + 3 * nn + (size_t)B + 64, s);
+    if (!buf) return fail(h, DSG_ERR_HIP, "out of memory");
+    float *in_a = buf, *in_n = in_a + na, *cn = in_n + nn, *F_a = cn + ((B + 63) / 64) * 64, *F_n = F_a + na, *tmp = F_n + nn;
     launch_precond_in(CStatePtrs{noisy_adj, noisy_node}, sigmas, StatePtrs{in_a, in_n}, cn, d, s);   // c_in * x, c_noise = ln(sigma)/4
     const TrainMid mid = [&](const float *Fa, const float *Fn, float *dFa, float *dFn) -> int {
         // D = mask(c_skip x + c_out F) (precond.py:101-104); per-sample losses; dL/dD; dL/dF = c_out dL/dD
@@ -2369,21 +2407,49 @@ int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const 
                            StatePtrs{nullptr, nullptr}, d, s);
         launch_rainbow_loss(CStatePtrs{out_D_adj, out_D_node}, CStatePtrs{target_adj, target_node}, flags, loss_weight, edge_loss_weight,
                             node_loss_weight, iou_loss_weight, iou_loss_type, out_loss_adj, out_loss_node, d, s);
-        float *tmp = nullptr;
-        if (hipMalloc((void **)&tmp, sizeof(float) * (na + nn)) != hipSuccess) return DSG_ERR_HIP;
         launch_rainbow_loss_backward(CStatePtrs{out_D_adj, out_D_node}, CStatePtrs{target_adj, target_node}, flags, loss_weight,
                                      edge_loss_weight, node_loss_weight, iou_loss_weight, iou_loss_type, sigmas, StatePtrs{tmp, tmp + na},
                                      StatePtrs{dFa, dFn}, d, s);
-        const hipError_t e = hipStreamSynchronize(s);
-        (void)hipFree(tmp);
-        return e == hipSuccess ? DSG_OK : DSG_ERR_HIP;
+        return hipGetLastError() == hipSuccess ? DSG_OK : DSG_ERR_HIP;
     };
     const bool want_grads = names && grad_params && n_params > 0;
     int rc = train_grads_core(h, B, in_a, in_n, flags, cn, sc_adj, sc_node, nullptr, nullptr, want_grads ? &mid : nullptr, F_a, F_n, n_params, names,
                               grad_params, stream);
     if (rc == DSG_OK && !want_grads) rc = mid(F_a, F_n, in_a, in_n);   // forward only: still report D and the losses (gradients discarded)
-    (void)hipFree(buf);
     return rc;
+}
+
+int dsg_train_self_cond(dsg_handle h, int32_t B, const float *noisy_adj, const float *noisy_node, const uint8_t *flags, const float *sigmas,
+                        float *out_sc_adj, float *out_sc_node, void *stream) {
+    if (!h || !h->ever_finalized) return fail(h, DSG_ERR_STATE, "weights not finalized");
+    if (B < 1 || !noisy_adj || !noisy_node || !flags || !sigmas || !out_sc_adj || !out_sc_node) return fail(h, DSG_ERR_INVALID, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const Dims d = dims_of(h, B);
+    const size_t na = (size_t)B * h->Ca * h->N * h->N, nn = (size_t)B * h->N * h->Cn;
+    float *buf = train_buf(h, h->train_io, h->train_io_cap, 3 * na + 3 * nn + (size_t)B + 64, s);
+    if (!buf) return fail(h, DSG_ERR_HIP, "out of memory");
+    float *in_a = buf, *in_n = in_a + na, *cn = in_n + nn, *F_a = cn + ((B + 63) / 64) * 64, *F_n = F_a + na;
+    launch_precond_in(CStatePtrs{noisy_adj, noisy_node}, sigmas, StatePtrs{in_a, in_n}, cn, d, s);
+    const int rc = train_grads_core(h, B, in_a, in_n, flags, cn, nullptr, nullptr, nullptr, nullptr, nullptr, F_a, F_n, 0, nullptr, nullptr, stream);
+    if (rc != DSG_OK) return rc;
+    launch_precond_out(CStatePtrs{noisy_adj, noisy_node}, CStatePtrs{F_a, F_n}, sigmas, flags, StatePtrs{out_sc_adj, out_sc_node},
+                       StatePtrs{nullptr, nullptr}, d, s);
+    HIP_TRY(h, hipGetLastError());
+    return DSG_OK;
+}
+
+int dsg_train_bind_params(dsg_handle h, int32_t n_params, const char *const *names, const float *const *params) {
+    if (!h || n_params < 0 || (n_params > 0 && (!names || !params))) return fail(h, DSG_ERR_INVALID, "null argument");
+    h->train_params.clear();
+    for (int k = 0; k < n_params; k++) {
+        if (!names[k] || !params[k]) { h->train_params.clear(); return fail(h, DSG_ERR_INVALID, "null entry %d", k); }
+        const std::string key = strip_prefix(names[k]);
+        bool known = false;
+        for (auto &sp : h->specs) if (sp.key == key) { known = !sp.is_index && !sp.is_mask; break; }
+        if (!known) { h->train_params.clear(); return fail(h, DSG_ERR_WEIGHTS, "unexpected key '%s'", names[k]); }
+        h->train_params[key] = params[k];
+    }
+    return DSG_OK;
 }
 
 int dsg_adam_step(int32_t n_tensors, float *const *params, float *const *grads, float *const *exp_avg, float *const *exp_avg_sq,

@@ -5,7 +5,10 @@
 
 namespace dsg {
 
-enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2,
+           // training-form products of the fp32 GEMM only (launch_gemm): GELU whose pre-activation is kept in C2 (the backward needs it);
+           // the product multiplied by GELU'(res) -- `res` is that kept pre-activation (the backward through fc2 and the GELU in one pass)
+           ACT_GELU_KEEP = 3, ACT_DGELU = 4 };
 
 // geometry of one Swin block's windows
 struct WinGeom {
@@ -209,13 +212,23 @@ struct TrainBlockArgs {
     // saved forward tensors and scratch (caller-allocated): aff / d_aff [B, 2C]; x_mod, xn1, att, x1, xn2, d_x1, t_mc, t_mc2 [M, C];
     // stats1, stats2 [M, 2]; qkv, t_m3c [M, 3C]; pre, hid, t_mh [M, hidden]
     float *aff, *d_aff, *x_mod, *xn1, *att, *x1, *xn2, *d_x1, *t_mc, *t_mc2, *stats1, *stats2, *qkv, *t_m3c, *pre, *hid, *t_mh;
+    // whole-network step: a.aff is already filled (one grouped launch for all blocks) and the affine linear's own backward
+    // (dW, db, d_emb from a.d_aff) is left to grouped launches at the end
+    bool aff_grouped = false;
 };
+// a group of small products in one launch (t_gemm_grouped / t_colsum_grouped): C = op(A) op(B) (+ bias)
+struct TGemmProb { const float *A, *B, *bias; float *C; int lda, ldb, ldc, M, N, K; };
+constexpr int T_GROUP_MAX = 32;
+struct TGemmGroup { TGemmProb p[T_GROUP_MAX]; int n = 0; };
+void t_gemm_grouped(bool ta, bool tb, bool sum, const TGemmGroup &g, hipStream_t s);   // sum: ONE output = the sum of the products (shared M, N, C)
+void t_colsum_grouped(const TGemmGroup &g, hipStream_t s);                             // p.C[n] = sum_m p.A[m][n] per problem
 bool train_block(const TrainBlockArgs &a, hipStream_t s);            // forward; + backward when a.grad_out is set
 bool train_block_backward(const TrainBlockArgs &a, hipStream_t s);   // backward alone, from the tensors the forward left in `a`
 // building blocks of the whole-network training step (same file): C (+)= op(A) op(B) (+ bias), column sums, elementwise / row ops
 // a_colsum (weight-gradient products, ta && !tb): also out[m] = sum_k A[k][m], the bias gradient that goes with dW = dy^T x
 void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K,
-            bool accumulate, hipStream_t s, float *a_colsum = nullptr);
+            bool accumulate, hipStream_t s, float *a_colsum = nullptr, const float *res = nullptr, int act = ACT_NONE, float *c2 = nullptr);
+// res: C = res + product (same pitch as C); act = ACT_GELU_KEEP: c2 = product + bias, C = GELU(c2); act = ACT_DGELU: C = product * GELU'(res)
 // scratch of the training kernels is kept per stream (train_kernels.hip); a failed allocation is reported here, once
 bool t_scratch_failed(hipStream_t s, bool clear);
 void t_scratch_release();
@@ -224,7 +237,9 @@ void t_silu(const float *x, const float *dy, float *out, size_t n, bool bwd, hip
 void t_gelu(const float *x, const float *dy, float *out, size_t n, bool bwd, hipStream_t s);
 void t_add(float *a, const float *b, size_t n, hipStream_t s);
 void t_ln_fwd(const float *x, const float *gam, const float *bet, float *y, float *stats, int M, int C, hipStream_t s);
-void t_ln_bwd(const float *x, const float *gam, const float *stats, const float *dy, float *dx_acc, float *xhat_dy, int M, int C, hipStream_t s);
+// dx_out = (dx_in ? dx_in : 0) + LayerNorm backward of dy; d_gamma / d_beta (either may be null) = the affine parameters' gradients
+void t_ln_bwd(const float *x, const float *gam, const float *stats, const float *dy, const float *dx_in, float *dx_out, float *d_gamma, float *d_beta,
+              int M, int C, hipStream_t s);
 void t_modulate(const float *x, const float *aff, const float *dy, float *out, float *d_aff, int B, int T, int C, bool bwd, hipStream_t s);
 void t_regroup(const float *src, float *dst, int B, int res, int C, bool gather, hipStream_t s);
 void t_concat(const float *x, const float *skip, float *cat, size_t M, int C, hipStream_t s);

@@ -487,11 +487,18 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
             v[r] = acc[j][r] + bias;
             if (ACT == ACT_GELU) v[r] = gelu_f(v[r]);
             else if (ACT == ACT_SILU) v[r] = silu_exact(v[r]);
-            if (RES) v[r] += rres[r];
+            if (ACT == ACT_DGELU) {   // (training form) d_pre = d_hid * GELU'(pre), pre read through the residual path: Phi(x) + x phi(x)
+                const float x = rres[r];
+                v[r] *= fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), 0.5f * (1.0f + erff(x * 0.70710678118654752f)));
+            } else if (RES) v[r] += rres[r];
         }
         if (g.C2) {
 #pragma unroll
             for (int r = 0; r < 16; r++) buf_store1(v[r], rsC2, vC2, (unsigned)((r & 3) + 8 * (r >> 2)) * g.ldc2 * 4u);
+        }
+        if (ACT == ACT_GELU_KEEP) {   // (training form) C2 just received the pre-activation
+#pragma unroll
+            for (int r = 0; r < 16; r++) v[r] = gelu_f(v[r]);
         }
         if (EPI >= 2) {
 #pragma unroll
@@ -599,7 +606,11 @@ void launch_gemm(const GemmArgs &g, hipStream_t s) {
         else { if (epi == 1) GEMM_EPI(false, 1); else if (epi == 2) GEMM_EPI(false, 2); else GEMM_EPI(false, 3); }
         return;
     }
-    if (ln && g.act == ACT_NONE && !res) GEMM_CASE(true, ACT_NONE, false);
+    if (g.act == ACT_GELU_KEEP || g.act == ACT_DGELU) {
+        if (ln || (g.act == ACT_GELU_KEEP && (res || !g.C2)) || (g.act == ACT_DGELU && (!res || g.C2))) { fprintf(stderr, "dsg: launch_gemm: unsupported training-form epilogue\n"); abort(); }
+        if (g.act == ACT_GELU_KEEP) GEMM_CASE(false, ACT_GELU_KEEP, false); else GEMM_CASE(false, ACT_DGELU, true);
+    }
+    else if (ln && g.act == ACT_NONE && !res) GEMM_CASE(true, ACT_NONE, false);
     else if (ln && g.act == ACT_GELU && !res) GEMM_CASE(true, ACT_GELU, false);
     else if (!ln && g.act == ACT_NONE && res) GEMM_CASE(false, ACT_NONE, true);
     else if (!ln && g.act == ACT_NONE && !res) GEMM_CASE(false, ACT_NONE, false);

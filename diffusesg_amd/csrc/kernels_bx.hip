@@ -31,6 +31,7 @@ __device__ __forceinline__ void buf_store2(u32x2 v, rsrc_t r, unsigned voff, uns
 __device__ __forceinline__ void buf_store4(f32x4 v, rsrc_t r, unsigned voff, unsigned soff) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
+__device__ __forceinline__ void buf_store_u4(u32x4 v, rsrc_t r, unsigned voff, unsigned soff) { __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, soff, 0); }
 __device__ __forceinline__ u32x4 buf_load_u4(rsrc_t r, unsigned voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0); }
 
 // -------------------------------------------------------------------------------------------------
@@ -62,6 +63,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 2 ? 2 : 4)) void gemm_bx_kerne
     constexpr int RPP = NT / CPR;                     // tile rows covered by one pass of the block
     constexpr int PA = BM / RPP, PW = (BN + RPP - 1) / RPP;
     constexpr int CV = (BN + NT - 1) / NT;            // column-vector entries per thread
+    constexpr int TLD = 104;                          // row stride (bf16) of a wave's 32 x 96 store-transposition buffer: 208 B
+    static_assert(WM * WN * 32 * TLD <= (BM + BN) * LDP, "the transposition buffers live in the tile stage");
     static_assert(NT % CPR == 0 && BM % RPP == 0, "staging layout");
     // tile stage | [3][BN] floats: the epilogue's per-column vectors (bias, 1 + scale, shift) | [BM][WN] row partials
     __shared__ __attribute__((aligned(16))) __bf16 lds[(BM + BN) * LDP + 6 * BN + 4 * BM * WN];
@@ -167,6 +170,26 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 2 ? 2 : 4)) void gemm_bx_kerne
         const rsrc_t rsC2 = make_rsrc(C2p ? C2p + (size_t)m0 * g.ldc2b : nullptr, C2p ? (unsigned)c.rows_m * g.ldc2b * 2u : 0u);
         const bool ln = g.ln_out != 0, gelu = g.act == ACT_GELU;
         const int ncol0 = wn * 96 + 4 * lhalf;          // + 32 nt + 8 q: this lane's column inside the tile
+        // bf16 outputs leave through a wave-private transposition buffer in the (now idle) tile stage: in accumulator order one store
+        // instruction would write 32 rows x 16 B -- the chip absorbs that footprint at 3.4 TB/s, row-contiguous 16-B pieces at 6.6
+        // (tools/store_pattern.cpp, profiles/r3/store_pattern.txt).  A wave collects a 32 x 96 half tile (8 B per lane and quad),
+        // then writes it out as 6 x 64 pieces of 16 B: 12 consecutive lanes cover one 192-B row segment.
+        __bf16 *T = lds + wave * 32 * TLD;
+        auto tput = [&](int nt, int q, const f32x4 &v) {
+            *reinterpret_cast<u32x2 *>(T + lrow * TLD + 4 * lhalf + 32 * nt + 8 * q) = pack_bf16x4(v);
+        };
+        int lane_e = lane;                               // opaque copy: the piece addresses below are rebuilt per tile instead of
+        asm volatile("" : "+v"(lane_e));                 // being hoisted out of the persistent loop into registers the K loop needs
+        auto tflush = [&](const rsrc_t &rs, unsigned ld, int mt) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const int i = lane_e + 64 * k, r = i / 12, p = i - 12 * r;
+                const u32x4 d = *reinterpret_cast<const u32x4 *>(T + r * TLD + 8 * p);
+                const int n = n0 + wn * 96 + 8 * p;
+                buf_store_u4(d, rs, n < g.N ? ((unsigned)(wm * WR + 32 * mt + r) * ld + (unsigned)n) * 2u : OOB, 0u);
+            }
+        };
+        const bool t_c2 = C2p != nullptr, t_cb = Cbp && !ln && !t_c2;   // one stream at a time goes through T inside the group loop
         // group = (mt, nt, qh): two accumulator quads = 8 values per lane at a time (register pressure: the next chunk is in flight)
         auto load_res = [&](f32x4 (&rr)[2], int grp) {
             const unsigned mrow = (unsigned)(wm * WR + 32 * (grp / 6) + lrow);
@@ -217,12 +240,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 2 ? 2 : 4)) void gemm_bx_kerne
 #pragma unroll
                 for (int q = 0; q < 2; q++) v[q] += (grp & 1) ? rrb[q] : rra[q];
             }
-            if (C2p) {
+            if (t_c2) {
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int n = n0 + ncol0 + 32 * nt + 8 * (q0 + q);
-                    buf_store2(pack_bf16x4(v[q]), rsC2, n < g.N ? (mrow * g.ldc2b + (unsigned)n) * 2u : OOB, 0u);
-                }
+                for (int q = 0; q < 2; q++) tput(nt, q0 + q, v[q]);
+                if (grp % 6 == 5) tflush(rsC2, (unsigned)g.ldc2b, mt);
             }
             if (MOD != 0) {
 #pragma unroll
@@ -244,7 +265,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 2 ? 2 : 4)) void gemm_bx_kerne
                     ssum[mt] += v[q][t]; ssq[mt] = fmaf(v[q][t], v[q][t], ssq[mt]);
                     acc[mt][nt][4 * (q0 + q) + t] = v[q][t];
                 }
-            if (Cbp && !ln) {
+            if (t_cb) {
+#pragma unroll
+                for (int q = 0; q < 2; q++) tput(nt, q0 + q, v[q]);
+                if (grp % 6 == 5) tflush(rsCb, (unsigned)g.ldcb, mt);
+            } else if (Cbp && !ln) {
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const int n = n0 + ncol0 + 32 * nt + 8 * (q0 + q);
@@ -273,12 +298,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 2 ? 2 : 4)) void gemm_bx_kerne
                 for (int nt = 0; nt < 3; nt++)
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const int n = n0 + ncol0 + 32 * nt + 8 * q;
                         f32x4 v;
 #pragma unroll
                         for (int t = 0; t < 4; t++) v[t] = fmaf(acc[mt][nt][4 * q + t], rstd, nmr);
-                        buf_store2(pack_bf16x4(v), rsCb, n < g.N ? (mrow * g.ldcb + (unsigned)n) * 2u : OOB, 0u);
+                        tput(nt, q, v);
                     }
+                tflush(rsCb, (unsigned)g.ldcb, mt);
             }
         }
     };
@@ -383,6 +408,7 @@ static int bx_cu_count() {
 bool launch_gemm_bx(const BxGemm &g, hipStream_t s) {
     if (!g.A || !g.W || g.M < 1 || g.N < 1 || g.K < 8 || g.K % 8 != 0 || g.N % 4 != 0 || (g.act != ACT_NONE && g.act != ACT_GELU)) return false;
     if (g.lda % 8 != 0 || (g.A2 && (g.lda2 % 8 != 0 || g.K1 <= 0))) return false;
+    if ((g.Cb || g.C2b) && (g.N % 8 != 0 || (g.Cb && g.ldcb % 8 != 0) || (g.C2b && g.ldc2b % 8 != 0))) return false;   // bf16 outputs leave in 16-byte row pieces
     if (g.act == ACT_GELU && g.res) return false;   // the epilogue adds the residual before bias / activation (fc1 has none)
     // geometry (wave grid WM x WN, block tile 64 WM x 96 WN): the tile spans the whole row when a LayerNorm output is asked for;
     // otherwise 128 x 192 where N splits into 192s, 256 x 96 for the narrow / odd widths (N = 96, 288)

@@ -64,17 +64,11 @@ void t_scratch_release() {   // dsg_destroy of the last handle / tests
 // C[M,N] (+)= op(A) op(B) (+ bias[n]);  op(A)(m,k) = TA ? A[k*lda+m] : A[m*lda+k];  op(B)(k,n) = TB ? B[n*ldb+k] : B[k*ldb+n]
 // 32x32 tile per 256-thread block, 4 outputs per thread, k in chunks of 32, fixed summation order (deterministic).
 // ---------------------------------------------------------------------------------------------------------------------
+// the k loop of one 32 x 32 tile: acc[i] += sum_k op(A)(m0 + ty + 8 i, k) op(B)(k, n0 + tx), k in [kbeg, kend)
 template <bool TA, bool TB>
-__global__ __launch_bounds__(256) void t_gemm_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
-                                                     const float *__restrict__ bias, float *__restrict__ C, int ldc, int M, int N, int K,
-                                                     int accumulate, int kslice) {
-    // kslice > 0: split-K -- block z handles k in [z kslice, (z+1) kslice) and writes its partial product to C + z M N (ldc = N)
-    __shared__ float As[32][33], Bs[32][33];
+__device__ __forceinline__ void t_gemm_accum(float (&acc)[4], const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb, int M, int N,
+                                             int kbeg, int K, int m0, int n0, float (*As)[33], float (*Bs)[33]) {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // ty 0..7
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    const int kbeg = kslice > 0 ? blockIdx.z * kslice : 0;
-    if (kslice > 0) { C += (size_t)blockIdx.z * M * N; K = min(K, kbeg + kslice); }
     for (int k0 = kbeg; k0 < K; k0 += 32) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -100,6 +94,19 @@ __global__ __launch_bounds__(256) void t_gemm_kernel(const float *__restrict__ A
         }
         __syncthreads();
     }
+}
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void t_gemm_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                     const float *__restrict__ bias, float *__restrict__ C, int ldc, int M, int N, int K,
+                                                     int accumulate, int kslice) {
+    // kslice > 0: split-K -- block z handles k in [z kslice, (z+1) kslice) and writes its partial product to C + z M N (ldc = N)
+    __shared__ float As[32][33], Bs[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int kbeg = kslice > 0 ? blockIdx.z * kslice : 0;
+    if (kslice > 0) { C += (size_t)blockIdx.z * M * N; K = min(K, kbeg + kslice); }
+    t_gemm_accum<TA, TB>(acc, A, lda, B, ldb, M, N, kbeg, K, m0, n0, As, Bs);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int m = m0 + ty + 8 * i, n = n0 + tx;
@@ -110,13 +117,58 @@ __global__ __launch_bounds__(256) void t_gemm_kernel(const float *__restrict__ A
         }
     }
 }
-// C[i] = (accumulate ? C[i] : 0) + sum_z part[z][i]   (fixed order)
-__global__ void t_splitk_reduce_kernel(const float *part, float *C, int ldc, int M, int N, int S, int accumulate) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)M * N) return;
+// Grouped small products (the 2C-wide `affine` linears of all blocks hang off ONE [B, 512] embedding: 13-19 products of a few MFLOP
+// each, forward and backward -- one launch per kind instead of one per block).
+//   SUM = false: problem z = blockIdx.z writes its own C_z = op(A_z) op(B_z) (+ bias_z)
+//   SUM = true : ONE output C = sum_z op(A_z) op(B_z) (all problems share M, N and C; k runs through the problems in order)
+template <bool TA, bool TB, bool SUM>
+__global__ __launch_bounds__(256) void t_gemm_grouped_kernel(TGemmGroup g) {
+    __shared__ float As[32][33], Bs[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (SUM) {
+        for (int z = 0; z < g.n; z++) {
+            const TGemmProb &p = g.p[z];
+            t_gemm_accum<TA, TB>(acc, p.A, p.lda, p.B, p.ldb, p.M, p.N, 0, p.K, m0, n0, As, Bs);
+        }
+    } else {
+        const TGemmProb &p = g.p[blockIdx.z];
+        if (m0 >= p.M || n0 >= p.N) return;   // block-uniform
+        t_gemm_accum<TA, TB>(acc, p.A, p.lda, p.B, p.ldb, p.M, p.N, 0, p.K, m0, n0, As, Bs);
+    }
+    const TGemmProb &p = g.p[SUM ? 0 : blockIdx.z];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int m = m0 + ty + 8 * i, n = n0 + tx;
+        if (m < p.M && n < p.N) p.C[(size_t)m * p.ldc + n] = acc[i] + (p.bias ? p.bias[n] : 0.f);
+    }
+}
+// out_z[n] = sum_m X_z[m][n] for a group of short matrices (M <= a few hundred rows: the bias gradients of the affine linears)
+__global__ __launch_bounds__(256) void t_colsum_grouped_kernel(TGemmGroup g) {
+    const TGemmProb &p = g.p[blockIdx.y];   // A = X [M, N] (lda), C = out [N]
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= p.N) return;
+    double sacc = 0.0;
+    for (int m = 0; m < p.M; m++) sacc += (double)p.A[(size_t)m * p.lda + n];
+    p.C[n] = (float)sacc;
+}
+// C[i] = (accumulate ? C[i] : 0) + sum_z part[z][i]   (fixed order); the blocks behind the M N elements add the slices of the
+// column sums that gemm_tn_f32_kernel<true> wrote next to its partial products: cs_out[m] = sum_z cs_part[z][m]
+__global__ void t_splitk_reduce_kernel(const float *part, float *C, int ldc, int M, int N, int S, int accumulate, const float *cs_part, float *cs_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, mn = (size_t)M * N, mn_pad = (mn + 255) / 256 * 256;
+    if (i >= mn) {
+        if (cs_out && i >= mn_pad && i - mn_pad < (size_t)M) {
+            const size_t m = i - mn_pad;
+            float v = 0.f;
+            for (int z = 0; z < S; z++) v += cs_part[(size_t)z * M + m];
+            cs_out[m] = v;
+        }
+        return;
+    }
     const int m = i / N, n = i % N;
     float v = accumulate ? C[(size_t)m * ldc + n] : 0.f;
-    for (int z = 0; z < S; z++) v += part[(size_t)z * M * N + i];
+    for (int z = 0; z < S; z++) v += part[(size_t)z * mn + i];
     C[(size_t)m * ldc + n] = v;
 }
 // [R][Cc] -> [Cc][R] (weights on their way into the MFMA GEMM, which wants both operands K-contiguous)
@@ -234,18 +286,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f32_kernel(const float *__rest
         if (lhalf == 0 && m < M) cs_part[(size_t)z * M + m] = asum;
     }
 }
-// out[i] = sum_z part[z][i]  (fixed order)
-__global__ void t_slices_sum_kernel(const float *part, float *out, int n, int S) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float v = 0.f;
-    for (int z = 0; z < S; z++) v += part[(size_t)z * n + i];
-    out[i] = v;
-}
 
 void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, const float *bias, float *C, int ldc, int M, int N, int K,
-            bool accumulate, hipStream_t s, float *a_colsum) {
+            bool accumulate, hipStream_t s, float *a_colsum, const float *res, int act, float *c2) {
+    // res (activation-side products only): C = res + product, res a tensor of C's shape and pitch -- the MFMA kernel reads it in its
+    // epilogue; the fallbacks copy it into C first and accumulate
+    if (act == ACT_NONE && res && res == C) { res = nullptr; accumulate = true; }
     TScratch &ts = t_scratch(s);
+    // the fallbacks below form the plain product; the fused activation forms are finished by an elementwise pass afterwards
+    struct ActAfter { int act; const float *res; float *C, *c2; size_t n; hipStream_t s; bool done;
+        ~ActAfter() {
+            if (done || act == ACT_NONE) return;
+            if (act == ACT_GELU_KEEP) t_gelu(c2, nullptr, C, n, false, s); else t_gelu(res, C, C, n, true, s);
+        } } act_after{act, res, C, c2, (size_t)M * N, s, false};
+    float *C_plain = (act == ACT_GELU_KEEP) ? c2 : C;   // where the fallbacks put the product
     bool colsum_done = false;
     struct ColsumAfter { const float *A; int lda, M, K; float *out; hipStream_t s; bool *done; bool ta;
         ~ColsumAfter() { if (out && !*done) t_colsum(A, lda, out, K, M, s); } } colsum_after{A, lda, M, K, a_colsum, s, &colsum_done, ta};
@@ -269,11 +323,21 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
         if (ok) {
             GemmArgs g;
             g.A = A; g.lda = K; g.K1 = K; g.K = K; g.M = M; g.N = N; g.W = Wop; g.bias = bias; g.C = C; g.ldc = ldc;
-            if (accumulate) { g.res = C; g.ldres = ldc; }
+            if (res) { g.res = res; g.ldres = ldc; }
+            else if (accumulate) { g.res = C; g.ldres = ldc; }
+            g.act = act;
+            if (act == ACT_GELU_KEEP) { g.C2 = c2; g.ldc2 = ldc; }
             launch_gemm(g, s);
+            act_after.done = true;
             return;
         }
     }
+    if (act != ACT_NONE && (ta || ldc != N || accumulate)) { ts.failed = true; act_after.done = true; return; }   // (activation-side products only)
+    if (res && act == ACT_NONE) {
+        if (hipMemcpy2DAsync(C, sizeof(float) * ldc, res, sizeof(float) * ldc, sizeof(float) * N, M, hipMemcpyDeviceToDevice, s) != hipSuccess) { ts.failed = true; return; }
+        accumulate = true;
+    }
+    C = C_plain;
     // Weight gradients dW [M = out, N = in] = dy^T x with K = tokens: gemm_tn_f32_kernel reads both token-major operands as they
     // are (no transposed copies), S slices of K in one launch, partial products added in slice order.
     if (use_mfma && ta && !tb && !bias && K >= 2048 && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0) {
@@ -288,11 +352,9 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
             const dim3 grid((unsigned)(tiles_m * tiles_n * S));
             if (a_colsum) hipLaunchKernelGGL((gemm_tn_f32_kernel<true>), grid, dim3(256), 0, s, A, lda, B, ldb, buf, M, N, K, kslice, tiles_m, tiles_n, buf + nC);
             else hipLaunchKernelGGL((gemm_tn_f32_kernel<false>), grid, dim3(256), 0, s, A, lda, B, ldb, buf, M, N, K, kslice, tiles_m, tiles_n, nullptr);
-            hipLaunchKernelGGL(t_splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, buf, C, ldc, M, N, S, (int)accumulate);
-            if (a_colsum) {
-                hipLaunchKernelGGL(t_slices_sum_kernel, dim3((M + 255) / 256), dim3(256), 0, s, buf + nC, a_colsum, M, S);
-                colsum_done = true;
-            }
+            const unsigned rb = (unsigned)(((size_t)M * N + 255) / 256) + (a_colsum ? (unsigned)((M + 255) / 256) : 0u);
+            hipLaunchKernelGGL(t_splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, buf, C, ldc, M, N, S, (int)accumulate, buf + nC, a_colsum);
+            if (a_colsum) colsum_done = true;
             return;
         }
     }
@@ -316,7 +378,24 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
     else hipLaunchKernelGGL((t_gemm_kernel<true, true>), grid, block, 0, s, A, lda, B, ldb, bias, Cout, ldo, M, N, K, acc1, kslice);
     if (S > 1)
         hipLaunchKernelGGL(t_splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, ts.sk, C, ldc, M, N, S,
-                           (int)accumulate);
+                           (int)accumulate, (const float *)nullptr, (float *)nullptr);
+}
+
+void t_gemm_grouped(bool ta, bool tb, bool sum, const TGemmGroup &g, hipStream_t s) {
+    if (g.n < 1) return;
+    int mx_m = 0, mx_n = 0;
+    for (int z = 0; z < g.n; z++) { mx_m = std::max(mx_m, g.p[z].M); mx_n = std::max(mx_n, g.p[z].N); }
+    const dim3 grid((mx_n + 31) / 32, (mx_m + 31) / 32, sum ? 1 : g.n), block(256);
+    if (!ta && tb && !sum) hipLaunchKernelGGL((t_gemm_grouped_kernel<false, true, false>), grid, block, 0, s, g);
+    else if (ta && !tb && !sum) hipLaunchKernelGGL((t_gemm_grouped_kernel<true, false, false>), grid, block, 0, s, g);
+    else if (!ta && !tb && sum) hipLaunchKernelGGL((t_gemm_grouped_kernel<false, false, true>), grid, block, 0, s, g);
+    else t_scratch(s).failed = true;   // (no other form is used)
+}
+void t_colsum_grouped(const TGemmGroup &g, hipStream_t s) {
+    if (g.n < 1) return;
+    int mx_n = 0;
+    for (int z = 0; z < g.n; z++) mx_n = std::max(mx_n, g.p[z].N);
+    hipLaunchKernelGGL(t_colsum_grouped_kernel, dim3((mx_n + 255) / 256, g.n), dim3(256), 0, s, g);
 }
 
 // out[n] = sum_m X[m*ld + n]: row chunks summed by separate blocks (double, fixed order inside a chunk), then the chunks in order.
@@ -416,23 +495,63 @@ __global__ __launch_bounds__(256) void t_ln_fwd_kernel(const float *x, const flo
     for (int c = lane; c < C; c += 64) y[(size_t)m * C + c] = (r[c] - mean) * rstd * gam[c] + bet[c];
     if (lane == 0) { stats[2 * (size_t)m] = mean; stats[2 * (size_t)m + 1] = rstd; }
 }
-// dx (ADDED to dx_acc) = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;  xhat_dy[m][c] = dy xhat (for d_gamma = colsum)
-__global__ __launch_bounds__(256) void t_ln_bwd_kernel(const float *x, const float *gam, const float *stats, const float *dy, float *dx_acc,
-                                                        float *xhat_dy, int M, int C) {
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (m >= M) return;
-    const float mean = stats[2 * (size_t)m], rstd = stats[2 * (size_t)m + 1];
-    const float *r = x + (size_t)m * C, *d = dy + (size_t)m * C;
-    float sg = 0.f, sgx = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        const float xh = (r[c] - mean) * rstd, g = d[c] * gam[c];
-        sg += g; sgx = fmaf(g, xh, sgx);
-        xhat_dy[(size_t)m * C + c] = d[c] * xh;
+// dx_out = (dx_in ? dx_in : 0) + rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;  d_gamma = sum_m dy xhat, d_beta = sum_m dy.
+// A block of 4 waves walks a chunk of rows (one wave per row, lanes stride over the channels); every lane keeps the two column sums of
+// its KC channels in registers (fp32 over the <= rows_per / 4 rows of its wave), the block adds its waves and writes
+// part[block][2][C] (double); t_ln_bwd_final_kernel adds the blocks in order.  (Round 2's form wrote dy xhat as a tensor and ran two
+// two-stage column-sum passes over it and dy: 5 launches and 3 more passes over [M, C] per LayerNorm.)
+template <int KC>
+__global__ __launch_bounds__(256) void t_ln_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gam, const float *__restrict__ stats,
+                                                        const float *__restrict__ dy, const float *dx_in, float *dx_out, double *part, int M, int C,
+                                                        int rows_per) {
+    __shared__ float red[4][2][KC * 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+    float ag[KC], ab[KC], gm[KC];
+#pragma unroll
+    for (int k = 0; k < KC; k++) { ag[k] = 0.f; ab[k] = 0.f; gm[k] = (lane + 64 * k < C) ? gam[lane + 64 * k] : 0.f; }
+    for (int m = r0 + wave; m < r1; m += 4) {
+        const float mean = stats[2 * (size_t)m], rstd = stats[2 * (size_t)m + 1];
+        const float *r = x + (size_t)m * C, *d = dy + (size_t)m * C;
+        float xh[KC], gg[KC], sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            const int c = lane + 64 * k;
+            xh[k] = 0.f; gg[k] = 0.f;
+            if (c < C) {
+                const float dv = d[c];
+                xh[k] = (r[c] - mean) * rstd; gg[k] = dv * gm[k];
+                sg += gg[k]; sgx = fmaf(gg[k], xh[k], sgx);
+                ag[k] = fmaf(dv, xh[k], ag[k]); ab[k] += dv;
+            }
+        }
+        const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            const int c = lane + 64 * k;
+            if (c < C) dx_out[(size_t)m * C + c] = (dx_in ? dx_in[(size_t)m * C + c] : 0.f) + rstd * (gg[k] - mg - xh[k] * mgx);
+        }
     }
-    const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
-    for (int c = lane; c < C; c += 64) {
-        const float xh = (r[c] - mean) * rstd, g = d[c] * gam[c];
-        dx_acc[(size_t)m * C + c] += rstd * (g - mg - xh * mgx);
+#pragma unroll
+    for (int k = 0; k < KC; k++) { red[wave][0][lane + 64 * k] = ag[k]; red[wave][1][lane + 64 * k] = ab[k]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double *p = part + (size_t)blockIdx.x * 2 * C;
+        p[c] = ((double)red[0][0][c] + (double)red[1][0][c]) + ((double)red[2][0][c] + (double)red[3][0][c]);
+        p[C + c] = ((double)red[0][1][c] + (double)red[1][1][c]) + ((double)red[2][1][c] + (double)red[3][1][c]);
+    }
+}
+// (d_gamma | d_beta)[c] = sum over the R block partials, in order: block = 64 columns x 4 lanes over the partials
+__global__ __launch_bounds__(256) void t_ln_bwd_final_kernel(const double *part, float *d_gamma, float *d_beta, int C, int R) {
+    __shared__ double red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;   // c over 2C
+    double sacc = 0.0;
+    if (c < 2 * C) for (int r = q; r < R; r += 4) sacc += part[(size_t)r * 2 * C + c];
+    red[q][threadIdx.x & 63] = sacc;
+    __syncthreads();
+    if (q == 0 && c < 2 * C) {
+        const float v = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+        if (c < C) { if (d_gamma) d_gamma[c] = v; } else if (d_beta) d_beta[c - C] = v;
     }
 }
 
@@ -870,21 +989,19 @@ static inline unsigned t_blocks(size_t n) { return (unsigned)((n + 255) / 256); 
 
 bool train_block(const TrainBlockArgs &a, hipStream_t s) {
     const int B = a.B, T = a.res * a.res, C = a.C, M = B * T, H = a.hidden;
-    const size_t nMC = (size_t)M * C, nMH = (size_t)M * H;
+    const size_t nMC = (size_t)M * C;
     TAttnGeom g{a.res, a.ws, a.shift, a.heads, C};
     // ---- forward ----
-    t_gemm(false, true, a.emb, NOISE_EMB, a.W.aff_w, NOISE_EMB, a.W.aff_b, a.aff, 2 * C, B, 2 * C, NOISE_EMB, false, s);     // params = affine(emb)
+    if (!a.aff_grouped)   // params = affine(emb); the whole-network step computes all blocks' rows in one grouped launch up front
+        t_gemm(false, true, a.emb, NOISE_EMB, a.W.aff_w, NOISE_EMB, a.W.aff_b, a.aff, 2 * C, B, 2 * C, NOISE_EMB, false, s);
     hipLaunchKernelGGL(t_modulate_fwd_kernel, dim3(t_blocks(nMC)), dim3(256), 0, s, a.x_in, a.aff, a.x_mod, T, C, nMC);
     hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x_mod, a.W.n1_w, a.W.n1_b, a.xn1, a.stats1, M, C);
     t_gemm(false, true, a.xn1, C, a.W.qkv_w, C, a.W.qkv_b, a.qkv, 3 * C, M, 3 * C, C, false, s);
     if (!t_attn_launch(false, a.qkv, a.W.rpb, a.att, nullptr, nullptr, nullptr, B, g, s)) return false;
-    if (hipMemcpyAsync(a.x1, a.x_mod, sizeof(float) * nMC, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;
-    t_gemm(false, true, a.att, C, a.W.proj_w, C, a.W.proj_b, a.x1, C, M, C, C, true, s);                                      // x1 = shortcut + proj(att)
+    t_gemm(false, true, a.att, C, a.W.proj_w, C, a.W.proj_b, a.x1, C, M, C, C, false, s, nullptr, a.x_mod);                  // x1 = shortcut + proj(att)
     hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x1, a.W.n2_w, a.W.n2_b, a.xn2, a.stats2, M, C);
-    t_gemm(false, true, a.xn2, C, a.W.fc1_w, C, a.W.fc1_b, a.pre, H, M, H, C, false, s);
-    hipLaunchKernelGGL(t_gelu_fwd_kernel, dim3(t_blocks(nMH)), dim3(256), 0, s, a.pre, a.hid, nMH);
-    if (hipMemcpyAsync(a.x_out, a.x1, sizeof(float) * nMC, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;
-    t_gemm(false, true, a.hid, H, a.W.fc2_w, H, a.W.fc2_b, a.x_out, C, M, C, H, true, s);                                      // x_out = x1 + fc2(gelu(fc1(ln2)))
+    t_gemm(false, true, a.xn2, C, a.W.fc1_w, C, a.W.fc1_b, a.hid, H, M, H, C, false, s, nullptr, nullptr, ACT_GELU_KEEP, a.pre);   // pre = fc1(xn2), hid = GELU(pre)
+    t_gemm(false, true, a.hid, H, a.W.fc2_w, H, a.W.fc2_b, a.x_out, C, M, C, H, false, s, nullptr, a.x1);                    // x_out = x1 + fc2(gelu(fc1(ln2)))
     if (!a.grad_out) return hipGetLastError() == hipSuccess;
     return train_block_backward(a, s);
 }
@@ -893,19 +1010,14 @@ bool train_block(const TrainBlockArgs &a, hipStream_t s) {
 // t_mh [M,H], t_m3c [M,3C]; a.grad_out is read, a.grad_in / a.grad_emb / a.G.* are written)
 bool train_block_backward(const TrainBlockArgs &a, hipStream_t s) {
     const int B = a.B, T = a.res * a.res, C = a.C, M = B * T, H = a.hidden;
-    const size_t nMC = (size_t)M * C, nMH = (size_t)M * H;
     TAttnGeom g{a.res, a.ws, a.shift, a.heads, C};
     const float *dY = a.grad_out;
     // MLP: x_out = x1 + hid W2^T + b2
     t_gemm(true, false, dY, C, a.hid, H, nullptr, a.G.fc2_w, H, C, H, M, false, s, a.G.fc2_b);  // dW2 [C,H] = dY^T hid, db2 = colsum(dY)
-    t_gemm(false, false, dY, C, a.W.fc2_w, H, nullptr, a.t_mh, H, M, H, C, false, s);          // d_hid = dY W2
-    hipLaunchKernelGGL(t_gelu_bwd_kernel, dim3(t_blocks(nMH)), dim3(256), 0, s, a.pre, a.t_mh, a.t_mh, nMH);   // d_pre
+    t_gemm(false, false, dY, C, a.W.fc2_w, H, nullptr, a.t_mh, H, M, H, C, false, s, nullptr, a.pre, ACT_DGELU);   // d_pre = (dY W2) GELU'(pre)
     t_gemm(true, false, a.t_mh, H, a.xn2, C, nullptr, a.G.fc1_w, C, H, C, M, false, s, a.G.fc1_b);   // dW1 [H,C] = d_pre^T xn2, db1
     t_gemm(false, false, a.t_mh, H, a.W.fc1_w, C, nullptr, a.t_mc, C, M, C, H, false, s);       // d_xn2 = d_pre W1
-    if (hipMemcpyAsync(a.d_x1, dY, sizeof(float) * nMC, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;   // residual branch
-    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x1, a.W.n2_w, a.stats2, a.t_mc, a.d_x1, a.t_mc2, M, C);
-    t_colsum(a.t_mc2, C, a.G.n2_w, M, C, s);                                                     // d_gamma2 = colsum(d_xn2 * xhat)
-    t_colsum(a.t_mc, C, a.G.n2_b, M, C, s);                                                      // d_beta2 = colsum(d_xn2)
+    t_ln_bwd(a.x1, a.W.n2_w, a.stats2, a.t_mc, dY, a.d_x1, a.G.n2_w, a.G.n2_b, M, C, s);       // d_x1 = dY (residual branch) + LN2 backward; d_gamma2, d_beta2
     // attention half: x1 = x_mod + att Wp^T + bp
     t_gemm(true, false, a.d_x1, C, a.att, C, nullptr, a.G.proj_w, C, C, C, M, false, s, a.G.proj_b);
     t_gemm(false, false, a.d_x1, C, a.W.proj_w, C, nullptr, a.t_mc, C, M, C, C, false, s);      // d_att
@@ -914,11 +1026,10 @@ bool train_block_backward(const TrainBlockArgs &a, hipStream_t s) {
     t_gemm(true, false, a.t_m3c, 3 * C, a.xn1, C, nullptr, a.G.qkv_w, C, 3 * C, C, M, false, s, a.G.qkv_b);
     t_gemm(false, false, a.t_m3c, 3 * C, a.W.qkv_w, C, nullptr, a.t_mc, C, M, C, 3 * C, false, s);   // d_xn1
     // d_xmod = d_x1 (shortcut) + LN1 backward
-    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x_mod, a.W.n1_w, a.stats1, a.t_mc, a.d_x1, a.t_mc2, M, C);
-    t_colsum(a.t_mc2, C, a.G.n1_w, M, C, s);
-    t_colsum(a.t_mc, C, a.G.n1_b, M, C, s);
+    t_ln_bwd(a.x_mod, a.W.n1_w, a.stats1, a.t_mc, a.d_x1, a.d_x1, a.G.n1_w, a.G.n1_b, M, C, s);
     // modulate: x_mod = silu(shift + x (1 + scale)); params = emb Wa^T + ba
     t_modulate(a.x_in, a.aff, a.d_x1, a.grad_in, a.d_aff, B, T, C, true, s);
+    if (a.aff_grouped) return hipGetLastError() == hipSuccess;   // dWa, d_ba and d_emb of all blocks: grouped launches of the whole-network step
     t_gemm(true, false, a.d_aff, 2 * C, a.emb, NOISE_EMB, nullptr, a.G.aff_w, NOISE_EMB, 2 * C, NOISE_EMB, B, false, s);   // dWa = d_aff^T emb
     t_colsum(a.d_aff, 2 * C, a.G.aff_b, B, 2 * C, s);
     t_gemm(false, false, a.d_aff, 2 * C, a.W.aff_w, NOISE_EMB, nullptr, a.grad_emb, NOISE_EMB, B, NOISE_EMB, 2 * C, false, s);   // d_emb
@@ -938,8 +1049,21 @@ void t_add(float *a, const float *b, size_t n, hipStream_t s) { hipLaunchKernelG
 void t_ln_fwd(const float *x, const float *gam, const float *bet, float *y, float *stats, int M, int C, hipStream_t s) {
     hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gam, bet, y, stats, M, C);
 }
-void t_ln_bwd(const float *x, const float *gam, const float *stats, const float *dy, float *dx_acc, float *xhat_dy, int M, int C, hipStream_t s) {
-    hipLaunchKernelGGL(t_ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gam, stats, dy, dx_acc, xhat_dy, M, C);
+void t_ln_bwd(const float *x, const float *gam, const float *stats, const float *dy, const float *dx_in, float *dx_out, float *d_gamma, float *d_beta,
+              int M, int C, hipStream_t s) {
+    // <= 1024 blocks, >= 4 rows each (one per wave)
+    int blocks = std::max(1, std::min(1024, (M + 3) / 4));
+    const int rows_per = ((M + blocks - 1) / blocks + 3) / 4 * 4;
+    blocks = (M + rows_per - 1) / rows_per;
+    TScratch &ts = t_scratch(s);
+    double *part = t_scratch_get(s, ts.cs, ts.cs_cap, (size_t)blocks * 2 * C, ts);
+    if (!part) return;   // (the stream's scratch is marked failed)
+    const int kc = (C + 63) / 64;
+#define T_LNB(KC_) hipLaunchKernelGGL((t_ln_bwd_kernel<KC_>), dim3(blocks), dim3(256), 0, s, x, gam, stats, dy, dx_in, dx_out, part, M, C, rows_per)
+    if (kc <= 2) T_LNB(2); else if (kc <= 3) T_LNB(3); else if (kc <= 6) T_LNB(6); else if (kc <= 12) T_LNB(12); else if (kc <= 24) T_LNB(24);
+    else { ts.failed = true; return; }   // rows wider than 1536 channels do not occur (4 x 384 is the widest LayerNorm of the networks)
+#undef T_LNB
+    hipLaunchKernelGGL(t_ln_bwd_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, s, part, d_gamma, d_beta, C, blocks);
 }
 void t_modulate(const float *x, const float *aff, const float *dy, float *out, float *d_aff, int B, int T, int C, bool bwd, hipStream_t s) {
     if (bwd) {

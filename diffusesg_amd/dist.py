@@ -69,6 +69,11 @@ def all_reduce_mean(grads, bucket_bytes: int = 256 << 20):
     if dist.get_world_size() == 1 and not os.environ.get("DSG_FORCE_COLLECTIVE"):   # (the world-size-1 RCCL test sets it)
         return grads
     world = dist.get_world_size()
+    flat = getattr(grads, "flat", None)
+    if flat is not None:   # train_step_grads' GradDict: every gradient is a view into one flat buffer -- one collective, no packing
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        return grads
     bucket, size = [], 0
 
     def flush():

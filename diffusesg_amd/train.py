@@ -218,18 +218,57 @@ def swin_block_train(net, block: str, x, emb, grad_out=None):
     return x_out, gx, ge, grads
 
 
+class GradDict(dict):
+    """{state-dict key: gradient}: every tensor is a view into ONE flat buffer (`.flat`; 64-float aligned segments), so that zeroing,
+    the data-parallel all-reduce and the optimiser each touch one tensor instead of 233."""
+    flat = None
+
+
+def _flat_layout(m):
+    """(keys, offsets, shapes, total) of the module's parameters in a flat fp32 buffer; cached on the module"""
+    lay = getattr(m, "_grad_layout", None)
+    if lay is None:
+        keys, offs, shapes, off = [], [], [], 0
+        for k, p_ in m.named_parameters():
+            keys.append(k); offs.append(off); shapes.append(tuple(p_.shape))
+            off += (p_.numel() + 63) // 64 * 64
+        lay = m._grad_layout = (keys, offs, shapes, off)
+    return lay
+
+
+def _train_handle(m):
+    """The handle for the training-form entries: the parameters are read IN PLACE (dsg_train_bind_params) when they live on the
+    device -- no upload per iteration; only the very first call pays for dsg_finalize_weights (block plans)."""
+    if m._handle is None:
+        m._ensure_handle()
+    h = m._handle
+    params = [(k, p_) for k, p_ in m.named_parameters()]
+    if all(p_.is_cuda and p_.dtype == torch.float32 and p_.is_contiguous() for _, p_ in params):
+        sig = tuple(p_.data_ptr() for _, p_ in params)
+        if getattr(m, "_bound_sig", None) != sig:
+            names = (C.c_char_p * len(params))(*[k.encode() for k, _ in params])
+            ptrs = (C.c_void_p * len(params))(*sig)
+            h.check(h.L.dsg_train_bind_params(h.raw, len(params), names, ptrs), "dsg_train_bind_params")
+            m._bound_sig = sig
+        return h
+    if getattr(m, "_bound_sig", None) is not None:
+        h.check(h.L.dsg_train_bind_params(h.raw, 0, None, None), "dsg_train_bind_params")
+        m._bound_sig = None
+    return m._ensure_handle(finalize=False)   # host parameters: uploaded when they changed
+
+
 @torch.no_grad()
 def train_step_grads(model, loss_func, net_input_a, net_input_x, node_flags, sigmas, net_target_a, net_target_x, loss_weight,
                      iou_loss_weight=0.0, want_grads=True, iou_loss_type="iou"):
     """One training iteration up to and including `loss.backward()` (trainer_node_adj.py:96-170) on the device:
     `model(adjs=net_input_a, nodes=net_input_x, node_flags=..., sigmas=...)` with the network in training form (the self-conditioning
-    coin is drawn from NumPy's global generator like precond.py:90 and the detached self-conditioning pass runs on the sampling path),
-    per-sample losses, and the gradient of `loss_adj.mean() + loss_node.mean()` for every parameter.
-    -> (net_output_a, net_output_x, reg_loss_adj [B], reg_loss_node [B], {state-dict key: gradient}).
-    Correctness-first kernels (`dsg_train_step_grads`), pinned to the reference's autograd; optimiser / EMA / clipping / DDP are not built."""
+    coin is drawn from NumPy's global generator like precond.py:90; the detached self-conditioning pass runs in training form too --
+    `dsg_train_self_cond` -- so an iteration never rebuilds the sampling path's packed weights), per-sample losses, and the gradient of
+    `loss_adj.mean() + loss_node.mean()` for every parameter.
+    -> (net_output_a, net_output_x, reg_loss_adj [B], reg_loss_node [B], GradDict {state-dict key: gradient})."""
     import numpy as np
     m = model.model
-    h = m._ensure_handle(finalize=False)   # raw weights only; the sampling path's packed weights are rebuilt when the coin needs them
+    h = _train_handle(m)
     B, a, x, fl, _, _ = m._canon(net_input_a, net_input_x, node_flags, None, None)
     _, ta, tx, _, _, _ = m._canon(net_target_a, net_target_x, node_flags, None, None)
     dev = m._dev
@@ -239,18 +278,29 @@ def train_step_grads(model, loss_func, net_input_a, net_input_x, node_flags, sig
     sa = sx = None
     if model.self_condition and np.random.rand() < 0.5:   # precond.py:90-98: D of a no-grad pass becomes the (detached) self-cond input
         sa, sx = torch.empty_like(a), torch.empty_like(x)
-        h = m._ensure_handle()   # this pass runs on the sampling path: needs the packed weights of the CURRENT parameters
-        h.check(h.L.dsg_precond(h.raw, B, _p(a), _p(x), _p(fl), _p(sg), None, None, 0, _p(sa), _p(sx), st), "dsg_precond")
-    keys = [k for k, _ in m.named_parameters()] if want_grads else []
-    sd = dict(m.named_parameters())
-    grads = {k: torch.zeros(tuple(sd[k].shape), device=dev, dtype=torch.float32) for k in keys}
-    names = (C.c_char_p * max(len(keys), 1))(*[k.encode() for k in keys]) if keys else None
-    ptrs = (C.c_void_p * max(len(keys), 1))(*[grads[k].data_ptr() for k in keys]) if keys else None
+        h.check(h.L.dsg_train_self_cond(h.raw, B, _p(a), _p(x), _p(fl), _p(sg), _p(sa), _p(sx), st), "dsg_train_self_cond")
+    grads = GradDict()
+    names = ptrs = None
+    n_keys = 0
+    if want_grads:
+        keys, offs, shapes, total = _flat_layout(m)
+        grads.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        for k, o, shp in zip(keys, offs, shapes):
+            n = 1
+            for d_ in shp:
+                n *= d_
+            grads[k] = grads.flat[o:o + n].view(shp)
+        cache = getattr(m, "_grad_names", None)
+        if cache is None:
+            cache = m._grad_names = (C.c_char_p * len(keys))(*[k.encode() for k in keys])
+        names, n_keys = cache, len(keys)
+        base = grads.flat.data_ptr()
+        ptrs = (C.c_void_p * len(keys))(*[base + 4 * o for o in offs])
     da, dx_ = torch.empty_like(a), torch.empty_like(x)
     la, ln = torch.empty(B, device=dev), torch.empty(B, device=dev)
     h.check(h.L.dsg_train_step_grads(h.raw, B, _p(a), _p(x), _p(fl), _p(sg), _p(sa), _p(sx), _p(ta), _p(tx), _p(w),
                                      float(loss_func.edge_loss_weight), float(loss_func.node_loss_weight), float(iou_loss_weight),
-                                     _lib.iou_loss_type_code(iou_loss_type), _p(da), _p(dx_), _p(la), _p(ln), len(keys), names, ptrs, st),
+                                     _lib.iou_loss_type_code(iou_loss_type), _p(da), _p(dx_), _p(la), _p(ln), n_keys, names, ptrs, st),
             "dsg_train_step_grads")
     oa, on = m._shape_out(da, dx_)
     return oa, on, la, ln, grads

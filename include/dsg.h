@@ -302,6 +302,20 @@ int dsg_train_step_grads(dsg_handle h, int32_t B, const float *noisy_adj, const 
                          int32_t iou_loss_type, float *out_D_adj, float *out_D_node, float *out_loss_adj, float *out_loss_node,
                          int32_t n_params, const char *const *names, float *const *grad_params, void *stream);
 
+/* The no-grad pass of a self-conditioning training step (precond.py:92-98): D = NodeAdjPrecond(noisy, sigmas) with NO self-conditioning
+ * input, computed by the network in TRAINING form -- i.e. from the raw parameters (dsg_train_bind_params / dsg_set_weight), without the
+ * sampling path's derived weights, which an optimiser step invalidates (dsg_finalize_weights costs several forwards).  out_sc_* are the
+ * masked D tensors the caller then passes to dsg_train_step_grads as sc_adj / sc_node. */
+int dsg_train_self_cond(dsg_handle h, int32_t B, const float *noisy_adj, const float *noisy_node, const uint8_t *flags, const float *sigmas,
+                        float *out_sc_adj, float *out_sc_node, void *stream);
+
+/* Let the training-form entries (dsg_train_grads, dsg_train_step_grads, dsg_train_self_cond) read these parameters IN PLACE: names[i]
+ * (state-dict key) -> params[i] (device tensor of the parameter's shape, e.g. the tensor the optimiser updates), instead of the
+ * handle's own copies -- no upload per iteration.  The caller keeps the tensors alive and unchanged in address until the next call of
+ * this function; n_params = 0 clears the binding.  Keys not bound fall back to the handle's copy.  The sampling-path entries are not
+ * affected: they use what dsg_set_weight + dsg_finalize_weights installed. */
+int dsg_train_bind_params(dsg_handle h, int32_t n_params, const char *const *names, const float *const *params);
+
 /* The rest of a training iteration (R/runner/trainer/trainer_node_adj.py:170-175), on caller-owned device tensors, no handle:
  * dsg_adam_step <-> nn.utils.clip_grad_norm_(parameters, max_norm) followed by torch.optim.Adam.step()  (utils/learning_utils.py:137-140:
  *   betas (0.9, 0.999), eps 1e-8, L2 weight_decay; gradients are scaled in place by the clip coefficient like the reference;
