@@ -52,6 +52,7 @@ struct BlockPlan {
     int lvl, C, res, ws, shift, heads;
     int aff_off;        // offset of this block's (scale,shift) in the concatenated affine output
     float *biasT = nullptr;  // [nWt][heads][Wp][Wp]
+    void *biasP = nullptr;   // the same tiles as fp16 in score-accumulator order (qkv_attn_bx_kernel)
     float *w1p = nullptr, *w2p = nullptr;  // fragment-major packed MLP weights (fused_mlp_kernel), narrow levels only
     float *wqp = nullptr, *wpp = nullptr;  // fragment-major packed qkv / proj weights (fused_attn96_kernel), C == 96 only
     float *bqkv_s = nullptr;               // qkv bias with the q part pre-scaled (fused_attn96_kernel)
@@ -126,6 +127,7 @@ struct dsg_handle_s {
     bool opt_gemm_bf16 = false;                                   // bf16-MFMA GEMMs (fp32 accumulate), opt-in precision mode
     int opt_bf16_act = 2;                                         // in that mode: 1 hidden / attention-output tensors stored as bf16 (bit-identical), 2 also qkv
     bool opt_bf16_pipe = true;                                    // in that mode: the bf16 block pipeline of kernels_bx.hip (0: round 2's kernels_lp.hip path)
+    bool opt_bf16_qkv_attn = true;                                // in that pipeline: QKV projection + window attention in one kernel (0: GEMM + attn_bx_kernel through a bf16 qkv tensor)
     int opt_bf16_mlp = 1;                                         // in that pipeline: the fused fc1-GELU-fc2 kernel at C <= 192 (0: two GEMMs with a bf16 hidden tensor; 2: also at C = 384)
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
@@ -362,6 +364,11 @@ int build_bias_table(dsg_handle h, BlockPlan &bp) {
     if (int rc = dev_alloc(h, h->derived_allocs, &p, sizeof(float) * out.size())) return rc;
     HIP_TRY(h, hipMemcpy(p, out.data(), sizeof(float) * out.size(), hipMemcpyHostToDevice));
     bp.biasT = (float *)p;
+    void *pp;
+    if (int rc = dev_alloc(h, h->derived_allocs, &pp, sizeof(uint16_t) * out.size())) return rc;
+    launch_bias_permute_bx(bp.biasT, pp, nWt * heads, Wp, nullptr);
+    HIP_TRY(h, hipStreamSynchronize(nullptr));
+    bp.biasP = pp;
     return 0;
 }
 
@@ -1108,11 +1115,18 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
     if (st == BX_RAW) P_KERN(PK_ROW, 0.0, launch_ln_bx(w->x, w->aff, w->aff_ld, b.aff_off, w->xn, B, T, C, true, s));
     else if (st == BX_MOD) P_KERN(PK_ROW, 0.0, launch_ln_bx(w->x, nullptr, 0, 0, w->xn, B, T, C, true, s));
     BxGemm g;
-    g.A = w->xn; g.lda = C; g.K = C; g.M = M; g.N = 3 * C;
-    g.W = bf16_of(h, b.qkv_wf); g.bias = b.qkv_bf; g.Cb = w->qkv; g.ldcb = 3 * C;
-    P_BX(g, "qkv");
     WinGeom wg{b.res, b.ws, b.shift, b.heads, C};
-    {
+    bool fused_qa = false;
+    if (h->opt_bf16_qkv_attn && h->taps.empty()) {   // (the qkv tap wants the tensor)
+        BxQkvAttn qa;
+        qa.xn = w->xn; qa.W = bf16_of(h, b.qkv_wf); qa.bias = b.qkv_bf; qa.biasP = b.biasP; qa.out = w->att; qa.B = B; qa.g = wg;
+        ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)M * 3.0 * C * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, "qkv_attn_bx");
+        fused_qa = launch_qkv_attn_bx(qa, s);
+    }
+    if (!fused_qa) {
+        g.A = w->xn; g.lda = C; g.K = C; g.M = M; g.N = 3 * C;
+        g.W = bf16_of(h, b.qkv_wf); g.bias = b.qkv_bf; g.Cb = w->qkv; g.ldcb = 3 * C;
+        P_BX(g, "qkv");
         ProfScope ps_(h, s, PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, "attn_bx");
         if (!launch_attn_bx(w->qkv, b.biasT, w->att, B, wg, s)) launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s, true, true);
     }
@@ -1504,6 +1518,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "bf16_act") h->opt_bf16_act = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "bf16_pipe") h->opt_bf16_pipe = value != 0;
     else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "bf16_qkv_attn") h->opt_bf16_qkv_attn = value != 0;
     else if (n == "fused_merge") { h->opt_fused_merge = value != 0; h->opt_fused_merge_small = value > 1; }   // 2: at every size
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
@@ -1532,6 +1547,7 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "bf16_act") *value = (h->opt_gemm_bf16 && !h->opt_gemm_split && !h->opt_bf16_pipe) ? h->opt_bf16_act : 0;   // acts in round 2's bf16 path only
     else if (n == "bf16_pipe") *value = bx_on(h);   // the bf16 block pipeline runs (bf16 mode only)
     else if (n == "bf16_mlp") *value = bx_on(h) ? h->opt_bf16_mlp : 0;
+    else if (n == "bf16_qkv_attn") *value = (bx_on(h) && h->opt_bf16_qkv_attn) ? 1 : 0;
     else if (n == "fused_merge") *value = h->opt_fused_merge ? (h->opt_fused_merge_small ? 2 : 1) : 0;
     else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
     else if (n == "gemm_split") *value = h->opt_gemm_split;
@@ -1938,6 +1954,29 @@ int dsg_debug_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int32_t
     return (e == hipSuccess && hipGetLastError() == hipSuccess) ? DSG_OK : DSG_ERR_HIP;
 }
 
+int dsg_debug_qkv_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int32_t heads, const float *xn, const float *W, const float *bias,
+                          const float *biasT, float *out, int32_t time_iters, float *out_ms, void *stream) {
+    if (B < 1 || res < 1 || ws < 1 || res % ws != 0 || heads < 1 || !xn || !W || !bias || !biasT || !out) return DSG_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    const int C = 32 * heads, Wp = (ws * ws + 31) / 32 * 32, nW = (res / ws) * (res / ws), nWt = shift > 0 ? nW : 1;
+    const size_t M = (size_t)B * res * res, nb = (size_t)nWt * heads * Wp * Wp;
+    void *xb = nullptr, *wb = nullptr, *ob = nullptr, *bp = nullptr;
+    if (hipMalloc(&xb, M * C * 2) != hipSuccess || hipMalloc(&wb, (size_t)3 * C * C * 2) != hipSuccess || hipMalloc(&ob, M * C * 2) != hipSuccess ||
+        hipMalloc(&bp, nb * 2) != hipSuccess) { (void)hipFree(xb); (void)hipFree(wb); (void)hipFree(ob); (void)hipFree(bp); return DSG_ERR_HIP; }
+    launch_f32_to_bf16(xn, xb, M * C, s);
+    launch_f32_to_bf16(W, wb, (size_t)3 * C * C, s);
+    launch_bias_permute_bx(biasT, bp, nWt * heads, Wp, s);
+    BxQkvAttn qa;
+    qa.xn = xb; qa.W = wb; qa.bias = bias; qa.biasP = bp; qa.out = ob; qa.B = B; qa.g = WinGeom{res, ws, shift, heads, C};
+    const bool ok = launch_qkv_attn_bx(qa, s);
+    if (ok) launch_bf16_to_f32(ob, out, M * C, s);
+    if (ok && time_iters > 0 && out_ms) *out_ms = time_launches(s, time_iters, [&]() { (void)launch_qkv_attn_bx(qa, s); });
+    const hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(xb); (void)hipFree(wb); (void)hipFree(ob); (void)hipFree(bp);
+    if (!ok) return DSG_ERR_INVALID;
+    return (e == hipSuccess && hipGetLastError() == hipSuccess) ? DSG_OK : DSG_ERR_HIP;
+}
+
 int dsg_train_inputs(int32_t B, int32_t N, int32_t c_adj, int32_t c_node, const float *clean_adj, const float *clean_node,
                      const uint8_t *flags, const float *rnd_sigma, const float *eps_adj, const float *eps_node, uint64_t seed,
                      float *out_sigmas, float *out_weights, float *out_noisy_adj, float *out_noisy_node, void *stream) {
@@ -2086,7 +2125,7 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
     const int *has_sc_dev = h->train_const + has_sc_host;
     // everything below runs twice: a dry pass that only sizes the arena, then the real pass
     struct Bufs {
-        float *pe, *m0, *s0, *m1, *emb, *d_emb, *tok, *pe_lin, *pe_ln, *pe_stats, *pe_aff, *pe_daff, *x0;
+        float *pe, *m0, *s0, *m1, *emb, *d_emb, *pe_demb, *tok, *pe_lin, *pe_ln, *pe_stats, *pe_aff, *pe_daff, *x0;
         float *mcat[8], *mnrm[8], *mstats[8], *mout[8];                       // PatchMerging per level
         float *ucat[8], *uy[8], *un[8], *ustats[8], *usc[8], *upn[8], *upstats[8], *uout[8];   // PatchBreakup per up layer
         float *fy, *fstats, *z1, *z2, *rep, *ha_pre, *ha, *oa, *pool, *hn_pre, *hn, *on;
@@ -2117,6 +2156,7 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
         for (int l = 0; l < 8; l++) { enc[l].clear(); dec[l].clear(); }
         Bf.pe = A.get((size_t)B * E); Bf.m0 = A.get((size_t)B * NOISE_EMB); Bf.s0 = A.get((size_t)B * NOISE_EMB);
         Bf.m1 = A.get((size_t)B * NOISE_EMB); Bf.emb = A.get((size_t)B * NOISE_EMB); Bf.d_emb = A.get((size_t)B * NOISE_EMB);
+        Bf.pe_demb = A.get((size_t)B * NOISE_EMB);
         Bf.tok = A.get(M0 * Cin); Bf.pe_lin = A.get(M0 * E); Bf.pe_ln = A.get(M0 * E); Bf.pe_stats = A.get(M0 * 2);
         Bf.pe_aff = A.get((size_t)B * 2 * E); Bf.pe_daff = A.get((size_t)B * 2 * E); Bf.x0 = A.get(M0 * E);
         int res = N, C = E;
@@ -2343,16 +2383,19 @@ static int train_grads_core(dsg_handle h, int32_t B, const float *in_adj, const 
         if (grouped) {
             // the affine linears' own backward, all at once: dWa_z = d_aff_z^T emb, d_ba_z = colsum(d_aff_z), d_emb = sum_z d_aff_z Wa_z
             TGemmGroup gw, gb, ge;
-            auto add = [&](const float *d_aff, const float *Wa, float *dWa, float *dba, int C2) {
+            // (d_emb: every product into its own [B, 512] buffer -- 16 x 2 tiles per product fill the chip, one shared output would
+            // leave it to 32 blocks -- then one ordered sum)
+            auto add = [&](const float *d_aff, const float *Wa, float *dWa, float *dba, float *d_emb_z, int C2) {
                 gw.p[gw.n++] = TGemmProb{d_aff, Bf.emb, nullptr, dWa, C2, NOISE_EMB, NOISE_EMB, C2, NOISE_EMB, B};
                 gb.p[gb.n++] = TGemmProb{d_aff, nullptr, nullptr, dba, C2, 0, 0, B, C2, 0};
-                ge.p[ge.n++] = TGemmProb{d_aff, Wa, nullptr, Bf.d_emb, C2, NOISE_EMB, NOISE_EMB, B, NOISE_EMB, C2};
+                ge.p[ge.n++] = TGemmProb{d_aff, Wa, nullptr, d_emb_z, C2, NOISE_EMB, NOISE_EMB, B, NOISE_EMB, C2};
             };
-            add(Bf.pe_daff, Wt("patch_embed.affine.weight"), Gd("patch_embed.affine.weight"), Gd("patch_embed.affine.bias"), 2 * E);
-            for (Stage *st : all_stages) add(st->a.d_aff, st->a.W.aff_w, st->a.G.aff_w, st->a.G.aff_b, 2 * st->a.C);
+            add(Bf.pe_daff, Wt("patch_embed.affine.weight"), Gd("patch_embed.affine.weight"), Gd("patch_embed.affine.bias"), Bf.pe_demb, 2 * E);
+            for (Stage *st : all_stages) add(st->a.d_aff, st->a.W.aff_w, st->a.G.aff_w, st->a.G.aff_b, st->d_emb, 2 * st->a.C);
             t_gemm_grouped(true, false, false, gw, s);
             t_colsum_grouped(gb, s);
-            t_gemm_grouped(false, false, true, ge, s);
+            t_gemm_grouped(false, false, false, ge, s);
+            t_sum_grouped(ge, Bf.d_emb, B * NOISE_EMB, s);
         } else {
             t_gemm(true, false, Bf.pe_daff, 2 * E, Bf.emb, NOISE_EMB, nullptr, Gd("patch_embed.affine.weight"), NOISE_EMB, 2 * E, NOISE_EMB, B, false, s);
             t_colsum(Bf.pe_daff, 2 * E, Gd("patch_embed.affine.bias"), B, 2 * E, s);

@@ -99,6 +99,12 @@ bool launch_mlp_bx(const BxMlp &g, hipStream_t s);
 void launch_ln_bx(float *x, const float *aff, int aff_ld, int aff_off, void *xn, int B, int T, int C, bool ln, hipStream_t s);
 // window attention on bf16 qkv [B*T, 3C] -> bf16 out [B*T, C]; biasT as launch_window_attn; false: window size not covered
 bool launch_attn_bx(const void *qkv, const float *biasT, void *out, int B, const WinGeom &g, hipStream_t s);
+// QKV projection + window attention fused (no qkv tensor): xn bf16 [B*T, C] (LayerNorm-1 without affine), W bf16 [3C, C] and bias [3C]
+// (gamma / beta and the q scale folded in), biasP = the block's bias tiles in accumulator order as fp16 (launch_bias_permute_bx of the
+// [nWt][heads][Wp][Wp] table), out bf16 [B*T, C].  false: window size / width not covered.
+struct BxQkvAttn { const void *xn = nullptr, *W = nullptr; const float *bias = nullptr; const void *biasP = nullptr; void *out = nullptr; int B = 0; WinGeom g{0, 0, 0, 0, 0}; };
+bool launch_qkv_attn_bx(const BxQkvAttn &a, hipStream_t s);
+void launch_bias_permute_bx(const float *biasT, void *out_fp16, int n_tiles, int Wp, hipStream_t s);
 void launch_f32_split3(const float *src, void *dst, size_t n, hipStream_t s);
 void launch_bf16_to_f32(const void *src, float *dst, size_t n, hipStream_t s);
 // device table of the fused MLP's table-driven GELU; must be called once (outside any stream capture) before the first launch
@@ -221,6 +227,7 @@ struct TGemmProb { const float *A, *B, *bias; float *C; int lda, ldb, ldc, M, N,
 constexpr int T_GROUP_MAX = 32;
 struct TGemmGroup { TGemmProb p[T_GROUP_MAX]; int n = 0; };
 void t_gemm_grouped(bool ta, bool tb, bool sum, const TGemmGroup &g, hipStream_t s);   // sum: ONE output = the sum of the products (shared M, N, C)
+void t_sum_grouped(const TGemmGroup &g, float *out, int n, hipStream_t s);           // out[i] = sum_z p[z].C[i], i < n (contiguous outputs)
 void t_colsum_grouped(const TGemmGroup &g, hipStream_t s);                             // p.C[n] = sum_m p.A[m][n] per problem
 bool train_block(const TrainBlockArgs &a, hipStream_t s);            // forward; + backward when a.grad_out is set
 bool train_block_backward(const TrainBlockArgs &a, hipStream_t s);   // backward alone, from the tensors the forward left in `a`

@@ -830,6 +830,239 @@ __global__ __launch_bounds__(256, 2) void attn_bx_kernel(const __bf16 *__restric
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// QKV projection + window attention in one kernel (diffusesg.py:108-139 with the window partition / cyclic shift / reverse of :246-270
+// folded into the token index): q, k, v never reach HBM.  A block owns 128 window positions -- one 100-token window padded to 128, two
+// 64-token windows, four 16/25-token windows padded to 32 -- of ONE head:
+//   1. [128 positions x C] (rows gathered from xn through the partition) x the head's [96 x C] slice of the QKV weight (32 q, 32 k,
+//      32 v rows; q pre-scaled by d^-1/2 log2 e, LayerNorm-1's gamma / beta folded in), the K loop of gemm_bx_kernel with 32 x 96 wave
+//      tiles (transposed product: a lane owns one window position, its accumulators are 16 features of q, of k and of v);
+//   2. q stays in registers as the B operand of S^T = K Q^T (register r <-> feature (r & 3) + 8 (r >> 2) + 4 half: the same feature
+//      order on both operands, so the contraction does not care); k goes to LDS in exactly that order (the writer's 16 bytes are the
+//      reader's A fragment); v goes to LDS transposed, vt[d][pos(key)], as attn_bx_kernel stages it;
+//   3. softmax and O^T = V^T P^T as in attn_bx_kernel, the bias tile read as fp16 in accumulator order (bias_permute_bx_kernel: 64
+//      bytes per lane and key tile, straight into the score accumulators' initial values).
+// Blocks of one window group run back to back on one XCD (head fastest), so the group's xn rows are read from HBM once.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias_permute_bx_kernel(const float *__restrict__ biasT, _Float16 *__restrict__ out, int n_tiles, int Wp) {
+    // out[tile][query][half][kt][r] = biasT[tile][key = 32 kt + (r & 3) + 8 (r >> 2) + 4 half][query]  (clamped into fp16 range)
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)n_tiles * Wp * Wp) return;
+    const int KT = Wp / 32;
+    const int r = idx % 16, kt = (idx / 16) % KT, half = (idx / (16 * KT)) % 2, q = (idx / (32 * KT)) % Wp;
+    const size_t tile = idx / ((size_t)Wp * Wp);
+    const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+    out[idx] = (_Float16)fmaxf(biasT[(tile * Wp + key) * Wp + q], -60000.f);
+}
+void launch_bias_permute_bx(const float *biasT, void *out, int n_tiles, int Wp, hipStream_t s) {
+    const size_t n = (size_t)n_tiles * Wp * Wp;
+    hipLaunchKernelGGL(bias_permute_bx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, biasT, (_Float16 *)out, n_tiles, Wp);
+}
+
+template <int KT, int WS>
+__global__ __launch_bounds__(256, 2) void qkv_attn_bx_kernel(BxQkvAttn a, int nblk, int U) {
+    constexpr int KB = 64, LDP = KB + 8, Wp = 32 * KT, Wt = WS * WS, UPB = 4 / KT, KLD = 40, VLD = Wp + 8;
+    constexpr int STAGE = (128 + 96) * LDP;
+    static_assert(128 * KLD + UPB * 32 * VLD <= STAGE, "k / v^T live in the tile stage after the K loop");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[STAGE + 2 * 96];
+    float *colv = reinterpret_cast<float *>(lds + STAGE);      // the head's 96 bias values (q | k | v)
+    __bf16 *kl = lds, *vtl = lds + 128 * KLD;
+    const unsigned OOB = 0x7fffffffu;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int heads = a.g.heads, C = a.g.C, res = a.g.res, shift = a.g.shift;
+    const int nwr = res / WS, nW = nwr * nwr, T = res * res;
+    const int t = blockIdx.x, xcd = t & 7, seq = t >> 3;
+    const int ub = (seq / heads) * 8 + xcd, head = seq % heads;
+    if (ub >= nblk) return;
+    // token of block row `row` (unit ub UPB + row / Wp, window position row % Wp): element offset in xn / out, or -1
+    auto row_token = [&](int row) -> int {
+        const int ul = row / Wp, pos = row % Wp, u = ub * UPB + ul;
+        if (pos >= Wt || u >= U) return -1;
+        const int b = u / nW, w = u % nW, wi = w / nwr, wj = w % nwr;
+        int ti = wi * WS + pos / WS + shift, tj = wj * WS + pos % WS + shift;
+        if (ti >= res) ti -= res;
+        if (tj >= res) tj -= res;
+        return b * T + ti * res + tj;
+    };
+    const __bf16 *xn = static_cast<const __bf16 *>(a.xn), *Wq = static_cast<const __bf16 *>(a.W);
+    const rsrc_t rsA = make_rsrc(xn, (unsigned)((size_t)a.B * T * C * 2u));
+    const rsrc_t rsW = make_rsrc(Wq, (unsigned)(3u * C * C * 2u));
+    const int sc = tid & 7, sr = tid >> 3;             // this thread's 16-byte piece / first stage row
+    unsigned offA[4], offW[3];
+#pragma unroll
+    for (int p = 0; p < 4; p++) { const int tk = row_token(sr + 32 * p); offA[p] = tk < 0 ? OOB : ((unsigned)tk * C + 8u * sc) * 2u; }
+#pragma unroll
+    for (int p = 0; p < 3; p++) offW[p] = ((unsigned)(p * C + head * 32 + sr) * C + 8u * sc) * 2u;
+    const int nk = (C + KB - 1) / KB;                  // >= 2 (launcher)
+    struct Stage { u32x4 a[4], w[3]; };
+    auto issue = [&](Stage &st, int kc) {
+        const int k0 = kc * KB;
+        const unsigned kmask = (k0 + 8 * sc < C) ? 0u : OOB;   // C = 96: the second chunk is half valid
+#pragma unroll
+        for (int p = 0; p < 4; p++) st.a[p] = buf_load_u4(rsA, offA[p] | kmask, (unsigned)k0 * 2u);
+#pragma unroll
+        for (int p = 0; p < 3; p++) st.w[p] = buf_load_u4(rsW, offW[p] | kmask, (unsigned)k0 * 2u);
+    };
+    auto write = [&](const Stage &st) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) *reinterpret_cast<u32x4 *>(lds + (sr + 32 * p) * LDP + 8 * sc) = st.a[p];
+#pragma unroll
+        for (int p = 0; p < 3; p++) *reinterpret_cast<u32x4 *>(lds + (128 + sr + 32 * p) * LDP + 8 * sc) = st.w[p];
+    };
+    f32x16 acc[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
+    const __bf16 *Afr = lds + (32 * wave + lrow) * LDP + 8 * lhalf;
+    const __bf16 *Wfr = lds + (128 + lrow) * LDP + 8 * lhalf;
+    auto compute = [&]() {
+#pragma unroll
+        for (int s = 0; s < KB / 16; s++) {
+            const bf16x8 af = *reinterpret_cast<const bf16x8 *>(Afr + 16 * s);
+#pragma unroll
+            for (int nt = 0; nt < 3; nt++) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(Wfr + 32 * nt * LDP + 16 * s);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc[nt], 0, 0, 0);
+            }
+        }
+    };
+    Stage s0, s1;
+    issue(s0, 0);
+    issue(s1, 1);
+    float cvb = 0.f;
+    if (tid < 96) cvb = a.bias[(tid >> 5) * C + head * 32 + (tid & 31)];
+    write(s0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; kc += 2) {   // LDS holds chunk kc, s1 holds chunk kc + 1, s0 is free
+        if (kc + 2 < nk) issue(s0, kc + 2);
+        compute();
+        __syncthreads();
+        if (kc + 1 < nk) {
+            write(s1);
+            __syncthreads();
+            if (kc + 3 < nk) issue(s1, kc + 3);
+            compute();
+            __syncthreads();
+            if (kc + 2 < nk) { write(s0); __syncthreads(); }
+        }
+    }
+    // ---- this wave's attention unit: window positions 32 wave .. + 31 are query tile qt of unit ul ----
+    const int ul = wave / KT, qt = wave % KT;
+    const int u = ub * UPB + ul, w_of_u = (u < U ? u : 0) % nW;
+    // bias tile of this lane's query in accumulator order (fp16): issued now, consumed after the LDS phase
+    const u32x4 *bp = reinterpret_cast<const u32x4 *>(a.biasP) +
+                      ((((size_t)(shift > 0 ? w_of_u : 0) * heads + head) * Wp + 32 * qt + lrow) * 2 + lhalf) * (KT * 2);
+    u32x4 bb[KT][2];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) { bb[kt][0] = bp[2 * kt]; bb[kt][1] = bp[2 * kt + 1]; }
+    if (tid < 96) colv[tid] = cvb;
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(colv + 32 * nt + 8 * q + 4 * lhalf);
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[nt][4 * q + e] += b4[e];
+        }
+    bf16x8 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        u32x4 pq, pk;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            pq[j] = pack_bf16(acc[0][8 * s + 2 * j], acc[0][8 * s + 2 * j + 1]);
+            pk[j] = pack_bf16(acc[1][8 * s + 2 * j], acc[1][8 * s + 2 * j + 1]);
+        }
+        qf[s] = __builtin_bit_cast(bf16x8, pq);
+        *reinterpret_cast<u32x4 *>(kl + (32 * wave + lrow) * KLD + 16 * s + 8 * lhalf) = pk;
+    }
+    {   // v^T: this lane's key -> column pos(key) (bits 2 and 3 of the position swapped), its 16 features -> rows
+        const int pos = 32 * qt + lrow, pp = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);
+        __bf16 *vcol = vtl + (ul * 32 + 4 * lhalf) * VLD + pp;
+#pragma unroll
+        for (int r = 0; r < 16; r++) vcol[((r & 3) + 8 * (r >> 2)) * VLD] = (__bf16)acc[2][r];
+    }
+    __syncthreads();
+    bf16x8 kf[KT][2], vf[KT][2];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            kf[kt][s] = *reinterpret_cast<const bf16x8 *>(kl + (ul * Wp + 32 * kt + lrow) * KLD + 16 * s + 8 * lhalf);
+            vf[kt][s] = *reinterpret_cast<const bf16x8 *>(vtl + (ul * 32 + lrow) * VLD + 32 * kt + 16 * s + 8 * lhalf);
+        }
+    f32x16 sacc[KT];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const unsigned dw = bb[kt][r >> 3][(r & 7) >> 1];   // (a bit_cast of the vector element itself reads element 0 with this compiler)
+            const h2 pk = __builtin_bit_cast(h2, dw);
+            sacc[kt][r] = (float)pk[0]; sacc[kt][r + 1] = (float)pk[1];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[s], sacc[kt], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[r] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        u32x4 pf[2];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float e0 = __builtin_amdgcn_exp2f(sacc[kt][r] - mx), e1 = __builtin_amdgcn_exp2f(sacc[kt][r + 1] - mx);
+            sum += e0 + e1;
+            pf[r >> 3][(r & 7) >> 1] = pack_bf16(e0, e1);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; s++) oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], __builtin_bit_cast(bf16x8, pf[s]), oacc, 0, 0, 0);
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = fast_rcp(sum);
+    // O^T tile: lane = query, quad q = head dims 8 q + 4 half + {0..3}
+    const int tq = row_token(32 * wave + lrow);
+    const rsrc_t rsO = make_rsrc(a.out, (unsigned)((size_t)a.B * T * C * 2u));
+    const unsigned eoff = tq < 0 ? OOB : ((unsigned)tq * (unsigned)C + (unsigned)(head * 32 + 4 * lhalf)) * 2u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = oacc[4 * q + e] * inv;
+        buf_store2(pack_bf16x4(o), rsO, tq < 0 ? OOB : eoff + 16u * q, 0u);
+    }
+}
+
+bool launch_qkv_attn_bx(const BxQkvAttn &a, hipStream_t s) {
+    const WinGeom &g = a.g;
+    if (!a.xn || !a.W || !a.bias || !a.biasP || !a.out || a.B < 1) return false;
+    if (g.C != 32 * g.heads || g.C % 8 != 0 || g.C < 96 || g.res % g.ws != 0) return false;
+    if ((size_t)a.B * g.res * g.res * g.C * 2u >= 0x7fffffffull) return false;   // 32-bit buffer offsets
+    const int nW = (g.res / g.ws) * (g.res / g.ws), U = a.B * nW;
+    int kt;
+    switch (g.ws) { case 4: case 5: kt = 1; break; case 8: kt = 2; break; case 10: kt = 4; break; default: return false; }
+    const int upb = 4 / kt, nblk = (U + upb - 1) / upb;
+    const dim3 grid((unsigned)(((nblk + 7) / 8) * 8 * g.heads)), block(256);
+#define QA(KT_, WS_) hipLaunchKernelGGL((qkv_attn_bx_kernel<KT_, WS_>), grid, block, 0, s, a, nblk, U)
+    switch (g.ws) {
+        case 4: QA(1, 4); break;
+        case 5: QA(1, 5); break;
+        case 8: QA(2, 8); break;
+        default: QA(4, 10); break;
+    }
+#undef QA
+    return true;
+}
+
 bool launch_attn_bx(const void *qkv, const float *biasT, void *out, int B, const WinGeom &g, hipStream_t s) {
     const int nW = (g.res / g.ws) * (g.res / g.ws);
     if (g.C != 32 * g.heads || g.C % 8 != 0 || g.res % g.ws != 0) return false;

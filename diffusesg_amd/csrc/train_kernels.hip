@@ -144,6 +144,14 @@ __global__ __launch_bounds__(256) void t_gemm_grouped_kernel(TGemmGroup g) {
         if (m < p.M && n < p.N) p.C[(size_t)m * p.ldc + n] = acc[i] + (p.bias ? p.bias[n] : 0.f);
     }
 }
+// out[i] = sum_z C_z[i] over the group's (contiguous, equally sized M x N) outputs, in order
+__global__ __launch_bounds__(256) void t_sum_grouped_kernel(TGemmGroup g, float *out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int z = 0; z < g.n; z++) v += g.p[z].C[i];
+    out[i] = v;
+}
 // out_z[n] = sum_m X_z[m][n] for a group of short matrices (M <= a few hundred rows: the bias gradients of the affine linears)
 __global__ __launch_bounds__(256) void t_colsum_grouped_kernel(TGemmGroup g) {
     const TGemmProb &p = g.p[blockIdx.y];   // A = X [M, N] (lda), C = out [N]
@@ -389,7 +397,12 @@ void t_gemm_grouped(bool ta, bool tb, bool sum, const TGemmGroup &g, hipStream_t
     if (!ta && tb && !sum) hipLaunchKernelGGL((t_gemm_grouped_kernel<false, true, false>), grid, block, 0, s, g);
     else if (ta && !tb && !sum) hipLaunchKernelGGL((t_gemm_grouped_kernel<true, false, false>), grid, block, 0, s, g);
     else if (!ta && !tb && sum) hipLaunchKernelGGL((t_gemm_grouped_kernel<false, false, true>), grid, block, 0, s, g);
+    else if (!ta && !tb && !sum) hipLaunchKernelGGL((t_gemm_grouped_kernel<false, false, false>), grid, block, 0, s, g);
     else t_scratch(s).failed = true;   // (no other form is used)
+}
+void t_sum_grouped(const TGemmGroup &g, float *out, int n, hipStream_t s) {
+    if (g.n < 1) return;
+    hipLaunchKernelGGL(t_sum_grouped_kernel, dim3((n + 255) / 256), dim3(256), 0, s, g, out, n);
 }
 void t_colsum_grouped(const TGemmGroup &g, hipStream_t s) {
     if (g.n < 1) return;
@@ -541,16 +554,20 @@ __global__ __launch_bounds__(256) void t_ln_bwd_kernel(const float *__restrict__
         p[C + c] = ((double)red[0][1][c] + (double)red[1][1][c]) + ((double)red[2][1][c] + (double)red[3][1][c]);
     }
 }
-// (d_gamma | d_beta)[c] = sum over the R block partials, in order: block = 64 columns x 4 lanes over the partials
+// (d_gamma | d_beta)[c] = sum over the R block partials, in a fixed order: block = 16 columns x 16 row lanes (lane q adds partials
+// q, q + 16, ...; the 16 lane sums are added in order)
 __global__ __launch_bounds__(256) void t_ln_bwd_final_kernel(const double *part, float *d_gamma, float *d_beta, int C, int R) {
-    __shared__ double red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;   // c over 2C
+    __shared__ double red[16][17];
+    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;   // c over 2C
     double sacc = 0.0;
-    if (c < 2 * C) for (int r = q; r < R; r += 4) sacc += part[(size_t)r * 2 * C + c];
-    red[q][threadIdx.x & 63] = sacc;
+    if (c < 2 * C) for (int r = q; r < R; r += 16) sacc += part[(size_t)r * 2 * C + c];
+    red[q][cl] = sacc;
     __syncthreads();
     if (q == 0 && c < 2 * C) {
-        const float v = (float)((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) t += red[k][cl];
+        const float v = (float)t;
         if (c < C) { if (d_gamma) d_gamma[c] = v; } else if (d_beta) d_beta[c - C] = v;
     }
 }
@@ -1063,7 +1080,7 @@ void t_ln_bwd(const float *x, const float *gam, const float *stats, const float 
     if (kc <= 2) T_LNB(2); else if (kc <= 3) T_LNB(3); else if (kc <= 6) T_LNB(6); else if (kc <= 12) T_LNB(12); else if (kc <= 24) T_LNB(24);
     else { ts.failed = true; return; }   // rows wider than 1536 channels do not occur (4 x 384 is the widest LayerNorm of the networks)
 #undef T_LNB
-    hipLaunchKernelGGL(t_ln_bwd_final_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, s, part, d_gamma, d_beta, C, blocks);
+    hipLaunchKernelGGL(t_ln_bwd_final_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, part, d_gamma, d_beta, C, blocks);
 }
 void t_modulate(const float *x, const float *aff, const float *dy, float *out, float *d_aff, int B, int T, int C, bool bwd, hipStream_t s) {
     if (bwd) {

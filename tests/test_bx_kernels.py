@@ -125,6 +125,52 @@ def test_attn_bx_vs_torch(B, res, ws, shift, heads):
     assert worst <= 2e-3, f"attention: {worst:.2e} beyond bf16 rounding of the output"
 
 
+@pytest.mark.parametrize("B,res,ws,shift,heads", [(3, 10, 10, 0, 12), (5, 20, 10, 5, 6), (2, 40, 10, 0, 3), (4, 16, 8, 4, 12), (3, 8, 8, 0, 24),
+                                                  (5, 16, 8, 0, 3), (2, 16, 4, 2, 3), (7, 4, 4, 0, 6), (3, 10, 5, 2, 3)])
+def test_qkv_attn_bx_vs_torch(B, res, ws, shift, heads):
+    """QKV projection + window attention in one kernel against fp64 on the bf16-rounded operands: q, k, v are formed in fp32, rounded
+    to bf16 (as the kernel hands them to the second and third product) and then follow test_attn_bx_vs_torch's reference.  Odd unit
+    counts (the last block is partly empty), two / four windows per block (64- / 16- / 25-token windows), shifted masks, C = 96 (K ends
+    inside a 64-deep chunk) up to 768."""
+    from diffusesg_amd import lib as L
+    lib = L.load()
+    Cc, T, Wt = 32 * heads, res * res, ws * ws
+    Wp = (Wt + 31) // 32 * 32
+    nW = (res // ws) ** 2
+    nWt = nW if shift > 0 else 1
+    gen = torch.Generator(device="cuda").manual_seed(11 + B + res + ws + heads)
+    xn = torch.randn(B * T, Cc, device="cuda", generator=gen)
+    W = torch.randn(3 * Cc, Cc, device="cuda", generator=gen) / Cc ** 0.5
+    W[:Cc] *= 0.25 * 1.4426950408889634               # q rows pre-scaled by d^-1/2 log2(e)
+    bqkv = torch.randn(3 * Cc, device="cuda", generator=gen) * 0.2
+    bias = torch.randn(nWt, heads, Wp, Wp, device="cuda", generator=gen) * 1.5
+    if shift > 0:
+        bias[torch.rand(nWt, 1, Wp, Wp, device="cuda", generator=gen).expand(-1, heads, -1, -1) < 0.2] -= 144.0
+    bias[:, :, Wt:, :] = -1.0e30
+    out = torch.full((B * T, Cc), float("nan"), device="cuda")
+    rc = lib.dsg_debug_qkv_attn_bx(B, res, ws, shift, heads, _p(xn), _p(W), _p(bqkv), _p(bias.contiguous()), _p(out), 0, None, None)
+    assert rc == 0
+    qkv = _bf((_bf(xn).double() @ _bf(W).double().t() + bqkv.double()).float())
+    tok = torch.from_numpy(_window_tokens(res, ws, shift)).cuda()
+    x = qkv.double().view(B, T, 3, heads, 32)
+    xw = x[:, tok]
+    q, k, v = xw[..., 0, :, :].permute(0, 1, 3, 2, 4), xw[..., 1, :, :].permute(0, 1, 3, 2, 4), xw[..., 2, :, :].permute(0, 1, 3, 2, 4)
+    # the kernel reads the bias tile as fp16
+    bt = bias[:, :, :Wt, :Wt].clamp(min=-60000.0).half().double()
+    s = torch.einsum("bwhkd,bwhqd->bwhkq", k, q) + (bt[None] if shift > 0 else bt[None].expand(1, nW, -1, -1, -1))
+    e = torch.exp2(s - s.max(dim=3, keepdim=True).values)
+    o = torch.einsum("bwhkq,bwhkd->bwhqd", _bf(e.float()).double(), v) / e.sum(dim=3)[..., None]
+    ref = torch.zeros(B, T, heads, 32, device="cuda", dtype=torch.float64)
+    ref[:, tok] = o.permute(0, 1, 3, 2, 4)
+    ref = ref.view(B * T, Cc)
+    assert torch.isfinite(out).all()
+    scale = float(ref.abs().max())
+    err = (out.double() - ref).abs() - 2.0 ** -8 * ref.abs()
+    worst = float(err.max()) / scale
+    # (a q / k / v value on a bf16 rounding boundary may round the other way than in fp64: 2^-9 relative on one of 32 + 100 terms)
+    assert worst <= 4e-3, f"qkv + attention: {worst:.2e} beyond bf16 rounding of the output"
+
+
 @pytest.mark.parametrize("M,C,mod,out_mode", [(51200, 384, 1, 1), (20037, 192, 1, 1), (65541, 96, 0, 2), (300, 96, 1, 1), (4096, 384, 0, 0),
                                                (1000, 192, 0, 2)])
 def test_mlp_bx_whole_matrix(M, C, mod, out_mode):

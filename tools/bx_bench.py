@@ -73,6 +73,27 @@ def attn(tag, B, res, ws, shift, heads):
           f"{by / ms.value / 1e9:6.2f} TB/s", flush=True)
 
 
+def qkv_attn(tag, B, res, ws, shift, heads):
+    g = torch.Generator(device="cuda").manual_seed(4)
+    Cc, T = 32 * heads, res * res
+    Wp = (ws * ws + 31) // 32 * 32
+    nWt = (res // ws) ** 2 if shift else 1
+    xn = torch.randn(B * T, Cc, device="cuda", generator=g)
+    W = torch.randn(3 * Cc, Cc, device="cuda", generator=g) / Cc ** 0.5
+    W[:Cc] *= 0.25
+    bq = torch.randn(3 * Cc, device="cuda", generator=g) * 0.1
+    bias = torch.randn(nWt, heads, Wp, Wp, device="cuda", generator=g)
+    bias[:, :, ws * ws:, :] = -1e30
+    out = torch.empty(B * T, Cc, device="cuda")
+    ms = C.c_float(0)
+    rc = lib.dsg_debug_qkv_attn_bx(B, res, ws, shift, heads, p(xn), p(W), p(bq), p(bias), p(out), ITERS, C.byref(ms), None)
+    assert rc == 0, rc
+    fl = 4.0 * B * T * ws * ws * Cc + 6.0 * B * T * Cc * Cc
+    by = B * T * 2 * Cc * 2
+    print(f"{tag:34s} B={B} res={res} ws={ws} heads={heads}: {ms.value * 1e3:8.1f} us  {fl / ms.value / 1e9:8.1f} TFLOP/s   min HBM {by / 1e6:7.1f} MB -> "
+          f"{by / ms.value / 1e9:6.2f} TB/s", flush=True)
+
+
 if __name__ == "__main__":
     B = int(os.environ.get("BX_B", "512"))
     print(f"DSG_BX_GEO={os.environ.get('DSG_BX_GEO')}  B={B}")
@@ -98,6 +119,10 @@ if __name__ == "__main__":
     mlp("L0 fused MLP (copy)", M0, 96, mod=0, out_mode=2)
     if only == "gemm":
         sys.exit(0)
+    qkv_attn("L2 qkv + attn fused", B, 10, 10, 0, 12)
+    qkv_attn("L1 qkv + attn fused", B, 20, 10, 0, 6)
+    qkv_attn("L1 qkv + attn fused, shifted", B, 20, 10, 5, 6)
+    qkv_attn("L0 qkv + attn fused", B, 40, 10, 0, 3)
     attn("L2 attn", B, 10, 10, 0, 12)
     attn("L1 attn", B, 20, 10, 0, 6)
     attn("L1 attn shifted", B, 20, 10, 5, 6)
