@@ -862,7 +862,7 @@ void launch_bias_permute_bx(const float *biasT, void *out, int n_tiles, int Wp, 
 template <int KT, int WS>
 __global__ __launch_bounds__(256, 2) void qkv_attn_bx_kernel(BxQkvAttn a, int nblk, int U) {
     constexpr int KB = 64, LDP = KB + 8, Wp = 32 * KT, Wt = WS * WS, UPB = 4 / KT, KLD = 40, VLD = Wp + 8;
-    constexpr int STAGE = (128 + 96) * LDP;
+    constexpr int STAGE = (128 + 96) * LDP, OLD = 40;
     static_assert(128 * KLD + UPB * 32 * VLD <= STAGE, "k / v^T live in the tile stage after the K loop");
     __shared__ __attribute__((aligned(16))) __bf16 lds[STAGE + 2 * 96];
     float *colv = reinterpret_cast<float *>(lds + STAGE);      // the head's 96 bias values (q | k | v)
@@ -994,6 +994,7 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
             kf[kt][s] = *reinterpret_cast<const bf16x8 *>(kl + (ul * Wp + 32 * kt + lrow) * KLD + 16 * s + 8 * lhalf);
             vf[kt][s] = *reinterpret_cast<const bf16x8 *>(vtl + (ul * 32 + lrow) * VLD + 32 * kt + 16 * s + 8 * lhalf);
         }
+    __syncthreads();   // every wave holds its k / v^T fragments: the stage is free for the output transposition at the end
     f32x16 sacc[KT];
     float mx = -3.0e38f;
 #pragma unroll
@@ -1007,8 +1008,11 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
         }
 #pragma unroll
         for (int s = 0; s < 2; s++) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[s], sacc[kt], 0, 0, 0);
+        // register r holds key 32 kt + (r & 3) + 8 (r >> 2) + 4 half: quads whose first key is beyond the window (the last key tile of a
+        // 100-token window keeps 1 quad of 4) are padding on every lane -- no maximum, no exponential, P = 0
 #pragma unroll
-        for (int r = 0; r < 16; r++) mx = fmaxf(mx, sacc[kt][r]);
+        for (int r = 0; r < 16; r++)
+            if (32 * kt + 8 * (r >> 2) < Wt) mx = fmaxf(mx, sacc[kt][r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
@@ -1020,25 +1024,37 @@ __global__ __launch_bounds__(256, 2) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
         u32x4 pf[2];
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            const float e0 = __builtin_amdgcn_exp2f(sacc[kt][r] - mx), e1 = __builtin_amdgcn_exp2f(sacc[kt][r + 1] - mx);
-            sum += e0 + e1;
-            pf[r >> 3][(r & 7) >> 1] = pack_bf16(e0, e1);
+            if (32 * kt + 8 * (r >> 2) < Wt) {
+                const float e0 = __builtin_amdgcn_exp2f(sacc[kt][r] - mx), e1 = __builtin_amdgcn_exp2f(sacc[kt][r + 1] - mx);
+                sum += e0 + e1;
+                pf[r >> 3][(r & 7) >> 1] = pack_bf16(e0, e1);
+            } else {
+                pf[r >> 3][(r & 7) >> 1] = 0u;
+            }
         }
 #pragma unroll
-        for (int s = 0; s < 2; s++) oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], __builtin_bit_cast(bf16x8, pf[s]), oacc, 0, 0, 0);
+        for (int s = 0; s < 2; s++)
+            if (32 * kt + 16 * s < Wt) oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], __builtin_bit_cast(bf16x8, pf[s]), oacc, 0, 0, 0);
     }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = fast_rcp(sum);
-    // O^T tile: lane = query, quad q = head dims 8 q + 4 half + {0..3}
-    const int tq = row_token(32 * wave + lrow);
-    const rsrc_t rsO = make_rsrc(a.out, (unsigned)((size_t)a.B * T * C * 2u));
-    const unsigned eoff = tq < 0 ? OOB : ((unsigned)tq * (unsigned)C + (unsigned)(head * 32 + 4 * lhalf)) * 2u;
+    // O^T tile: lane = query, quad q = head dims 8 q + 4 half + {0..3}.  Through a wave-private 32 x 32 transposition in the (idle) K
+    // loop stage so that a store instruction writes 16 tokens x 64 B instead of 32 tokens x 16 B (tools/store_pattern.cpp)
+    __bf16 *Tq = lds + wave * 32 * OLD;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; e++) o[e] = oacc[4 * q + e] * inv;
-        buf_store2(pack_bf16x4(o), rsO, tq < 0 ? OOB : eoff + 16u * q, 0u);
+        *reinterpret_cast<u32x2 *>(Tq + lrow * OLD + 8 * q + 4 * lhalf) = pack_bf16x4(o);
+    }
+    const rsrc_t rsO = make_rsrc(a.out, (unsigned)((size_t)a.B * T * C * 2u));
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int r = (lane >> 2) + 16 * k, pc = lane & 3;          // token row of the tile, 16-byte piece of its 64 bytes
+        const int tq = row_token(32 * wave + r);
+        const u32x4 d = *reinterpret_cast<const u32x4 *>(Tq + r * OLD + 8 * pc);
+        buf_store_u4(d, rsO, tq < 0 ? OOB : ((unsigned)tq * (unsigned)C + (unsigned)(head * 32 + 8 * pc)) * 2u, 0u);
     }
 }
 
