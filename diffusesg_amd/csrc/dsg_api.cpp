@@ -128,7 +128,7 @@ struct dsg_handle_s {
     int opt_bf16_act = 2;                                         // in that mode: 1 hidden / attention-output tensors stored as bf16 (bit-identical), 2 also qkv
     bool opt_bf16_pipe = true;                                    // in that mode: the bf16 block pipeline of kernels_bx.hip (0: round 2's kernels_lp.hip path)
     bool opt_bf16_qkv_attn = true;                                // in that pipeline: QKV projection + window attention in one kernel (0: GEMM + attn_bx_kernel through a bf16 qkv tensor)
-    int opt_bf16_mlp = 1;                                         // in that pipeline: the fused fc1-GELU-fc2 kernel at C <= 192 (0: two GEMMs with a bf16 hidden tensor; 2: also at C = 384)
+    int opt_bf16_mlp = 1;                                         // in that pipeline: the fused fc1-GELU-fc2 kernels (0: two GEMMs with a bf16 hidden tensor; 1: C <= 192 on 4 waves, C = 384 on 8; 2: C = 384 on the 4-wave kernel too; 3: GEMM pair at C = 384)
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
     bool opt_gemm_split = false;                                  // split-bf16 GEMMs (3 planes, 6 products): fp32-accurate, opt-in
@@ -1142,8 +1142,9 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
     // where the pair of GEMMs is bound by the hidden tensor's HBM round trip (measured at COCO B = 512, tools/bx_bench.py: 324 us
     // against 302 + 325 at C = 96, 270 against 193 + 196 at C = 192).  At C = 384 the fused kernel needs 230 + 192 registers, runs one
     // wave per SIMD and is slower than the two GEMMs (312 us against 115 + 156): option value 2 forces it there too (tests).
-    if (h->opt_bf16_mlp && h->cfg.mlp_ratio == 4 && (C == 96 || C == 192 || (C == 384 && h->opt_bf16_mlp >= 2))) {
+    if (h->opt_bf16_mlp && h->cfg.mlp_ratio == 4 && (C == 96 || C == 192 || (C == 384 && h->opt_bf16_mlp != 3))) {
         BxMlp m;
+        m.wide8 = h->opt_bf16_mlp == 2 ? 0 : 1;
         m.xn = w->xn; m.x = w->x; m.W1 = bf16_of(h, b.fc1_wf); m.b1 = b.fc1_bf;
         m.W2 = bf16_of(h, WT(h, p + ".mlp.fc2.weight")); m.b2 = WT(h, p + ".mlp.fc2.bias"); m.M = M; m.C = C;
         BxState out = BX_RAW;
@@ -1517,7 +1518,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "loop_graph") h->opt_loop_graph = value != 0;
     else if (n == "bf16_act") h->opt_bf16_act = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "bf16_pipe") h->opt_bf16_pipe = value != 0;
-    else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (n == "bf16_qkv_attn") h->opt_bf16_qkv_attn = value != 0;
     else if (n == "fused_merge") { h->opt_fused_merge = value != 0; h->opt_fused_merge_small = value > 1; }   // 2: at every size
     else if (n == "gemm_bf16") {
@@ -1913,6 +1914,8 @@ int dsg_debug_gemm_bx(int32_t M, int32_t N, int32_t K, const float *A, const flo
 
 int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *mod, int32_t out_mode, float *out_xn, int32_t time_iters, float *out_ms, void *stream) {
+    const int narrow384 = (out_mode >> 4) & 1;   // + 16: C = 384 on the one-wave-per-SIMD kernel instead of the eight-wave one
+    out_mode &= 15;
     if (M < 1 || !xn || !x || !W1 || !b1 || !W2 || !b2 || (out_mode && !out_xn)) return DSG_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     void *xb = nullptr, *w1b = nullptr, *w2b = nullptr, *ob = nullptr;
@@ -1925,6 +1928,7 @@ int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const floa
     BxMlp g;
     g.xn = xb; g.x = x; g.W1 = w1b; g.b1 = b1; g.W2 = w2b; g.b2 = b2; g.M = M; g.C = C;
     if (out_mode) { g.xn_out = ob; g.out_mode = out_mode; }
+    g.wide8 = narrow384 ? 0 : 1;
     if (mod) { g.mod_aff = mod; g.mod_ld = 0; g.mod_off = 0; g.mod_T = 1; }
     const bool ok = launch_mlp_bx(g, s);
     if (ok && out_mode) launch_bf16_to_f32(ob, out_xn, (size_t)M * C, s);

@@ -93,6 +93,7 @@ struct BxMlp {
     void *xn_out = nullptr; int out_mode = 0;
     const float *mod_aff = nullptr; int mod_ld = 0, mod_off = 0, mod_T = 1;
     int M = 0, C = 0;
+    int wide8 = 1;   // C = 384: the eight-wave kernel (0: mlp_bx_kernel<384>, one wave per SIMD)
 };
 bool launch_mlp_bx(const BxMlp &g, hipStream_t s);
 // x fp32 [B*T, C] -> optional in-place modulate+SiLU (aff != null) -> xn bf16: LayerNorm without affine (ln) or the plain copy

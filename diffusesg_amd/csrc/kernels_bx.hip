@@ -598,6 +598,197 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same fused MLP at C = 384 on EIGHT waves (two per SIMD).  One wave with a whole 384-wide row needs 96 + 192 registers for Xn and
+// O^T alone, runs one wave per SIMD and loses to the pair of GEMMs (mlp_bx_kernel<384>: 306 us against 110 + 149 at COCO level 2); here a
+// PAIR of waves shares 32 tokens:
+//   * fc1 is split along K: wave kh of the pair keeps channels 192 kh .. + 191 of the normalised rows (48 registers) and forms the
+//     partial products of BOTH 32-wide hidden chunks of a chunk pair; the partial sum of the partner's chunk goes to the partner through
+//     LDS (fp32), the own chunk is completed, + b1, GELU, bf16 -- every hidden unit passes through GELU once;
+//   * the two bf16 hidden tiles are exchanged through LDS, and fc2 is split along N: wave kh accumulates output channels
+//     192 kh .. + 191 (96 registers) over both chunks;
+//   * the weights stream through ONE LDS stage per matrix (W1 pair 64 x 384, W2 pair 384 x 64), refilled from registers in the phase in
+//     which the other matrix is being read (W2 during fc1, W1 during GELU / fc2); three barriers per chunk pair.
+// The epilogue is mlp_bx_kernel's with the LayerNorm statistics added across the pair.
+// -------------------------------------------------------------------------------------------------
+template <int MOD>
+__global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
+    constexpr int C = 384, H = 4 * C, NPAIR = H / 64, CT = 6;
+    constexpr int LD1 = C + 8, LD2 = 64 + 8, TLD = 104;
+    constexpr int W1S = 64 * LD1, W2S = C * LD2, B1S = 2 * 64 * 2, X1S = 8 * 64 * 16 * 2, X2S = 8 * 64 * 16;   // bf16 elements
+    static_assert(8 * 32 * TLD <= W1S + W2S, "the output transposition reuses the weight stages");
+    __shared__ __attribute__((aligned(16))) __bf16 lds[W1S + W2S + B1S + X1S + X2S];
+    __bf16 *w1s = lds, *w2s = lds + W1S;
+    float *b1s = reinterpret_cast<float *>(lds + W1S + W2S);                    // [2][64]
+    f32x4 *xch1 = reinterpret_cast<f32x4 *>(lds + W1S + W2S + B1S);             // [4 quads][8 waves][64 lanes]
+    u32x4 *xch2 = reinterpret_cast<u32x4 *>(lds + W1S + W2S + B1S + X1S);       // [2 k-steps][8 waves][64 lanes]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lrow = lane & 31, lhalf = lane >> 5;
+    const int ts = wave >> 1, kh = wave & 1;
+    const int m0 = blockIdx.x * 128;
+    const int rows = min(128, g.M - m0);
+    const unsigned mrow = (unsigned)(32 * ts + lrow);
+    const __bf16 *W1 = static_cast<const __bf16 *>(g.W1), *W2 = static_cast<const __bf16 *>(g.W2);
+    const rsrc_t rsW1 = make_rsrc(W1, (unsigned)H * C * 2u), rsW2 = make_rsrc(W2, (unsigned)C * H * 2u);
+    // staging pieces of this thread: q = tid + 512 p, p < 6.  W1 pair: row q / 48, 16-byte column q % 48; W2 pair: row q / 8, piece q % 8
+    u32x4 st[6];
+    float s_b1 = 0.f;
+    auto issue_w1 = [&](int cp) {
+        if (tid < 64) s_b1 = g.b1[64 * cp + tid];
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            const int q = tid + 512 * p;
+            st[p] = buf_load_u4(rsW1, ((unsigned)(64 * cp + q / 48) * C + 8u * (q % 48)) * 2u, 0u);
+        }
+    };
+    auto write_w1 = [&](int cp) {
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            const int q = tid + 512 * p;
+            *reinterpret_cast<u32x4 *>(w1s + (q / 48) * LD1 + 8 * (q % 48)) = st[p];
+        }
+        if (tid < 64) b1s[64 * (cp & 1) + tid] = s_b1;
+    };
+    auto issue_w2 = [&](int cp) {
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            const int q = tid + 512 * p;
+            st[p] = buf_load_u4(rsW2, ((unsigned)(q / 8) * H + 64u * cp + 8u * (q % 8)) * 2u, 0u);
+        }
+    };
+    auto write_w2 = [&]() {
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            const int q = tid + 512 * p, c = q & 7, c4 = c & 3;
+            // hidden units 8 c4 .. + 7 of chunk c >> 2 go to positions 16 (c4 >> 1) + 8 (e >> 2) + 4 (c4 & 1) + (e & 3) of the chunk
+            __bf16 *dst = w2s + (q >> 3) * LD2 + 32 * (c >> 2) + 16 * (c4 >> 1) + 4 * (c4 & 1);
+            *reinterpret_cast<u32x2 *>(dst) = (u32x2){st[p][0], st[p][1]};
+            *reinterpret_cast<u32x2 *>(dst + 8) = (u32x2){st[p][2], st[p][3]};
+        }
+    };
+    issue_w1(0);
+    // the wave's half of the normalised rows: lane (token, half) holds channels 192 kh + 16 s + 8 half .. + 7 of k-step s
+    const rsrc_t rsXn = make_rsrc(static_cast<const __bf16 *>(g.xn) + (size_t)m0 * C, (unsigned)rows * C * 2u);
+    bf16x8 xf[12];
+#pragma unroll
+    for (int s = 0; s < 12; s++) xf[s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsXn, (mrow * C + 192u * kh + 16u * s + 8u * lhalf) * 2u, 0u));
+    f32x16 oacc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
+    write_w1(0);
+    issue_w2(0);
+    const __bf16 *w1own = w1s + (32 * kh + lrow) * LD1 + 192 * kh + 8 * lhalf, *w1oth = w1s + (32 * (1 - kh) + lrow) * LD1 + 192 * kh + 8 * lhalf;
+    const __bf16 *w2own = w2s + (192 * kh + lrow) * LD2 + 32 * kh + 8 * lhalf, *w2oth = w2s + (192 * kh + lrow) * LD2 + 32 * (1 - kh) + 8 * lhalf;
+    for (int cp = 0; cp < NPAIR; cp++) {
+        __syncthreads();                       // B1: fc2 of the previous pair is done (W2 stage free), W1 stage / b1 of this pair visible
+        write_w2();
+        if (cp + 1 < NPAIR) issue_w1(cp + 1);
+        f32x16 ho, hx;                         // partial products of the own chunk (32 kh ..) and of the partner's chunk
+#pragma unroll
+        for (int r = 0; r < 16; r++) { ho[r] = 0.f; hx[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 12; s++) {
+            ho = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w1own + 16 * s), xf[s], ho, 0, 0, 0);
+            hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w1oth + 16 * s), xf[s], hx, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) xch1[(q * 8 + wave) * 64 + lane] = (f32x4){hx[4 * q], hx[4 * q + 1], hx[4 * q + 2], hx[4 * q + 3]};
+        __syncthreads();                       // Bx: partial sums visible; nobody reads the W1 stage any more
+        if (cp + 1 < NPAIR) { write_w1(cp + 1); issue_w2(cp + 1); }
+        u32x4 hf[2];
+        {
+            const float *bb = b1s + 64 * (cp & 1) + 32 * kh + 4 * lhalf;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 pp = xch1[(q * 8 + (wave ^ 1)) * 64 + lane], b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * q);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = gelu_f(ho[4 * q + e] + pp[e] + b4[e]);
+                hf[q >> 1][2 * (q & 1)] = pack_bf16(v[0], v[1]);
+                hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(v[2], v[3]);
+            }
+        }
+        xch2[(0 * 8 + wave) * 64 + lane] = hf[0];
+        xch2[(1 * 8 + wave) * 64 + lane] = hf[1];
+        __syncthreads();                       // B2: hidden tiles visible, W2 stage of this pair visible
+        u32x4 hp[2];
+        hp[0] = xch2[(0 * 8 + (wave ^ 1)) * 64 + lane];
+        hp[1] = xch2[(1 * 8 + (wave ^ 1)) * 64 + lane];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; s2++) {
+                oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w2own + 32 * ct * LD2 + 16 * s2),
+                                                                   __builtin_bit_cast(bf16x8, hf[s2]), oacc[ct], 0, 0, 0);
+                oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w2oth + 32 * ct * LD2 + 16 * s2),
+                                                                   __builtin_bit_cast(bf16x8, hp[s2]), oacc[ct], 0, 0, 0);
+            }
+    }
+    __syncthreads();                           // the stages are free: output transposition, row statistics
+    // ---- epilogue: lane (token, half) holds channels 192 kh + 32 ct + 8 q + 4 half + {0..3} in oacc[ct][4 q ..]
+    const rsrc_t rsX = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
+    __bf16 *xo = static_cast<__bf16 *>(g.xn_out);
+    const rsrc_t rsO = make_rsrc(xo ? xo + (size_t)m0 * C : nullptr, xo ? (unsigned)rows * C * 2u : 0u);
+    const float *aff_row = nullptr;
+    if (MOD != 0) aff_row = g.mod_aff + (size_t)(MOD == 2 ? min(m0 + (int)mrow, g.M - 1) / g.mod_T : 0) * g.mod_ld + g.mod_off;
+    __bf16 *T = lds + wave * 32 * TLD;
+    f32x2 *part = reinterpret_cast<f32x2 *>(xch1);   // [128 rows][2]
+    auto tflush = [&](int half96) {               // the wave's 32 x 96 tile -> row-contiguous 16-byte stores (as gemm_bx_kernel)
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = lane + 64 * k, r = i / 12, pc = i - 12 * r;
+            const u32x4 d = *reinterpret_cast<const u32x4 *>(T + r * TLD + 8 * pc);
+            buf_store_u4(d, rsO, ((unsigned)(32 * ts + r) * C + (unsigned)(192 * kh + 96 * half96 + 8 * pc)) * 2u, 0u);
+        }
+    };
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        f32x4 rr[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) rr[q] = buf_load4(rsX, (mrow * C + (unsigned)(192 * kh + 32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = 192 * kh + 32 * ct + 8 * q + 4 * lhalf;
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.b2 + c);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = oacc[ct][4 * q + e] + b4[e] + rr[q][e];
+            if (MOD != 0) {
+                const f32x4 scl = *reinterpret_cast<const f32x4 *>(aff_row + c), sft = *reinterpret_cast<const f32x4 *>(aff_row + C + c);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = silu_exact(fmaf(v[e], scl[e] + 1.0f, sft[e]));
+            }
+            buf_store4(v, rsX, (mrow * C + (unsigned)c) * 4u, 0u);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { ssum += v[e]; ssq = fmaf(v[e], v[e], ssq); oacc[ct][4 * q + e] = v[e]; }
+            if (g.out_mode == 2) *reinterpret_cast<u32x2 *>(T + lrow * TLD + 32 * (ct % 3) + 8 * q + 4 * lhalf) = pack_bf16x4(v);
+        }
+        if (g.out_mode == 2 && ct % 3 == 2) tflush(ct / 3);
+    }
+    if (g.out_mode == 1) {
+        ssum += __shfl_xor(ssum, 32, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (lhalf == 0) part[mrow * 2 + kh] = (f32x2){ssum, ssq};
+        __syncthreads();
+        const f32x2 p0 = part[mrow * 2], p1 = part[mrow * 2 + 1];
+        const float sm = p0[0] + p1[0], sq = p0[1] + p1[1];
+        const float mean = sm * (1.0f / C), rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * (1.0f / C)), 0.f) + LN_EPS), nmr = -mean * rstd;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = fmaf(oacc[ct][4 * q + e], rstd, nmr);
+                *reinterpret_cast<u32x2 *>(T + lrow * TLD + 32 * (ct % 3) + 8 * q + 4 * lhalf) = pack_bf16x4(v);
+            }
+            if (ct % 3 == 2) tflush(ct / 3);
+        }
+    }
+}
+
 bool launch_mlp_bx(const BxMlp &g, hipStream_t s) {
     if (!g.xn || !g.x || !g.W1 || !g.b1 || !g.W2 || !g.b2 || g.M < 1 || (g.out_mode && !g.xn_out)) return false;
     const dim3 grid((g.M + 127) / 128), block(256);
@@ -611,7 +802,16 @@ bool launch_mlp_bx(const BxMlp &g, hipStream_t s) {
     switch (g.C) {
         case 96: MLP_LAUNCH(96); break;
         case 192: MLP_LAUNCH(192); break;
-        case 384: MLP_LAUNCH(384); break;
+        case 384:
+            if (g.wide8) {   // eight waves per 128 tokens (mlp384_bx_kernel)
+                const dim3 block8(512);
+                if (mod == 0) hipLaunchKernelGGL((mlp384_bx_kernel<0>), grid, block8, 0, s, g);
+                else if (mod == 1) hipLaunchKernelGGL((mlp384_bx_kernel<1>), grid, block8, 0, s, g);
+                else hipLaunchKernelGGL((mlp384_bx_kernel<2>), grid, block8, 0, s, g);
+            } else {
+                MLP_LAUNCH(384);
+            }
+            break;
         default: return false;
     }
 #undef MLP_LAUNCH

@@ -172,7 +172,7 @@ def test_qkv_attn_bx_vs_torch(B, res, ws, shift, heads):
 
 
 @pytest.mark.parametrize("M,C,mod,out_mode", [(51200, 384, 1, 1), (20037, 192, 1, 1), (65541, 96, 0, 2), (300, 96, 1, 1), (4096, 384, 0, 0),
-                                               (1000, 192, 0, 2)])
+                                               (1000, 192, 0, 2), (20037, 384, 0, 2), (51200, 384, 1, 1 + 16), (4100, 384, 0, 2 + 16)])
 def test_mlp_bx_whole_matrix(M, C, mod, out_mode):
     """the fused fc1 -> GELU -> fc2 -> + residual -> [modulate] -> [LayerNorm | copy] kernel at its three widths against fp64 on the
     bf16-rounded operands, with the hidden activations rounded to bf16 between the two products as the kernel does"""
@@ -188,8 +188,10 @@ def test_mlp_bx_whole_matrix(M, C, mod, out_mode):
     aff = (torch.randn(2 * C, device="cuda", generator=gen) * 0.5) if mod else None
     x_io = x.clone()
     out_xn = torch.full((M, C), float("nan"), device="cuda")
+    # C = 384: the eight-wave kernel (pairs of waves share 32 tokens); out_mode + 16 selects the one-wave-per-SIMD kernel instead
     rc = lib.dsg_debug_mlp_bx(M, C, _p(xn), _p(x_io), _p(W1), _p(b1), _p(W2), _p(b2), _p(aff), out_mode, _p(out_xn) if out_mode else None, 0, None, None)
     assert rc == 0
+    out_mode &= 15
     hid = torch.nn.functional.gelu(_bf(xn).double() @ _bf(W1).double().t() + b1.double())
     v = _bf(hid.float()).double() @ _bf(W2).double().t() + b2.double() + x.double()
     if aff is not None:

@@ -521,7 +521,7 @@ def rms_rel(a, ref):
 
 
 @pytest.mark.parametrize("name", ["tiny", "small", "vg", "coco"])
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [1, 2, 0])
 @pytest.mark.parametrize("pipe", [1, 0])
 def test_bf16_gemm_mode_vs_reference(name, fused, pipe):
     """opt-in precision mode (BASELINE config 5): bf16-MFMA GEMMs, fp32 accumulate -- looser, stated tolerance.
@@ -535,11 +535,16 @@ def test_bf16_gemm_mode_vs_reference(name, fused, pipe):
     h.set_option("gemm_bf16", 1)
     h.set_option("bf16_pipe", pipe)
     assert h.get_option("bf16_pipe") == pipe
-    # the fused MLP kernel: at every width it covers when the other kernels are "fused", not at all otherwise (the GEMM pair)
-    h.set_option("bf16_mlp", 2 if fused else 0)
-    assert h.get_option("bf16_mlp") == ((2 if fused else 0) if pipe else 0)
+    # fused = 1: the pipeline's defaults (QKV + attention in one kernel, fc1-GELU-fc2 in one kernel at every width it covers, eight
+    # waves at C = 384); 2: the separate QKV GEMM + attention kernel and the four-wave MLP kernel at C = 384; 0: GEMM pairs everywhere
+    if pipe == 0 and fused == 2:
+        pytest.skip("the kernel variants of fused = 2 belong to the block pipeline")
+    h.set_option("bf16_mlp", fused)
+    h.set_option("bf16_qkv_attn", 1 if fused == 1 else 0)
+    assert h.get_option("bf16_mlp") == (fused if pipe else 0)
+    assert h.get_option("bf16_qkv_attn") == (1 if (pipe and fused == 1) else 0)
     for opt in ("fused_attn", "fused_mlp", "fused_readout", "fused_patch_embed"):
-        h.set_option(opt, fused)
+        h.set_option(opt, 1 if fused else 0)
     oa, on = net(T(adj), T(node), T(flags), T(Y.FWD_C_NOISE), T(sc_adj), T(sc_node))
     ea = assert_close(oa.cpu().numpy(), g["sc_adj_out"], BF16_MAX_RTOL, f"{name} adj (bf16 GEMMs)")
     en = assert_close(on.cpu().numpy(), g["sc_node_out"], BF16_MAX_RTOL, f"{name} node (bf16 GEMMs)")

@@ -114,7 +114,8 @@ if __name__ == "__main__":
     gemm("merge L1->L2 (skip, mod, LN)", M2, 384, 768, c32=1, mod=1, ln=1, c2=1)
     gemm("pre_linear L2->L1 (fp32 out)", M2, 768, 768, c32=1, cb=0)
     gemm("post_linear L1 (mod, LN)", M1, 192, 192, c32=1, mod=1, ln=1)
-    mlp("L2 fused MLP (mod, LN)", M2, 384)
+    mlp("L2 fused MLP (mod, LN), 8 waves", M2, 384)
+    mlp("L2 fused MLP (mod, LN), 4 waves", M2, 384, out_mode=1 + 16)
     mlp("L1 fused MLP (mod, LN)", M1, 192)
     mlp("L0 fused MLP (copy)", M0, 96, mod=0, out_mode=2)
     if only == "gemm":
