@@ -127,6 +127,7 @@ struct dsg_handle_s {
     bool opt_gemm_bf16 = false;                                   // bf16-MFMA GEMMs (fp32 accumulate), opt-in precision mode
     int opt_bf16_act = 2;                                         // in that mode: 1 hidden / attention-output tensors stored as bf16 (bit-identical), 2 also qkv
     bool opt_bf16_pipe = true;                                    // in that mode: the bf16 block pipeline of kernels_bx.hip (0: round 2's kernels_lp.hip path)
+    bool opt_bf16_proj_mlp = true;                                // in that pipeline: proj + residual + LayerNorm-2 in front of the fused MLP kernel (0: the proj GEMM)
     bool opt_bf16_qkv_attn = true;                                // in that pipeline: QKV projection + window attention in one kernel (0: GEMM + attn_bx_kernel through a bf16 qkv tensor)
     int opt_bf16_mlp = 1;                                         // in that pipeline: the fused fc1-GELU-fc2 kernels (0: two GEMMs with a bf16 hidden tensor; 1: C <= 192 on 4 waves, C = 384 on 8; 2: C = 384 on the 4-wave kernel too; 3: GEMM pair at C = 384)
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
@@ -1130,21 +1131,27 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
         ProfScope ps_(h, s, PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, "attn_bx");
         if (!launch_attn_bx(w->qkv, b.biasT, w->att, B, wg, s)) launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s, true, true);
     }
-    g = BxGemm();
-    g.A = w->att; g.lda = C; g.K = C; g.M = M; g.N = C;
-    g.W = bf16_of(h, WT(h, p + ".attn.proj.weight")); g.bias = WT(h, p + ".attn.proj.bias");
-    g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
+    // the fused MLP kernel can take the proj linear, the residual and LayerNorm-2 in front (x + proj(att) never goes to HBM)
+    const bool mlp_fused = h->opt_bf16_mlp && h->cfg.mlp_ratio == 4 && (C == 96 || C == 192 || (C == 384 && h->opt_bf16_mlp != 3));
+    const bool proj_in_mlp = mlp_fused && h->opt_bf16_proj_mlp && h->taps.empty() && (C == 96 || C == 192 || (C == 384 && h->opt_bf16_mlp == 1));
     const bool full = bx_full_row(C);
-    if (full) { g.ln_out = 1; g.Cb = w->xn; g.ldcb = C; }   // LayerNorm-2 of x + proj(...) (gamma / beta folded into fc1_wf / fc1_bf)
-    P_BX(g, "proj");
-    if (!full) P_KERN(PK_ROW, 0.0, launch_ln_bx(w->x, nullptr, 0, 0, w->xn, B, T, C, true, s));
+    if (!proj_in_mlp) {
+        g = BxGemm();
+        g.A = w->att; g.lda = C; g.K = C; g.M = M; g.N = C;
+        g.W = bf16_of(h, WT(h, p + ".attn.proj.weight")); g.bias = WT(h, p + ".attn.proj.bias");
+        g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;
+        if (full) { g.ln_out = 1; g.Cb = w->xn; g.ldcb = C; }   // LayerNorm-2 of x + proj(...) (gamma / beta folded into fc1_wf / fc1_bf)
+        P_BX(g, "proj");
+        if (!full) P_KERN(PK_ROW, 0.0, launch_ln_bx(w->x, nullptr, 0, 0, w->xn, B, T, C, true, s));
+    }
     // fc1 -> GELU -> fc2 -> + residual (-> the next block's modulate / LayerNorm-1) in one kernel, no hidden tensor: at C = 96 / 192,
     // where the pair of GEMMs is bound by the hidden tensor's HBM round trip (measured at COCO B = 512, tools/bx_bench.py: 324 us
     // against 302 + 325 at C = 96, 270 against 193 + 196 at C = 192).  At C = 384 the fused kernel needs 230 + 192 registers, runs one
     // wave per SIMD and is slower than the two GEMMs (312 us against 115 + 156): option value 2 forces it there too (tests).
-    if (h->opt_bf16_mlp && h->cfg.mlp_ratio == 4 && (C == 96 || C == 192 || (C == 384 && h->opt_bf16_mlp != 3))) {
+    if (mlp_fused) {
         BxMlp m;
         m.wide8 = h->opt_bf16_mlp == 2 ? 0 : 1;
+        if (proj_in_mlp) { m.att = w->att; m.Wp = bf16_of(h, WT(h, p + ".attn.proj.weight")); m.bp = WT(h, p + ".attn.proj.bias"); }
         m.xn = w->xn; m.x = w->x; m.W1 = bf16_of(h, b.fc1_wf); m.b1 = b.fc1_bf;
         m.W2 = bf16_of(h, WT(h, p + ".mlp.fc2.weight")); m.b2 = WT(h, p + ".mlp.fc2.bias"); m.M = M; m.C = C;
         BxState out = BX_RAW;
@@ -1152,7 +1159,7 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
             m.mod_aff = w->aff; m.mod_ld = w->aff_ld; m.mod_off = next->aff_off; m.mod_T = next->res * next->res;
             m.xn_out = w->xn; m.out_mode = 1; out = BX_READY;
         } else if (!next && want_copy) { m.xn_out = w->xn; m.out_mode = 2; }
-        ProfScope ps_(h, s, PK_FUSED, 4.0 * (double)M * (double)C * (double)Hd, "mlp_bx");
+        ProfScope ps_(h, s, PK_FUSED, 4.0 * (double)M * (double)C * (double)Hd + (proj_in_mlp ? 2.0 * (double)M * C * C : 0.0), proj_in_mlp ? "proj_mlp_bx" : "mlp_bx");
         if (!launch_mlp_bx(m, s)) { fprintf(stderr, "dsg: mlp_bx: shape not covered (M=%d C=%d)\n", M, C); abort(); }
         return out;
     }
@@ -1520,6 +1527,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "bf16_pipe") h->opt_bf16_pipe = value != 0;
     else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (n == "bf16_qkv_attn") h->opt_bf16_qkv_attn = value != 0;
+    else if (n == "bf16_proj_mlp") h->opt_bf16_proj_mlp = value != 0;
     else if (n == "fused_merge") { h->opt_fused_merge = value != 0; h->opt_fused_merge_small = value > 1; }   // 2: at every size
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
@@ -1549,6 +1557,7 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "bf16_pipe") *value = bx_on(h);   // the bf16 block pipeline runs (bf16 mode only)
     else if (n == "bf16_mlp") *value = bx_on(h) ? h->opt_bf16_mlp : 0;
     else if (n == "bf16_qkv_attn") *value = (bx_on(h) && h->opt_bf16_qkv_attn) ? 1 : 0;
+    else if (n == "bf16_proj_mlp") *value = (bx_on(h) && h->opt_bf16_mlp && h->opt_bf16_proj_mlp) ? 1 : 0;
     else if (n == "fused_merge") *value = h->opt_fused_merge ? (h->opt_fused_merge_small ? 2 : 1) : 0;
     else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
     else if (n == "gemm_split") *value = h->opt_gemm_split;
@@ -1929,6 +1938,32 @@ int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const floa
     g.xn = xb; g.x = x; g.W1 = w1b; g.b1 = b1; g.W2 = w2b; g.b2 = b2; g.M = M; g.C = C;
     if (out_mode) { g.xn_out = ob; g.out_mode = out_mode; }
     g.wide8 = narrow384 ? 0 : 1;
+    if (mod) { g.mod_aff = mod; g.mod_ld = 0; g.mod_off = 0; g.mod_T = 1; }
+    const bool ok = launch_mlp_bx(g, s);
+    if (ok && out_mode) launch_bf16_to_f32(ob, out_xn, (size_t)M * C, s);
+    if (ok && time_iters > 0 && out_ms) *out_ms = time_launches(s, time_iters, [&]() { (void)launch_mlp_bx(g, s); });   // (x keeps accumulating: timing only)
+    const hipError_t e = hipStreamSynchronize(s);
+    cleanup();
+    if (!ok) return DSG_ERR_INVALID;
+    return (e == hipSuccess && hipGetLastError() == hipSuccess) ? DSG_OK : DSG_ERR_HIP;
+}
+
+int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const float *Wp, const float *bp, const float *W1, const float *b1,
+                         const float *W2, const float *b2, const float *mod, int32_t out_mode, float *out_xn, int32_t time_iters, float *out_ms,
+                         void *stream) {
+    if (M < 1 || !att || !x || !Wp || !bp || !W1 || !b1 || !W2 || !b2 || (out_mode && !out_xn)) return DSG_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    void *ab = nullptr, *wpb = nullptr, *w1b = nullptr, *w2b = nullptr, *ob = nullptr;
+    auto cleanup = [&]() { (void)hipFree(ab); (void)hipFree(wpb); (void)hipFree(w1b); (void)hipFree(w2b); (void)hipFree(ob); };
+    if (hipMalloc(&ab, (size_t)M * C * 2) != hipSuccess || hipMalloc(&wpb, (size_t)C * C * 2) != hipSuccess || hipMalloc(&w1b, (size_t)4 * C * C * 2) != hipSuccess ||
+        hipMalloc(&w2b, (size_t)4 * C * C * 2) != hipSuccess || hipMalloc(&ob, (size_t)M * C * 2) != hipSuccess) { cleanup(); return DSG_ERR_HIP; }
+    launch_f32_to_bf16(att, ab, (size_t)M * C, s);
+    launch_f32_to_bf16(Wp, wpb, (size_t)C * C, s);
+    launch_f32_to_bf16(W1, w1b, (size_t)4 * C * C, s);
+    launch_f32_to_bf16(W2, w2b, (size_t)4 * C * C, s);
+    BxMlp g;
+    g.att = ab; g.Wp = wpb; g.bp = bp; g.x = x; g.W1 = w1b; g.b1 = b1; g.W2 = w2b; g.b2 = b2; g.M = M; g.C = C;
+    if (out_mode) { g.xn_out = ob; g.out_mode = out_mode; }
     if (mod) { g.mod_aff = mod; g.mod_ld = 0; g.mod_off = 0; g.mod_T = 1; }
     const bool ok = launch_mlp_bx(g, s);
     if (ok && out_mode) launch_bf16_to_f32(ob, out_xn, (size_t)M * C, s);

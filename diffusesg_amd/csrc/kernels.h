@@ -94,6 +94,8 @@ struct BxMlp {
     const float *mod_aff = nullptr; int mod_ld = 0, mod_off = 0, mod_T = 1;
     int M = 0, C = 0;
     int wide8 = 1;   // C = 384: the eight-wave kernel (0: mlp_bx_kernel<384>, one wave per SIMD)
+    // the attention half's tail in front (att != null; xn is then unused): x <- x + att Wp^T + bp first, its LayerNorm feeds fc1
+    const void *att = nullptr, *Wp = nullptr; const float *bp = nullptr;
 };
 bool launch_mlp_bx(const BxMlp &g, hipStream_t s);
 // x fp32 [B*T, C] -> optional in-place modulate+SiLU (aff != null) -> xn bf16: LayerNorm without affine (ln) or the plain copy

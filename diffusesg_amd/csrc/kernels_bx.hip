@@ -471,7 +471,12 @@ bool launch_gemm_bx(const BxGemm &g, hipStream_t s) {
 //     modulate+SiLU and the LayerNorm of the stored row are lane-local: the same epilogue options as gemm_bx at any width.
 // Registers: C/4 for Xn, C/2 for O^T (+ staging): C = 384 runs one wave per SIMD (512 registers), C = 192 two, C = 96 three.
 // -------------------------------------------------------------------------------------------------
-template <int C, int MOD>
+// PROJ: the attention half's tail rides in front -- x1 = x + proj(att) + bp is formed on the matrix pipe FIRST (att [M, C] bf16 as the B
+// operand, the proj weight streamed through the same LDS stage in CT chunks of 32 output channels) and lands in the O^T accumulators,
+// i.e. it is the initial value of the fc2 accumulation: x1 never goes to HBM (unfused: proj writes it, this kernel re-reads it), neither
+// does LayerNorm-2 -- its statistics are lane-local sums of the accumulators and the normalised row, packed pairwise to bf16 AS THE
+// REGISTERS STAND, is fc1's B operand (k order 16 s + 8 (j >> 2) + 4 half + (j & 3); the W1 chunk is laid out in LDS in that order).
+template <int C, int MOD, bool PROJ = false>
 __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_bx_kernel(BxMlp g) {
     constexpr int H = 4 * C, NCH = H / 32, KS = C / 16, CT = C / 32;
     constexpr int LD1 = C + 8, LD2 = 40;                       // LDS row strides (bf16) of the W1 chunk [32][C] and the W2 chunk [C][32]
@@ -506,7 +511,14 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
         for (int p = 0; p < NP; p++) {
             const int q = tid + 256 * p;
             if (q < 4 * C) {
-                *reinterpret_cast<u32x4 *>(w1s + (q / (C / 8)) * LD1 + 8 * (q % (C / 8))) = s1[p];
+                if (PROJ) {   // channels 8 c8 .. + 7 of a row go to positions 16 (c8 >> 1) + 8 (e >> 2) + 4 (c8 & 1) + (e & 3)
+                    const int c8 = q % (C / 8);
+                    __bf16 *d1 = w1s + (q / (C / 8)) * LD1 + 16 * (c8 >> 1) + 4 * (c8 & 1);
+                    *reinterpret_cast<u32x2 *>(d1) = (u32x2){s1[p][0], s1[p][1]};
+                    *reinterpret_cast<u32x2 *>(d1 + 8) = (u32x2){s1[p][2], s1[p][3]};
+                } else {
+                    *reinterpret_cast<u32x4 *>(w1s + (q / (C / 8)) * LD1 + 8 * (q % (C / 8))) = s1[p];
+                }
                 // the 8 hidden units 8 c .. 8 c + 7 of the chunk go to positions 16 s + 8 (e >> 2) + 4 (c & 1) + (e & 3), s = c >> 1
                 const int c = q % 4;
                 __bf16 *dst = w2s + (q / 4) * LD2 + 16 * (c >> 1) + 4 * (c & 1);
@@ -516,9 +528,27 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
         }
         if (tid < 32) b1s[tid] = s_b1;
     };
-    issue(0);
-    // the wave's normalised rows: lane (token, half) holds channels 16 s + 8 half .. + 7 of k-step s
-    const rsrc_t rsXn = make_rsrc(static_cast<const __bf16 *>(g.xn) + (size_t)m0 * C, (unsigned)rows * C * 2u);
+    // (PROJ) chunk ct of the proj weight: rows 32 ct .. + 31 of Wp [C, C], natural column order, through s1 and the W1 half of a stage buffer
+    const rsrc_t rsWp = make_rsrc(PROJ ? static_cast<const __bf16 *>(g.Wp) : nullptr, PROJ ? (unsigned)C * C * 2u : 0u);
+    auto issue_p = [&](int ct) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int q = tid + 256 * p;
+            s1[p] = buf_load_u4(rsWp, q < 4 * C ? ((unsigned)(32 * ct + q / (C / 8)) * C + 8u * (q % (C / 8))) * 2u : 0x7fffffffu, 0u);
+        }
+    };
+    auto write_p = [&](int buf) {
+        __bf16 *w1s = lds + buf * STAGE;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int q = tid + 256 * p;
+            if (q < 4 * C) *reinterpret_cast<u32x4 *>(w1s + (q / (C / 8)) * LD1 + 8 * (q % (C / 8))) = s1[p];
+        }
+    };
+    if (PROJ) issue_p(0); else issue(0);
+    // the wave's B operand rows: lane (token, half) holds channels 16 s + 8 half .. + 7 of k-step s -- of the normalised rows, or (PROJ)
+    // of the attention output
+    const rsrc_t rsXn = make_rsrc(static_cast<const __bf16 *>(PROJ ? g.att : g.xn) + (size_t)m0 * C, (unsigned)rows * C * 2u);
     bf16x8 xf[KS];
 #pragma unroll
     for (int s = 0; s < KS; s++) xf[s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsXn, (mrow * C + 16u * s + 8u * lhalf) * 2u, 0u));
@@ -527,10 +557,54 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
     for (int ct = 0; ct < CT; ct++)
 #pragma unroll
         for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
-    write(0);
-    __syncthreads();
+    if (PROJ) {
+        write_p(0);
+        __syncthreads();
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            if (ct + 1 < CT) issue_p(ct + 1); else issue(0);
+            const __bf16 *wps = lds + (ct & 1) * STAGE;
+#pragma unroll
+            for (int s = 0; s < KS; s++)
+                oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(wps + lrow * LD1 + 16 * s + 8 * lhalf), xf[s], oacc[ct], 0, 0, 0);
+            if (ct + 1 < CT) write_p((ct + 1) & 1); else write(CT & 1);
+            __syncthreads();
+        }
+        // x1 = x + proj + bp (the shortcut and fc2's initial value), LayerNorm-2 of it -> fc1's B operand
+        const rsrc_t rsXi = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            f32x4 rr[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) rr[q] = buf_load4(rsXi, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.bp + 32 * ct + 8 * q + 4 * lhalf);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float v = oacc[ct][4 * q + e] + b4[e] + rr[q][e];
+                    oacc[ct][4 * q + e] = v; sm += v; sq = fmaf(v, v, sq);
+                }
+            }
+        }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        const float mean = sm * (1.0f / C), rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * (1.0f / C)), 0.f) + LN_EPS), nmr = -mean * rstd;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            u32x4 pk;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                pk[j] = pack_bf16(fmaf(oacc[s >> 1][8 * (s & 1) + 2 * j], rstd, nmr), fmaf(oacc[s >> 1][8 * (s & 1) + 2 * j + 1], rstd, nmr));
+            xf[s] = __builtin_bit_cast(bf16x8, pk);
+        }
+    } else {
+        write(0);
+        __syncthreads();
+    }
     for (int hc = 0; hc < NCH; hc++) {
-        const int cur = hc & 1;
+        const int cur = (hc + (PROJ ? CT : 0)) & 1;
         if (hc + 1 < NCH) issue(hc + 1);
         const __bf16 *w1s = lds + cur * STAGE, *w2s = w1s + 32 * LD1;
         const float *b1s = reinterpret_cast<const float *>(w2s + C * LD2);
@@ -563,7 +637,8 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
     for (int ct = 0; ct < CT; ct++) {
         f32x4 rr[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) rr[q] = buf_load4(rsX, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+        for (int q = 0; q < 4; q++)
+            rr[q] = PROJ ? (f32x4){0.f, 0.f, 0.f, 0.f} : buf_load4(rsX, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);   // (PROJ: x1 is in oacc)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int c = 32 * ct + 8 * q + 4 * lhalf;
@@ -611,7 +686,10 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
 //     which the other matrix is being read (W2 during fc1, W1 during GELU / fc2); three barriers per chunk pair.
 // The epilogue is mlp_bx_kernel's with the LayerNorm statistics added across the pair.
 // -------------------------------------------------------------------------------------------------
-template <int MOD>
+// PROJ (as mlp_bx_kernel): x1 = x + att Wp^T + bp first, split along N like fc2 -- wave kh forms output channels 192 kh .. + 191 of its 32
+// tokens from the whole attention row (96 registers, dead afterwards) -- which are exactly the channels of its K half of fc1 and of its
+// fc2 accumulators: the LayerNorm statistics cross the pair through LDS, nothing else moves.
+template <int MOD, bool PROJ = false>
 __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
     constexpr int C = 384, H = 4 * C, NPAIR = H / 64, CT = 6;
     constexpr int LD1 = C + 8, LD2 = 64 + 8, TLD = 104;
@@ -644,9 +722,32 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
 #pragma unroll
         for (int p = 0; p < 6; p++) {
             const int q = tid + 512 * p;
-            *reinterpret_cast<u32x4 *>(w1s + (q / 48) * LD1 + 8 * (q % 48)) = st[p];
+            if (PROJ) {   // fc1's B operand is the accumulator order: channels 8 c8 .. + 7 -> positions 16 (c8 >> 1) + 8 (e >> 2) + 4 (c8 & 1) + (e & 3)
+                const int c8 = q % 48;
+                __bf16 *d1 = w1s + (q / 48) * LD1 + 16 * (c8 >> 1) + 4 * (c8 & 1);
+                *reinterpret_cast<u32x2 *>(d1) = (u32x2){st[p][0], st[p][1]};
+                *reinterpret_cast<u32x2 *>(d1 + 8) = (u32x2){st[p][2], st[p][3]};
+            } else {
+                *reinterpret_cast<u32x4 *>(w1s + (q / 48) * LD1 + 8 * (q % 48)) = st[p];
+            }
         }
         if (tid < 64) b1s[64 * (cp & 1) + tid] = s_b1;
+    };
+    // (PROJ) stage ct of the proj weight: rows 32 ct .. + 31 (the kh = 0 waves' output channels) and 192 + 32 ct .. + 31 (kh = 1), natural order
+    const rsrc_t rsWp = make_rsrc(PROJ ? static_cast<const __bf16 *>(g.Wp) : nullptr, PROJ ? (unsigned)C * C * 2u : 0u);
+    auto issue_p = [&](int ct) {
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            const int q = tid + 512 * p, r = q / 48;
+            st[p] = buf_load_u4(rsWp, ((unsigned)((r < 32 ? 32 * ct + r : 160 + 32 * ct + r)) * C + 8u * (q % 48)) * 2u, 0u);
+        }
+    };
+    auto write_p = [&]() {
+#pragma unroll
+        for (int p = 0; p < 6; p++) {
+            const int q = tid + 512 * p;
+            *reinterpret_cast<u32x4 *>(w1s + (q / 48) * LD1 + 8 * (q % 48)) = st[p];
+        }
     };
     auto issue_w2 = [&](int cp) {
 #pragma unroll
@@ -665,19 +766,74 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
             *reinterpret_cast<u32x2 *>(dst + 8) = (u32x2){st[p][2], st[p][3]};
         }
     };
-    issue_w1(0);
-    // the wave's half of the normalised rows: lane (token, half) holds channels 192 kh + 16 s + 8 half .. + 7 of k-step s
-    const rsrc_t rsXn = make_rsrc(static_cast<const __bf16 *>(g.xn) + (size_t)m0 * C, (unsigned)rows * C * 2u);
     bf16x8 xf[12];
-#pragma unroll
-    for (int s = 0; s < 12; s++) xf[s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsXn, (mrow * C + 192u * kh + 16u * s + 8u * lhalf) * 2u, 0u));
     f32x16 oacc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ct++)
 #pragma unroll
         for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
-    write_w1(0);
-    issue_w2(0);
+    if (PROJ) {
+        issue_p(0);
+        const rsrc_t rsAt = make_rsrc(static_cast<const __bf16 *>(g.att) + (size_t)m0 * C, (unsigned)rows * C * 2u);
+        bf16x8 af[24];   // the whole attention row of the lane's token: channels 16 s + 8 half .. + 7 of k-step s
+#pragma unroll
+        for (int s = 0; s < 24; s++) af[s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsAt, (mrow * C + 16u * s + 8u * lhalf) * 2u, 0u));
+        const __bf16 *wpf = w1s + (32 * kh + lrow) * LD1 + 8 * lhalf;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            __syncthreads();                   // the previous stage has been read
+            write_p();
+            __syncthreads();
+            if (ct + 1 < CT) issue_p(ct + 1); else issue_w1(0);
+#pragma unroll
+            for (int s = 0; s < 24; s++)
+                oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(wpf + 16 * s), af[s], oacc[ct], 0, 0, 0);
+        }
+        // x1 = x + proj + bp on this wave's 192 channels; LayerNorm-2 statistics across the pair; the normalised values are fc1's B operand
+        const rsrc_t rsXi = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            f32x4 rr[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) rr[q] = buf_load4(rsXi, (mrow * C + (unsigned)(192 * kh + 32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.bp + 192 * kh + 32 * ct + 8 * q + 4 * lhalf);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float v = oacc[ct][4 * q + e] + b4[e] + rr[q][e];
+                    oacc[ct][4 * q + e] = v; sm += v; sq = fmaf(v, v, sq);
+                }
+            }
+        }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        f32x2 *part0 = reinterpret_cast<f32x2 *>(xch1);   // [128 rows][2]
+        if (lhalf == 0) part0[mrow * 2 + kh] = (f32x2){sm, sq};
+        __syncthreads();                       // statistics visible; the last proj stage has been read
+        write_w1(0);
+        issue_w2(0);
+        const f32x2 q0 = part0[mrow * 2], q1 = part0[mrow * 2 + 1];
+        const float tsm = q0[0] + q1[0], tsq = q0[1] + q1[1];
+        const float mean = tsm * (1.0f / C), rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, tsq * (1.0f / C)), 0.f) + LN_EPS), nmr = -mean * rstd;
+#pragma unroll
+        for (int s = 0; s < 12; s++) {
+            u32x4 pk;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                pk[j] = pack_bf16(fmaf(oacc[s >> 1][8 * (s & 1) + 2 * j], rstd, nmr), fmaf(oacc[s >> 1][8 * (s & 1) + 2 * j + 1], rstd, nmr));
+            xf[s] = __builtin_bit_cast(bf16x8, pk);
+        }
+    } else {
+        issue_w1(0);
+        // the wave's half of the normalised rows: lane (token, half) holds channels 192 kh + 16 s + 8 half .. + 7 of k-step s
+        const rsrc_t rsXn = make_rsrc(static_cast<const __bf16 *>(g.xn) + (size_t)m0 * C, (unsigned)rows * C * 2u);
+#pragma unroll
+        for (int s = 0; s < 12; s++) xf[s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsXn, (mrow * C + 192u * kh + 16u * s + 8u * lhalf) * 2u, 0u));
+        write_w1(0);
+        issue_w2(0);
+    }
     const __bf16 *w1own = w1s + (32 * kh + lrow) * LD1 + 192 * kh + 8 * lhalf, *w1oth = w1s + (32 * (1 - kh) + lrow) * LD1 + 192 * kh + 8 * lhalf;
     const __bf16 *w2own = w2s + (192 * kh + lrow) * LD2 + 32 * kh + 8 * lhalf, *w2oth = w2s + (192 * kh + lrow) * LD2 + 32 * (1 - kh) + 8 * lhalf;
     for (int cp = 0; cp < NPAIR; cp++) {
@@ -747,7 +903,8 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
     for (int ct = 0; ct < CT; ct++) {
         f32x4 rr[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) rr[q] = buf_load4(rsX, (mrow * C + (unsigned)(192 * kh + 32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+        for (int q = 0; q < 4; q++)
+            rr[q] = PROJ ? (f32x4){0.f, 0.f, 0.f, 0.f} : buf_load4(rsX, (mrow * C + (unsigned)(192 * kh + 32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);   // (PROJ: x1 is in oacc)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int c = 192 * kh + 32 * ct + 8 * q + 4 * lhalf;
@@ -790,14 +947,22 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
 }
 
 bool launch_mlp_bx(const BxMlp &g, hipStream_t s) {
-    if (!g.xn || !g.x || !g.W1 || !g.b1 || !g.W2 || !g.b2 || g.M < 1 || (g.out_mode && !g.xn_out)) return false;
+    if ((!g.xn && !g.att) || !g.x || !g.W1 || !g.b1 || !g.W2 || !g.b2 || g.M < 1 || (g.out_mode && !g.xn_out)) return false;
     const dim3 grid((g.M + 127) / 128), block(256);
     const int mod = !g.mod_aff ? 0 : (g.mod_ld == 0 ? 1 : 2);
+    const bool proj = g.att != nullptr;
+    if (proj && (!g.Wp || !g.bp)) return false;
 #define MLP_LAUNCH(C_)                                                                                   \
     do {                                                                                                 \
-        if (mod == 0) hipLaunchKernelGGL((mlp_bx_kernel<C_, 0>), grid, block, 0, s, g);                  \
-        else if (mod == 1) hipLaunchKernelGGL((mlp_bx_kernel<C_, 1>), grid, block, 0, s, g);             \
-        else hipLaunchKernelGGL((mlp_bx_kernel<C_, 2>), grid, block, 0, s, g);                           \
+        if (proj) {                                                                                      \
+            if (mod == 0) hipLaunchKernelGGL((mlp_bx_kernel<C_, 0, true>), grid, block, 0, s, g);        \
+            else if (mod == 1) hipLaunchKernelGGL((mlp_bx_kernel<C_, 1, true>), grid, block, 0, s, g);   \
+            else hipLaunchKernelGGL((mlp_bx_kernel<C_, 2, true>), grid, block, 0, s, g);                 \
+        } else {                                                                                         \
+            if (mod == 0) hipLaunchKernelGGL((mlp_bx_kernel<C_, 0>), grid, block, 0, s, g);              \
+            else if (mod == 1) hipLaunchKernelGGL((mlp_bx_kernel<C_, 1>), grid, block, 0, s, g);         \
+            else hipLaunchKernelGGL((mlp_bx_kernel<C_, 2>), grid, block, 0, s, g);                       \
+        }                                                                                                \
     } while (0)
     switch (g.C) {
         case 96: MLP_LAUNCH(96); break;
@@ -805,9 +970,15 @@ bool launch_mlp_bx(const BxMlp &g, hipStream_t s) {
         case 384:
             if (g.wide8) {   // eight waves per 128 tokens (mlp384_bx_kernel)
                 const dim3 block8(512);
-                if (mod == 0) hipLaunchKernelGGL((mlp384_bx_kernel<0>), grid, block8, 0, s, g);
-                else if (mod == 1) hipLaunchKernelGGL((mlp384_bx_kernel<1>), grid, block8, 0, s, g);
-                else hipLaunchKernelGGL((mlp384_bx_kernel<2>), grid, block8, 0, s, g);
+                if (proj) {
+                    if (mod == 0) hipLaunchKernelGGL((mlp384_bx_kernel<0, true>), grid, block8, 0, s, g);
+                    else if (mod == 1) hipLaunchKernelGGL((mlp384_bx_kernel<1, true>), grid, block8, 0, s, g);
+                    else hipLaunchKernelGGL((mlp384_bx_kernel<2, true>), grid, block8, 0, s, g);
+                } else {
+                    if (mod == 0) hipLaunchKernelGGL((mlp384_bx_kernel<0>), grid, block8, 0, s, g);
+                    else if (mod == 1) hipLaunchKernelGGL((mlp384_bx_kernel<1>), grid, block8, 0, s, g);
+                    else hipLaunchKernelGGL((mlp384_bx_kernel<2>), grid, block8, 0, s, g);
+                }
             } else {
                 MLP_LAUNCH(384);
             }

@@ -15,7 +15,7 @@ EXPORTS = [
     "dsg_create", "dsg_destroy", "dsg_last_error", "dsg_version", "dsg_set_weight", "dsg_finalize_weights",
     "dsg_num_weight_keys", "dsg_weight_key", "dsg_workspace_bytes", "dsg_denoise", "dsg_precond", "dsg_sample",
     "dsg_sigma_schedule", "dsg_debug_tap", "dsg_debug_clear_taps", "dsg_decode_bits", "dsg_profile_forward", "dsg_set_option",
-    "dsg_get_option", "dsg_gen_noise", "dsg_train_inputs", "dsg_rainbow_loss", "dsg_rainbow_loss_backward", "dsg_noise_embed", "dsg_affine_width", "dsg_block_train", "dsg_train_grads", "dsg_train_step_grads", "dsg_train_self_cond", "dsg_train_bind_params", "dsg_adam_step", "dsg_ema_update", "dsg_debug_gemm", "dsg_debug_gemm_bx", "dsg_debug_attn_bx", "dsg_debug_qkv_attn_bx", "dsg_debug_mlp_bx", "dsg_profile_clock_ghz",
+    "dsg_get_option", "dsg_gen_noise", "dsg_train_inputs", "dsg_rainbow_loss", "dsg_rainbow_loss_backward", "dsg_noise_embed", "dsg_affine_width", "dsg_block_train", "dsg_train_grads", "dsg_train_step_grads", "dsg_train_self_cond", "dsg_train_bind_params", "dsg_adam_step", "dsg_ema_update", "dsg_debug_gemm", "dsg_debug_gemm_bx", "dsg_debug_attn_bx", "dsg_debug_qkv_attn_bx", "dsg_debug_projmlp_bx", "dsg_debug_mlp_bx", "dsg_profile_clock_ghz",
 ]
 
 
@@ -88,6 +88,7 @@ def load() -> C.CDLL:
     L.dsg_debug_gemm.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]
     L.dsg_debug_gemm_bx.argtypes = [i32, i32, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, C.POINTER(C.c_float), vp]
     L.dsg_debug_attn_bx.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, i32, C.POINTER(C.c_float), vp]
+    L.dsg_debug_projmlp_bx.argtypes = [i32, i32] + [vp] * 9 + [i32, vp, i32, C.POINTER(C.c_float), vp]
     L.dsg_debug_qkv_attn_bx.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, C.POINTER(C.c_float), vp]
     L.dsg_debug_mlp_bx.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, C.POINTER(C.c_float), vp]
     L.dsg_train_inputs.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp]

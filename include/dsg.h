@@ -219,6 +219,11 @@ int dsg_debug_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int32_t
  * pre-scaled by d^-1/2 log2 e), bias [3C], biasT as above; operands are rounded to bf16 on the way in, out is the bf16 result as fp32 */
 int dsg_debug_qkv_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int32_t heads, const float *xn, const float *W, const float *bias,
                           const float *biasT, float *out, int32_t time_iters, float *out_ms, void *stream);
+/* the fused MLP kernel with the attention half's tail in front: x <- [modulate] (x1 + fc2(GELU(fc1(LN(x1))))), x1 = x + att Wp^T + bp;
+ * att [M, C], Wp [C, C], W1 [4C, C], W2 [C, 4C] are rounded to bf16 on the way in; x [M, C] fp32 in place; out_xn as dsg_debug_mlp_bx */
+int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const float *Wp, const float *bp, const float *W1, const float *b1,
+                         const float *W2, const float *b2, const float *mod, int32_t out_mode, float *out_xn, int32_t time_iters, float *out_ms,
+                         void *stream);
 /* dsg_debug_mlp_bx: the fused MLP half of a block, x [M,C] <- [modulate] (x + fc2(GELU(fc1(xn)))) in place, with xn [M,C], W1 [4C,C],
  *   W2 [C,4C] given as fp32 and rounded to bf16 inside; mod = (scale [C] | shift [C]) or NULL; out_mode 0 none, 1 LayerNorm of the
  *   stored row, 2 its plain copy -> out_xn [M,C] (the bf16 store widened).  C in {96, 192, 384}. */

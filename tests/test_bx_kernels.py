@@ -206,3 +206,44 @@ def test_mlp_bx_whole_matrix(M, C, mod, out_mode):
         err = (out_xn.double() - ref).abs() - 2.0 ** -8 * ref.abs()
         worst = float(err.max()) / float(ref.abs().max())
         assert worst <= 1e-3, f"bf16 output: {worst:.2e} beyond bf16 rounding"
+
+
+@pytest.mark.parametrize("M,C,mod,out_mode", [(20037, 192, 1, 1), (65541, 96, 0, 2), (300, 96, 1, 1), (4096, 192, 0, 0), (51200, 96, 1, 1),
+                                               (51200, 384, 1, 1), (20037, 384, 0, 2), (300, 384, 0, 0)])
+def test_projmlp_bx_whole_matrix(M, C, mod, out_mode):
+    """proj + residual + LayerNorm-2 + fc1 + GELU + fc2 + residual [+ modulate] [+ LayerNorm | copy] in one kernel against fp64 on the
+    bf16-rounded operands: x1 = x + att Wp^T + bp stays in the accumulators (fp32), its LayerNorm is rounded to bf16 as fc1's operand,
+    the hidden activations are rounded to bf16 between the two products"""
+    from diffusesg_amd import lib as L
+    lib = L.load()
+    gen = torch.Generator(device="cuda").manual_seed(17 + M + C)
+    att = torch.randn(M, C, device="cuda", generator=gen)
+    x = torch.randn(M, C, device="cuda", generator=gen)
+    Wp = torch.randn(C, C, device="cuda", generator=gen) / C ** 0.5
+    bp = torch.randn(C, device="cuda", generator=gen) * 0.3
+    W1 = torch.randn(4 * C, C, device="cuda", generator=gen) / C ** 0.5
+    b1 = torch.randn(4 * C, device="cuda", generator=gen) * 0.3
+    W2 = torch.randn(C, 4 * C, device="cuda", generator=gen) / (4 * C) ** 0.5
+    b2 = torch.randn(C, device="cuda", generator=gen) * 0.3
+    aff = (torch.randn(2 * C, device="cuda", generator=gen) * 0.5) if mod else None
+    x_io = x.clone()
+    out_xn = torch.full((M, C), float("nan"), device="cuda")
+    rc = lib.dsg_debug_projmlp_bx(M, C, _p(att), _p(x_io), _p(Wp), _p(bp), _p(W1), _p(b1), _p(W2), _p(b2), _p(aff), out_mode,
+                                  _p(out_xn) if out_mode else None, 0, None, None)
+    assert rc == 0
+    x1 = x.double() + _bf(att).double() @ _bf(Wp).double().t() + bp.double()
+    xn = _bf(torch.nn.functional.layer_norm(x1, (C,), eps=1e-5).float()).double()
+    hid = torch.nn.functional.gelu(xn @ _bf(W1).double().t() + b1.double())
+    v = _bf(hid.float()).double() @ _bf(W2).double().t() + b2.double() + x1
+    if aff is not None:
+        v = torch.nn.functional.silu(aff[C:].double() + v * (1.0 + aff[:C].double()))
+    scale = float(v.abs().max())
+    d = float((x_io.double() - v).abs().max()) / scale
+    # (LayerNorm values / hidden values on a bf16 rounding boundary may round the other way than in fp64)
+    assert d <= 1e-3, f"fp32 residual stream: {d:.2e}"
+    if out_mode:
+        ref = torch.nn.functional.layer_norm(v, (C,), eps=1e-5) if out_mode == 1 else v
+        assert torch.isfinite(out_xn).all()
+        err = (out_xn.double() - ref).abs() - 2.0 ** -8 * ref.abs()
+        worst = float(err.max()) / float(ref.abs().max())
+        assert worst <= 2e-3, f"bf16 output: {worst:.2e} beyond bf16 rounding"

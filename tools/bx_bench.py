@@ -54,6 +54,27 @@ def mlp(tag, M, Cc, mod=1, out_mode=1):
           f"{by / ms.value / 1e9:6.2f} TB/s", flush=True)
 
 
+def projmlp(tag, M, Cc, mod=1, out_mode=1):
+    g = torch.Generator(device="cuda").manual_seed(3)
+    att = torch.randn(M, Cc, device="cuda", generator=g)
+    x = torch.randn(M, Cc, device="cuda", generator=g)
+    Wp = torch.randn(Cc, Cc, device="cuda", generator=g) / Cc ** 0.5
+    bp = torch.randn(Cc, device="cuda", generator=g)
+    W1 = torch.randn(4 * Cc, Cc, device="cuda", generator=g) / Cc ** 0.5
+    b1 = torch.randn(4 * Cc, device="cuda", generator=g)
+    W2 = torch.randn(Cc, 4 * Cc, device="cuda", generator=g) / (4 * Cc) ** 0.5
+    b2 = torch.randn(Cc, device="cuda", generator=g)
+    aff = torch.randn(2 * Cc, device="cuda", generator=g) * 0.1 if mod else None
+    o = torch.empty(M, Cc, device="cuda")
+    ms = C.c_float(0)
+    rc = lib.dsg_debug_projmlp_bx(M, Cc, p(att), p(x), p(Wp), p(bp), p(W1), p(b1), p(W2), p(b2), p(aff), out_mode, p(o), ITERS, C.byref(ms), None)
+    assert rc == 0, rc
+    fl = 18.0 * M * Cc * Cc
+    by = M * Cc * (2 + 4 + 4 + 2)
+    print(f"{tag:34s} M={M:7d} C={Cc:5d}        : {ms.value * 1e3:8.1f} us  {fl / ms.value / 1e9:8.1f} TFLOP/s   min HBM {by / 1e6:7.1f} MB -> "
+          f"{by / ms.value / 1e9:6.2f} TB/s", flush=True)
+
+
 def attn(tag, B, res, ws, shift, heads):
     g = torch.Generator(device="cuda").manual_seed(2)
     Cc, T = 32 * heads, res * res
@@ -118,6 +139,9 @@ if __name__ == "__main__":
     mlp("L2 fused MLP (mod, LN), 4 waves", M2, 384, out_mode=1 + 16)
     mlp("L1 fused MLP (mod, LN)", M1, 192)
     mlp("L0 fused MLP (copy)", M0, 96, mod=0, out_mode=2)
+    projmlp("L2 proj + MLP fused (mod, LN)", M2, 384)
+    projmlp("L1 proj + MLP fused (mod, LN)", M1, 192)
+    projmlp("L0 proj + MLP fused (copy)", M0, 96, mod=0, out_mode=2)
     if only == "gemm":
         sys.exit(0)
     qkv_attn("L2 qkv + attn fused", B, 10, 10, 0, 12)
