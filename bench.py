@@ -275,9 +275,13 @@ def worker(args):
         # avg_launch_ms: HIP events recorded on the launch stream around every GEMM launch (eager forwards).
         # avg_launch_ms_inkernel: first-block-start -> last-block-end stamps (100 MHz constant clock) of back-to-back
         # launches; consecutive kernels overlap at their tails, so this one reads a few % high.
-        gemm_avg_ms = ms[0] / cnt[0]
-        gemm_avg_ms_inkernel = gemm_ms.value / cnt[0]
-        achieved = (fl[0] / cnt[0]) / (gemm_avg_ms * 1e-3) / 1e12
+        # the dominant kernel class: the GEMM, except on the bf16 block pipeline, where a Swin block is two kernels (QKV + attention;
+        # proj + MLP) and the second one carries most of the time and of the FLOPs
+        bx_pipe = mode == "bf16" and bool(h.get_option("bf16_pipe")) and bool(h.get_option("bf16_proj_mlp")) and cnt[4] > 0
+        dk = 4 if bx_pipe else 0
+        gemm_avg_ms = ms[dk] / cnt[dk]
+        gemm_avg_ms_inkernel = gemm_ms.value / cnt[0] if cnt[0] else None
+        achieved = (fl[dk] / cnt[dk]) / (gemm_avg_ms * 1e-3) / 1e12
         clock_ghz = float(h.L.dsg_profile_clock_ghz(h.raw))   # shader clock held during those GEMM launches (in-kernel stamps)
         kinds = ["gemm", "window_attn", "row", "elementwise", "fused_blocks"]
         breakdown = {kinds[i]: {"ms_per_forward": ms[i] / iters, "launches_per_forward": cnt[i] // iters,
@@ -288,18 +292,22 @@ def worker(args):
         prof_root = os.path.join(ROOT, "profiles")
         # (file, kernel family, condition): the committed PMC passes exist for the headline workload and for configs[4]'s per-GPU share
         pmc_sets = [("pmc_traffic.json", "gemm4_f32_kernel", args.config == "vg" and B == 64 and mode == "f32"),
-                    ("pmc_traffic_coco_bf16.json", "gemm_bx_kernel", args.config == "coco" and B == 512 and mode == "bf16")]
+                    ("pmc_traffic_coco_bf16.json", ("mlp384_bx_kernel", "mlp_bx_kernel") if bx_pipe else "gemm_bx_kernel",
+                     args.config == "coco" and B == 512 and mode == "bf16")]
         for rnd in sorted(os.listdir(prof_root), reverse=True) if os.path.isdir(prof_root) else []:
             for fname, fam, cond in pmc_sets:
                 pj = os.path.join(prof_root, rnd, fname)
                 if cond and traffic is None and os.path.exists(pj):
                     tj = json.load(open(pj))
-                    if fam in tj.get("kernels", {}):
-                        traffic = tj["kernels"][fam]["hbm_bytes_per_launch"]
+                    fams = [f for f in ((fam,) if isinstance(fam, str) else fam) if f in tj.get("kernels", {})]
+                    if fams and len(fams) == (1 if isinstance(fam, str) else len(fam)):
+                        n_l = sum(tj["kernels"][f]["launches"] for f in fams)
+                        traffic = sum(tj["kernels"][f]["hbm_bytes_per_launch"] * tj["kernels"][f]["launches"] for f in fams) / n_l
                         traffic_src = f"profiles/{rnd}/{fname} (committed rocprofv3 --pmc passes of this command from an earlier run of this build's kernels, not this process)"
         # peak of the pipe the dominant kernel runs on, in ALGORITHMIC (2*M*N*K) FLOP/s: the split kernel issues six bf16
         # MFMA products per algorithmic product, so its ceiling is the bf16 dense peak / 6
-        bf16_kern = "gemm_bx_kernel" if (mode == "bf16" and h.get_option("bf16_pipe")) else "gemm_bf16_kernel"
+        bf16_kern = ("mlp384_bx_kernel + mlp_bx_kernel (proj + MLP half of a Swin block)" if bx_pipe else
+                     ("gemm_bx_kernel" if (mode == "bf16" and h.get_option("bf16_pipe")) else "gemm_bf16_kernel"))
         kern, peak = {"f32": ("gemm4_f32_kernel", PEAK_F32_MFMA_TFLOPS), "bf16": (bf16_kern, PEAK_BF16_MFMA_TFLOPS),
                       "f32-split": ("gemm_split2_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0)}[mode]
         if mode != "f32":
@@ -307,7 +315,7 @@ def worker(args):
         roofline = {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak,
                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_ms": gemm_avg_ms, "avg_launch_ms_inkernel": gemm_avg_ms_inkernel,
-                    "flops_per_launch": fl[0] / cnt[0], "launches_per_forward": cnt[0] // iters,
+                    "flops_per_launch": fl[dk] / cnt[dk], "launches_per_forward": cnt[dk] // iters,
                     "held_clock_ghz": clock_ghz if mode == "f32" else None,
                     "clock_limited_peak": (clock_ghz * 1024 * 64 / 1e3) if (mode == "f32" and clock_ghz > 0) else None,
                     "forward_breakdown": breakdown}

@@ -1121,7 +1121,7 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
     if (h->opt_bf16_qkv_attn && h->taps.empty()) {   // (the qkv tap wants the tensor)
         BxQkvAttn qa;
         qa.xn = w->xn; qa.W = bf16_of(h, b.qkv_wf); qa.bias = b.qkv_bf; qa.biasP = b.biasP; qa.out = w->att; qa.B = B; qa.g = wg;
-        ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)M * 3.0 * C * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, "qkv_attn_bx");
+        ProfScope ps_(h, s, PK_ATTN, 2.0 * (double)M * 3.0 * C * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, "qkv_attn_bx");
         fused_qa = launch_qkv_attn_bx(qa, s);
     }
     if (!fused_qa) {
