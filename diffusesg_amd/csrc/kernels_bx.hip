@@ -632,6 +632,20 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
     const rsrc_t rsO = make_rsrc(xo ? xo + (size_t)m0 * C : nullptr, xo ? (unsigned)rows * C * 2u : 0u);
     const float *aff_row = nullptr;
     if (MOD != 0) aff_row = g.mod_aff + (size_t)(MOD == 2 ? min(m0 + (int)mrow, g.M - 1) / g.mod_T : 0) * g.mod_ld + g.mod_off;
+    // bf16 outputs leave through a wave-private 32 x 96 transposition in the (idle) weight stages, as in gemm_bx_kernel: row-contiguous
+    // 16-byte pieces instead of 32 rows x 16 B per store instruction
+    constexpr int TLD = 104;
+    static_assert(4 * 32 * TLD <= 2 * STAGE, "the output transposition reuses the weight stages");
+    __bf16 *T = lds + wave * 32 * TLD;
+    auto tput = [&](int ct, int q, const f32x4 &v) { *reinterpret_cast<u32x2 *>(T + lrow * TLD + 32 * (ct % 3) + 8 * q + 4 * lhalf) = pack_bf16x4(v); };
+    auto tflush = [&](int third) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = lane + 64 * k, r = i / 12, pc = i - 12 * r;
+            const u32x4 d = *reinterpret_cast<const u32x4 *>(T + r * TLD + 8 * pc);
+            buf_store_u4(d, rsO, ((unsigned)(32 * wave + r) * C + (unsigned)(96 * third + 8 * pc)) * 2u, 0u);
+        }
+    };
     float ssum = 0.f, ssq = 0.f;
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) {
@@ -654,8 +668,9 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
             buf_store4(v, rsX, (mrow * C + (unsigned)c) * 4u, 0u);
 #pragma unroll
             for (int t = 0; t < 4; t++) { ssum += v[t]; ssq = fmaf(v[t], v[t], ssq); oacc[ct][4 * q + t] = v[t]; }
-            if (g.out_mode == 2) buf_store2(pack_bf16x4(v), rsO, (mrow * C + (unsigned)c) * 2u, 0u);
+            if (g.out_mode == 2) tput(ct, q, v);
         }
+        if (g.out_mode == 2 && ct % 3 == 2) tflush(ct / 3);
     }
     if (g.out_mode == 1) {
         ssum += __shfl_xor(ssum, 32, 64);
@@ -668,7 +683,8 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
                 f32x4 v;
 #pragma unroll
                 for (int t = 0; t < 4; t++) v[t] = fmaf(oacc[ct][4 * q + t], rstd, nmr);
-                buf_store2(pack_bf16x4(v), rsO, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 2u, 0u);
+                tput(ct, q, v);
+                if (ct % 3 == 2 && q == 3) tflush(ct / 3);
             }
     }
 }
@@ -1231,7 +1247,7 @@ void launch_bias_permute_bx(const float *biasT, void *out, int n_tiles, int Wp, 
 }
 
 template <int KT, int WS>
-__global__ __launch_bounds__(256, 2) void qkv_attn_bx_kernel(BxQkvAttn a, int nblk, int U) {
+__global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nblk, int U) {
     constexpr int KB = 64, LDP = KB + 8, Wp = 32 * KT, Wt = WS * WS, UPB = 4 / KT, KLD = 40, VLD = Wp + 8;
     constexpr int STAGE = (128 + 96) * LDP, OLD = 40;
     static_assert(128 * KLD + UPB * 32 * VLD <= STAGE, "k / v^T live in the tile stage after the K loop");
