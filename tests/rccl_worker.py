@@ -56,6 +56,12 @@ def main():
     D.all_reduce_mean(grads, bucket_bytes=300000)
     for k in grads:
         assert torch.equal(grads[k], ref[k]), k
+    from diffusesg_amd.train import GradDict   # the flat form train_step_grads returns: one collective on the flat buffer
+    fg = GradDict()
+    fg.flat = torch.cat([ref[k].reshape(-1) for k in ref]).clone()
+    flat_ref = fg.flat.clone()
+    D.all_reduce_mean(fg)
+    assert torch.equal(fg.flat, flat_ref)
     t = torch.tensor([1.25], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)   # bench.py's max-over-ranks timing reduction
     assert float(t) == 1.25

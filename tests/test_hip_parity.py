@@ -535,12 +535,15 @@ def test_bf16_gemm_mode_vs_reference(name, fused, pipe):
     h.set_option("gemm_bf16", 1)
     h.set_option("bf16_pipe", pipe)
     assert h.get_option("bf16_pipe") == pipe
-    # fused = 1: the pipeline's defaults (QKV + attention in one kernel, fc1-GELU-fc2 in one kernel at every width it covers, eight
-    # waves at C = 384); 2: the separate QKV GEMM + attention kernel and the four-wave MLP kernel at C = 384; 0: GEMM pairs everywhere
+    # fused = 1: the pipeline's defaults (QKV + attention in one kernel; proj + fc1-GELU-fc2 in one kernel at every width it covers,
+    # eight waves at C = 384); 2: the separate QKV GEMM + attention kernel, the proj GEMM, the MLP kernels without the proj stage and
+    # on four waves at C = 384; 0: GEMM pairs everywhere
     if pipe == 0 and fused == 2:
         pytest.skip("the kernel variants of fused = 2 belong to the block pipeline")
     h.set_option("bf16_mlp", fused)
     h.set_option("bf16_qkv_attn", 1 if fused == 1 else 0)
+    h.set_option("bf16_proj_mlp", 1 if fused == 1 else 0)   # (fused = 2: the proj GEMM in front of the plain MLP kernels)
+    assert h.get_option("bf16_proj_mlp") == (1 if (pipe and fused == 1) else 0)
     assert h.get_option("bf16_mlp") == (fused if pipe else 0)
     assert h.get_option("bf16_qkv_attn") == (1 if (pipe and fused == 1) else 0)
     for opt in ("fused_attn", "fused_mlp", "fused_readout", "fused_patch_embed"):

@@ -113,6 +113,17 @@ def _grad_worker(rank, world, port, q):
         mine = {k: v.clone() for k, v in grads.items()}
         out = ddist.all_reduce_mean(grads, bucket_bytes=4096)   # small buckets: several collectives, one tensor larger than a bucket
         assert out is grads
+        # the flat form train_step_grads returns (train.GradDict: every gradient a view into one buffer): ONE collective, in place
+        from diffusesg_amd.train import GradDict
+        fg = GradDict()
+        fg.flat = torch.cat([mine[k].reshape(-1) for k in mine]).clone()
+        off = 0
+        for k, v in mine.items():
+            fg[k] = fg.flat[off:off + v.numel()].view(v.shape)
+            off += v.numel()
+        assert ddist.all_reduce_mean(fg) is fg
+        for k in grads:
+            assert torch.allclose(fg[k], grads[k], atol=1e-7), k
         q.put((rank, {k: v.numpy() for k, v in grads.items()}, {k: v.numpy() for k, v in mine.items()}))
     finally:
         dist.destroy_process_group()
