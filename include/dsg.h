@@ -294,7 +294,8 @@ int dsg_block_train(dsg_handle h, const char *block, int32_t B, const float *x_i
  * set afterwards (an optimiser step) are used as they are -- the training form reads the raw tensors only.
  *   in_adj [B,C_adj,N,N], in_node [B,N,C_node]: the preconditioned inputs c_in(sigma) * noisy (precond.py:100); c_noise [B];
  *   sc_*: the self-conditioning inputs (constants: the reference detaches them) or NULL; out_F_*: the raw network outputs;
- *   names[i] (state-dict keys of all parameters) -> grad_params[i] (device buffers of the parameters' shapes, overwritten). */
+ *   names[i] (state-dict keys of all parameters) -> grad_params[i] (device buffers of the parameters' shapes, overwritten).
+ *   Like every entry that takes a stream, the work is only ENQUEUED when the call returns (round 2 synchronised at the end of this one). */
 int dsg_train_grads(dsg_handle h, int32_t B, const float *in_adj, const float *in_node, const uint8_t *flags, const float *c_noise,
                     const float *sc_adj, const float *sc_node, const float *grad_F_adj, const float *grad_F_node, float *out_F_adj,
                     float *out_F_node, int32_t n_params, const char *const *names, float *const *grad_params, void *stream);

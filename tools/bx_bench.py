@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU box: per-shape timings of the bf16 block pipeline's kernels (csrc/kernels_bx.hip) at BASELINE configs[4]'s per-GPU share
 (COCO-bits, B = 512): HIP-event mean over back-to-back launches on random data, with the algorithmic TFLOP/s and the HBM bytes each
-launch has to move at least (-> the GB/s it would need at that time).  `DSG_BX_GEO` selects alternative tile geometries."""
+launch has to move at least (-> the GB/s it would need at that time)."""
 import ctypes as C
 import os
 import sys
@@ -117,7 +117,7 @@ def qkv_attn(tag, B, res, ws, shift, heads):
 
 if __name__ == "__main__":
     B = int(os.environ.get("BX_B", "512"))
-    print(f"DSG_BX_GEO={os.environ.get('DSG_BX_GEO')}  B={B}")
+    print(f"B={B}")
     M2, M1, M0 = B * 100, B * 400, B * 1600
     only = os.environ.get("BX_ONLY", "")
     gemm("L2 qkv", M2, 1152, 384)
