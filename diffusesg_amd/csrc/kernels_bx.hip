@@ -705,6 +705,9 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
 // PROJ (as mlp_bx_kernel): x1 = x + att Wp^T + bp first, split along N like fc2 -- wave kh forms output channels 192 kh .. + 191 of its 32
 // tokens from the whole attention row (96 registers, dead afterwards) -- which are exactly the channels of its K half of fc1 and of its
 // fc2 accumulators: the LayerNorm statistics cross the pair through LDS, nothing else moves.
+#ifndef DSG_MLP_EXP
+#define DSG_MLP_EXP 0   // timing experiments (wrong results): 1 no GELU, 2 no MFMAs in the chunk-pair loop, 3 no weight staging (loads / LDS refills)
+#endif
 template <int MOD, bool PROJ = false>
 __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
     constexpr int C = 384, H = 4 * C, NPAIR = H / 64, CT = 6;
@@ -727,6 +730,7 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
     u32x4 st[6];
     float s_b1 = 0.f;
     auto issue_w1 = [&](int cp) {
+        if (DSG_MLP_EXP == 3 && cp > 0) return;
         if (tid < 64) s_b1 = g.b1[64 * cp + tid];
 #pragma unroll
         for (int p = 0; p < 6; p++) {
@@ -735,6 +739,7 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
         }
     };
     auto write_w1 = [&](int cp) {
+        if (DSG_MLP_EXP == 3 && cp > 0) return;
 #pragma unroll
         for (int p = 0; p < 6; p++) {
             const int q = tid + 512 * p;
@@ -766,6 +771,7 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
         }
     };
     auto issue_w2 = [&](int cp) {
+        if (DSG_MLP_EXP == 3 && cp > 0) return;
 #pragma unroll
         for (int p = 0; p < 6; p++) {
             const int q = tid + 512 * p;
@@ -773,6 +779,7 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
         }
     };
     auto write_w2 = [&]() {
+        if (DSG_MLP_EXP == 3) return;
 #pragma unroll
         for (int p = 0; p < 6; p++) {
             const int q = tid + 512 * p, c = q & 7, c4 = c & 3;
@@ -861,6 +868,7 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
         for (int r = 0; r < 16; r++) { ho[r] = 0.f; hx[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 12; s++) {
+            if (DSG_MLP_EXP == 2) { ho[s] += (float)xf[s][0]; continue; }
             ho = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w1own + 16 * s), xf[s], ho, 0, 0, 0);
             hx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w1oth + 16 * s), xf[s], hx, 0, 0, 0);
         }
@@ -876,7 +884,7 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
                 const f32x4 pp = xch1[(q * 8 + (wave ^ 1)) * 64 + lane], b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * q);
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = gelu_f(ho[4 * q + e] + pp[e] + b4[e]);
+                for (int e = 0; e < 4; e++) v[e] = DSG_MLP_EXP == 1 ? ho[4 * q + e] + pp[e] + b4[e] : gelu_f(ho[4 * q + e] + pp[e] + b4[e]);
                 hf[q >> 1][2 * (q & 1)] = pack_bf16(v[0], v[1]);
                 hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(v[2], v[3]);
             }
@@ -891,6 +899,7 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
             for (int s2 = 0; s2 < 2; s2++) {
+                if (DSG_MLP_EXP == 2) { oacc[ct][s2] += __builtin_bit_cast(float, hf[s2][0] ^ hp[s2][1]); continue; }
                 oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w2own + 32 * ct * LD2 + 16 * s2),
                                                                    __builtin_bit_cast(bf16x8, hf[s2]), oacc[ct], 0, 0, 0);
                 oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w2oth + 32 * ct * LD2 + 16 * s2),
