@@ -1082,7 +1082,9 @@ void readout_stage(dsg_handle h, Workspace *w, hipStream_t s) {
 //   BX_MOD   x holds silu(shift + x (1 + scale)) of the block about to run (its shortcut), w->xn is not valid yet
 //   BX_READY x as BX_MOD and w->xn = LayerNorm-1 of it without affine (gamma / beta are folded into qkv_wf / qkv_bf)
 enum BxState { BX_RAW = 0, BX_MOD = 1, BX_READY = 2 };
-bool bx_on(dsg_handle h) { return h->opt_gemm_bf16 && !h->opt_gemm_split && h->opt_bf16_pipe; }
+// (the pipeline's kernels are built and tested for embed_dim = 96 -- every configuration of the reference; any other width keeps
+// round 2's kernels_lp.hip path instead of meeting an uncovered shape half-way through a forward, and get_option reports that)
+bool bx_on(dsg_handle h) { return h->opt_gemm_bf16 && !h->opt_gemm_split && h->opt_bf16_pipe && h->E == 96; }
 
 #define P_BX(g, tag)                                                                                                           \
     do {                                                                                                                       \
