@@ -861,6 +861,40 @@ def test_coco_short_trajectory_vs_reference(mode):
         assert rms_rel(oa.numpy(), ra) <= 2e-2 and rms_rel(on.numpy(), rn) <= 2e-2
 
 
+def test_coco_bf16_full_schedule_decoded_agreement():
+    """configs[4]'s network, a whole T = 20 Heun + churn schedule (39 preconditioner calls, the device's own noise and coins from one
+    seed) in the opt-in bf16 mode against the fp32 mode: SURVEY §8c asks for decoded-graph agreement as a RATE at T >= 50-like lengths
+    -- a +-1-thresholded bit decode flips where the continuous output sits near 0, and with synthetic (untrained) weights many outputs
+    do -- so the continuous outputs are held to a stated bar and the decoded agreement is printed and held to a loose floor."""
+    from diffusesg_amd.model import build_network
+    from diffusesg_amd import io as dio
+    cfg = Y.CONFIGS["coco"]()
+    n, B = cfg.max_node_num, 8
+    flags = np.zeros((B, n), np.uint8)
+    for b_, k in enumerate([20, 40, 7, 33, 12, 25, 40, 3]):
+        flags[b_, :k] = 1
+    outs = {}
+    for mode in ("f32", "bf16"):
+        net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")
+        if mode == "bf16":
+            net.model._ensure_handle().set_option("gemm_bf16", 1)
+            assert net.model._ensure_handle().precision_mode() == "bf16" and net.model._ensure_handle().get_option("bf16_proj_mlp") == 1
+        np.random.seed(1234)   # the preconditioner's self-conditioning coins come from NumPy's global stream
+        oa, on = make_sampler(20).sample(net, T(flags.astype(bool)), num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj, seed=77)
+        qa, qn, bb = dio.decode_bits(net.model, oa.cuda(), on.cuda(), T(flags), n_adj_type=184, n_node_type=172)
+        outs[mode] = (oa.numpy(), on.numpy(), qa.cpu().numpy(), qn.cpu().numpy())
+    (fa, fn, fqa, fqn), (ba, bn, bqa, bqn) = outs["f32"], outs["bf16"]
+    ra_, rn_ = rms_rel(ba, fa), rms_rel(bn, fn)
+    valid_e = (flags[:, :, None] * flags[:, None, :]).astype(bool)
+    agree_a = float((fqa == bqa)[valid_e].mean())
+    agree_n = float((fqn == bqn)[flags.astype(bool)].mean())
+    print(f"coco bf16 T=20 vs fp32: rms {ra_:.2e}/{rn_:.2e}; decoded agreement edges {agree_a:.4f}, nodes {agree_n:.4f}")
+    # measured (round 3, block pipeline with every fused kernel on): RMS 1.1e-3 / 8e-4 of the output scale, 99.2 % of the decoded edges
+    # and 99.4 % of the decoded node labels identical -- the clipped, denoised end of a schedule contracts the per-forward error
+    assert ra_ <= 1e-2 and rn_ <= 1e-2
+    assert agree_a >= 0.97 and agree_n >= 0.97
+
+
 def test_coco_batch512_properties():
     """configs[4] per-GPU batch (COCO-bits, B = 512), fp32 and bf16 mode: finite, exact-zero masks, batch independence,
     and the bf16 mode stays within its stated bar of the fp32 result on every one of the 512 graphs"""
