@@ -113,6 +113,7 @@ struct dsg_handle_s {
     float *ro0_w = nullptr;     // read_out.0 transposed to [out,in]
     // folded read-out (E = 96): Fa = F1.W2.W1.W0^T packed fragment-major, fa; F2 padded+packed; node: Gext [E,128]
     float *ro_fap = nullptr, *ro_fa = nullptr, *ro_f2p = nullptr, *ro_gext = nullptr;
+    float *ro_fapb = nullptr, *ro_f2pb = nullptr;   // the same two matrices in the bf16 MFMA's fragment order (fp32 here; their bf16 copies are what runs)
     float *ro0_wf = nullptr, *ro0_bf = nullptr;  // read_out.0 ([out,in]) with the final norm's gamma/beta folded in
     float *merge_wf[DSG_MAX_LAYERS] = {}, *merge_bf[DSG_MAX_LAYERS] = {};   // PatchMerging reduction with its LayerNorm(4C) folded in
     std::vector<void *> derived_allocs;
@@ -127,6 +128,7 @@ struct dsg_handle_s {
     bool opt_gemm_bf16 = false;                                   // bf16-MFMA GEMMs (fp32 accumulate), opt-in precision mode
     int opt_bf16_act = 2;                                         // in that mode: 1 hidden / attention-output tensors stored as bf16 (bit-identical), 2 also qkv
     bool opt_bf16_pipe = true;                                    // in that mode: the bf16 block pipeline of kernels_bx.hip (0: round 2's kernels_lp.hip path)
+    bool opt_bf16_readout = true;                                 // in that pipeline: the read-out's two products on the bf16 matrix pipe
     bool opt_bf16_proj_mlp = true;                                // in that pipeline: proj + residual + LayerNorm-2 in front of the fused MLP kernel (0: the proj GEMM)
     bool opt_bf16_qkv_attn = true;                                // in that pipeline: QKV projection + window attention in one kernel (0: GEMM + attn_bx_kernel through a bf16 qkv tensor)
     int opt_bf16_mlp = 1;                                         // in that pipeline: the fused fc1-GELU-fc2 kernels (0: two GEMMs with a bf16 hidden tensor; 1: C <= 192 on 4 waves, C = 384 on 8; 2: C = 384 on the 4-wave kernel too; 3: GEMM pair at C = 384)
@@ -708,6 +710,7 @@ int dsg_finalize_weights(dsg_handle h) {
     // Folded read-out (E = 96, C_adj <= 32): final-LN output -> read_out.0/1/2 -> readout_adj_mlp.fc1 is affine up to the
     // GELU, and the node head's pooled shared_rep is an affine image of the pooled LN output.  Fold in double precision.
     h->ro_fap = h->ro_fa = h->ro_f2p = h->ro_gext = nullptr;
+    h->ro_fapb = h->ro_f2pb = nullptr;
     if (E == 96 && h->Ca <= 32) {
         auto dl = [&](const char *k, size_t n) { std::vector<float> v(n); (void)hipMemcpy(v.data(), WT(h, k), sizeof(float) * n, hipMemcpyDeviceToHost); return v; };
         const std::vector<float> r0 = dl("read_out.0.weight", (size_t)E * E), r1 = dl("read_out.1.weight", (size_t)E * E),
@@ -759,6 +762,25 @@ int dsg_finalize_weights(dsg_handle h) {
         if (int rc = up(faf, &h->ro_fa)) return rc;
         if (int rc = up(f2p, &h->ro_f2p)) return rc;
         if (int rc = up(gext, &h->ro_gext)) return rc;
+        // bf16-MFMA fragments (32x32x16: lane (row, half) holds 8 k values per k-step; k order 16 s + 8 (j >> 2) + 4 half + (j & 3), the order
+        // in which fused_readout96_kernel<true>'s register pairs enumerate LN(x)'s channels / the hidden units)
+        std::vector<float> fapb((size_t)3 * 6 * 64 * 8), f2pb((size_t)3 * 2 * 64 * 8, 0.f);
+        for (int nt = 0; nt < 3; nt++)
+            for (int sx = 0; sx < 6; sx++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++)
+                        fapb[(((size_t)nt * 6 + sx) * 64 + lane) * 8 + j] =
+                            (float)Fa[(size_t)(32 * nt + (lane & 31)) * E + 16 * sx + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)];
+        for (int nt = 0; nt < 3; nt++)
+            for (int g2 = 0; g2 < 2; g2++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int c = lane & 31;
+                        f2pb[(((size_t)nt * 2 + g2) * 64 + lane) * 8 + j] =
+                            c < h->Ca ? F2[(size_t)c * E + 32 * nt + 16 * g2 + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3)] : 0.f;
+                    }
+        if (int rc = up(fapb, &h->ro_fapb)) return rc;
+        if (int rc = up(f2pb, &h->ro_f2pb)) return rc;
     }
     drop_graphs(h);   // captured graphs bake weight pointers
     // bf16 copies (opt-in mode): drop stale ones, list every GEMM weight, rebuild if the mode is on
@@ -780,6 +802,8 @@ int dsg_finalize_weights(dsg_handle h) {
     h->gemm_weights.push_back({h->pe_w, (size_t)E * h->Kp});
     h->gemm_weights.push_back({h->ro0_wf, (size_t)E * E});
     if (h->ro_gext) h->gemm_weights.push_back({h->ro_gext, (size_t)E * 128});
+    if (h->ro_fapb) h->gemm_weights.push_back({h->ro_fapb, (size_t)3 * 6 * 64 * 8});
+    if (h->ro_f2pb) h->gemm_weights.push_back({h->ro_f2pb, (size_t)3 * 2 * 64 * 8});
     if (h->opt_gemm_bf16) if (int rc = ensure_bf16_weights(h)) return rc;
     if (h->opt_gemm_split) if (int rc = ensure_split_weights(h)) return rc;
     h->finalized = true;
@@ -1029,15 +1053,20 @@ bool patch_embed_stage(dsg_handle h, Workspace *w, bool fp32_rule, hipStream_t s
 }
 
 // final norm + read_out + heads (diffusesg.py:758-761, :806-825): w->x -> (f_adj, f_node)
+bool bx_on(dsg_handle h);
 void readout_stage(dsg_handle h, Workspace *w, hipStream_t s) {
     const int B = w->B, N = h->N, E = h->E, T0 = N * N;
     GemmArgs g;
     const int M0 = B * T0;
     if (h->opt_fused_readout && h->ro_fap && h->taps.empty()) {
         // one pass over x: LN, folded read_out+fc1, GELU, fc2, masked adjacency store; pooled LN(x) for the node head
+        // (the bf16 block pipeline runs the two products of the read-out on the bf16 matrix pipe as well: option bf16_readout)
+        const float *fap_b = (bx_on(h) && h->opt_bf16_readout && h->ro_fapb) ? (const float *)bf16_of(h, h->ro_fapb) : nullptr;
+        const float *f2p_b = fap_b ? (const float *)bf16_of(h, h->ro_f2pb) : nullptr;
+        const bool ro_bf = fap_b && f2p_b;
         P_KERN(PK_FUSED, 2.0 * (double)M0 * E * (E + 32.0),
-               launch_fused_readout96(w->x, WT(h, "norm.weight"), WT(h, "norm.bias"), h->ro_fap, h->ro_fa, h->ro_f2p,
-                                      WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, w->pool_part, w->pool_ext, B, N, h->Ca, s));
+               launch_fused_readout96(w->x, WT(h, "norm.weight"), WT(h, "norm.bias"), ro_bf ? fap_b : h->ro_fap, h->ro_fa, ro_bf ? f2p_b : h->ro_f2p,
+                                      WT(h, "readout_adj_mlp.fc2.bias"), w->flags, w->f_adj, w->pool_part, w->pool_ext, B, N, h->Ca, s, ro_bf));
         g = GemmArgs();
         g.A = w->pool_ext; g.lda = 128; g.K1 = 128; g.K = 128; g.M = B * N; g.N = E; g.act = ACT_GELU;
         g.W = h->ro_gext; g.bias = WT(h, "readout_node_mlp.fc1.bias"); g.C = w->hn; g.ldc = E;
@@ -1530,6 +1559,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (n == "bf16_qkv_attn") h->opt_bf16_qkv_attn = value != 0;
     else if (n == "bf16_proj_mlp") h->opt_bf16_proj_mlp = value != 0;
+    else if (n == "bf16_readout") h->opt_bf16_readout = value != 0;
     else if (n == "fused_merge") { h->opt_fused_merge = value != 0; h->opt_fused_merge_small = value > 1; }   // 2: at every size
     else if (n == "gemm_bf16") {
         h->opt_gemm_bf16 = value != 0;
@@ -1560,6 +1590,7 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "bf16_mlp") *value = bx_on(h) ? h->opt_bf16_mlp : 0;
     else if (n == "bf16_qkv_attn") *value = (bx_on(h) && h->opt_bf16_qkv_attn) ? 1 : 0;
     else if (n == "bf16_proj_mlp") *value = (bx_on(h) && h->opt_bf16_mlp && h->opt_bf16_proj_mlp) ? 1 : 0;
+    else if (n == "bf16_readout") *value = (bx_on(h) && h->opt_bf16_readout && h->opt_fused_readout) ? 1 : 0;
     else if (n == "fused_merge") *value = h->opt_fused_merge ? (h->opt_fused_merge_small ? 2 : 1) : 0;
     else if (n == "gemm_bf16") *value = h->opt_gemm_bf16 && !h->opt_gemm_split;   // "gemm_split" takes precedence
     else if (n == "gemm_split") *value = h->opt_gemm_split;

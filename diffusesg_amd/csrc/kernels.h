@@ -129,7 +129,7 @@ bool launch_fused_patch_embed96(const float *adj, const float *node, const float
 int readout_pool_segments(int N);
 void launch_fused_readout96(const float *x, const float *gam, const float *bet, const float *Wfp, const float *fa, const float *W2p,
                             const float *f2, const uint8_t *flags, float *out_adj, float *pool_part, float *pool_ext, int B, int N,
-                            int Ca, hipStream_t s);
+                            int Ca, hipStream_t s, bool bf16_frags = false);   // bf16_frags: Wfp / W2p are bf16 fragments (dsg_api.cpp: ro_fapb / ro_f2pb)
 // whole attention half of a C=96 Swin block in one kernel (modulate+SiLU, LN1, QKV, window attention, proj, residual);
 // windows of at most 64 tokens; packed weights from pack_attn_weights in dsg_api.cpp
 void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, const float *gam, const float *bet, const float *Wqp,

@@ -984,6 +984,10 @@ void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, co
 // The same pass accumulates the node head's padding-aware pooling of LN(x) (the pooled shared_rep is recovered
 // from it by linearity in the node chain): pool[b,i,:] += (f_i f_j / N) * LN(x)[b,i,j,:].
 // =================================================================================================
+// BF (the opt-in bf16 mode's block pipeline only): the two products on v_mfma_f32_32x32x16_bf16 -- 18 + 6 instructions per wave instead
+// of 144 + 48 f32 ones; LN(x) pairs as they stand in the registers are the first product's B operand (k order 16 s + 8 (j >> 2) + 4 half +
+// (j & 3), the packed weights Wfp / W2p follow it: dsg_api.cpp), the GELU'd accumulators the second's.  The pooling stays fp32.
+template <bool BF>
 __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__restrict__ x, const float *__restrict__ gam,
                                                                  const float *__restrict__ bet, const float *__restrict__ Wfp,
                                                                  const float *__restrict__ fa, const float *__restrict__ W2p,
@@ -1052,6 +1056,17 @@ __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__
 
     const f32x4 *w1 = reinterpret_cast<const f32x4 *>(Wfp) + lane;
     const f32x4 *w2 = reinterpret_cast<const f32x4 *>(W2p) + lane;
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t *w1b = reinterpret_cast<const u32x4_t *>(Wfp) + lane, *w2b = reinterpret_cast<const u32x4_t *>(W2p) + lane;   // BF: bf16 fragments
+    u32x4_t xb[S / 2];
+    if (BF) {
+#pragma unroll
+        for (int s2 = 0; s2 < S / 2; s2++) {
+            xb[s2][0] = pack_bf16(xn[2 * s2][0], xn[2 * s2][1]); xb[s2][1] = pack_bf16(xn[2 * s2][2], xn[2 * s2][3]);
+            xb[s2][2] = pack_bf16(xn[2 * s2 + 1][0], xn[2 * s2 + 1][1]); xb[s2][3] = pack_bf16(xn[2 * s2 + 1][2], xn[2 * s2 + 1][3]);
+        }
+    }
     f32x16 oacc;
 #pragma unroll
     for (int r = 0; r < 16; r++) oacc[r] = 0.f;
@@ -1064,19 +1079,37 @@ __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__
 #pragma unroll
             for (int t = 0; t < 4; t++) hacc[4 * g + t] = bv[t];
         }
+        if (BF) {
 #pragma unroll
-        for (int s = 0; s < S; s++) {
-            const f32x4 a = w1[((size_t)nt * S + s) * 64];
+            for (int s2 = 0; s2 < S / 2; s2++)
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w1b[((size_t)nt * (S / 2) + s2) * 64]),
+                                                               __builtin_bit_cast(bf16x8_t, xb[s2]), hacc, 0, 0, 0);
+        } else {
 #pragma unroll
-            for (int t = 0; t < 4; t++) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], xn[s][t], hacc, 0, 0, 0);
+            for (int s = 0; s < S; s++) {
+                const f32x4 a = w1[((size_t)nt * S + s) * 64];
+#pragma unroll
+                for (int t = 0; t < 4; t++) hacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], xn[s][t], hacc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) hacc[r] = gelu_f(hacc[r]);
+        if (BF) {
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const f32x4 a = w2[((size_t)nt * 4 + g) * 64];
+            for (int g2 = 0; g2 < 2; g2++) {
+                u32x4_t hb;
 #pragma unroll
-            for (int t = 0; t < 4; t++) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], hacc[4 * g + t], oacc, 0, 0, 0);
+                for (int j = 0; j < 4; j++) hb[j] = pack_bf16(hacc[8 * g2 + 2 * j], hacc[8 * g2 + 2 * j + 1]);
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w2b[((size_t)nt * 2 + g2) * 64]),
+                                                               __builtin_bit_cast(bf16x8_t, hb), oacc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 a = w2[((size_t)nt * 4 + g) * 64];
+#pragma unroll
+                for (int t = 0; t < 4; t++) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], hacc[4 * g + t], oacc, 0, 0, 0);
+            }
         }
     }
     if (ok) {
@@ -1110,10 +1143,14 @@ int readout_pool_segments(int N) { return (N + 30) / 32 + 1; }  // most 32-token
 
 void launch_fused_readout96(const float *x, const float *gam, const float *bet, const float *Wfp, const float *fa, const float *W2p,
                             const float *f2, const uint8_t *flags, float *out_adj, float *pool_part, float *pool_ext, int B, int N,
-                            int Ca, hipStream_t s) {
+                            int Ca, hipStream_t s, bool bf16_frags) {
     const int M = B * N * N, nseg = readout_pool_segments(N);
-    hipLaunchKernelGGL(fused_readout96_kernel, dim3((M + 127) / 128), dim3(256), 0, s, x, gam, bet, Wfp, fa, W2p, f2, flags, out_adj,
-                       pool_part, nseg, B, N, Ca);
+    if (bf16_frags)
+        hipLaunchKernelGGL(fused_readout96_kernel<true>, dim3((M + 127) / 128), dim3(256), 0, s, x, gam, bet, Wfp, fa, W2p, f2, flags, out_adj,
+                           pool_part, nseg, B, N, Ca);
+    else
+        hipLaunchKernelGGL(fused_readout96_kernel<false>, dim3((M + 127) / 128), dim3(256), 0, s, x, gam, bet, Wfp, fa, W2p, f2, flags, out_adj,
+                           pool_part, nseg, B, N, Ca);
     const int n = B * N * 128;
     hipLaunchKernelGGL(pool_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flags, pool_part, nseg, pool_ext, B, N);
 }

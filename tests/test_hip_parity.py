@@ -543,6 +543,7 @@ def test_bf16_gemm_mode_vs_reference(name, fused, pipe):
     h.set_option("bf16_mlp", fused)
     h.set_option("bf16_qkv_attn", 1 if fused == 1 else 0)
     h.set_option("bf16_proj_mlp", 1 if fused == 1 else 0)   # (fused = 2: the proj GEMM in front of the plain MLP kernels)
+    h.set_option("bf16_readout", 1 if fused == 1 else 0)    # (the read-out's products on the bf16 pipe, or the fp32 path's kernel)
     assert h.get_option("bf16_proj_mlp") == (1 if (pipe and fused == 1) else 0)
     assert h.get_option("bf16_mlp") == (fused if pipe else 0)
     assert h.get_option("bf16_qkv_attn") == (1 if (pipe and fused == 1) else 0)
