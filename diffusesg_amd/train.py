@@ -9,7 +9,8 @@ Same constructor kwargs, call signatures and return conventions as the reference
 `NodeAdjRainbowLossHip.backward` -> `dsg_rainbow_loss_backward` (loss -> preconditioned outputs -> raw network outputs, every
 `iou_loss_type` of the trainer) and the whole training iteration --
 `train_step_grads` (network in training form, loss, backward to every parameter: `dsg_train_step_grads`), `AdamHip` (clip + Adam:
-`dsg_adam_step`), `EMAHip` (`dsg_ema_update`; parity unpinned), `train_one_iteration`; gradients all-reduce through
+`dsg_adam_step`), `ExponentialLRHip` (the scheduler `get_optimizer` returns beside it), `EMAHip` (`dsg_ema_update`; parity unpinned),
+`train_one_iteration`; gradients all-reduce through
 `diffusesg_amd.dist.all_reduce_mean`.  The kernels are plain fp32 (csrc/train_kernels.hip), not the sampling path's MFMA kernels.
 """
 from __future__ import annotations
@@ -348,6 +349,30 @@ class AdamHip(object):
 
     def zero_grad(self, set_to_none=True):
         pass   # gradients are returned fresh by every train_step_grads call
+
+
+class ExponentialLRHip(object):
+    """`torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=config.train.lr_dacey)` as `get_optimizer` pairs it with the optimiser
+    (utils/learning_utils.py:142) and the epoch loop steps it once per epoch (trainer_node_adj.py:233): after `k` calls of `step()` the
+    learning rate is lr_init * gamma**k (torch's closed form; `get_last_lr()` as torch returns it)."""
+
+    def __init__(self, optimizer, gamma):
+        self.optimizer, self.gamma = optimizer, float(gamma)
+        self.base_lr, self.last_epoch = float(optimizer.lr), 0
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.lr = self.base_lr * self.gamma ** self.last_epoch
+
+    def get_last_lr(self):
+        return [self.optimizer.lr]
+
+    def state_dict(self):
+        return {"gamma": self.gamma, "base_lrs": [self.base_lr], "last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.gamma, self.base_lr, self.last_epoch = float(sd["gamma"]), float(sd["base_lrs"][0]), int(sd["last_epoch"])
+        self.optimizer.lr = self.base_lr * self.gamma ** self.last_epoch
 
 
 class EMAHip(object):

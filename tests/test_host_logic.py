@@ -388,3 +388,27 @@ def test_ema_decay_schedule_restated_from_ema_pytorch():
         seen.append(e.get_current_decay())
     assert seen[0] == 0.0 and seen[1] == 0.5 and abs(seen[2] - 2.0 / 3.0) < 1e-12
     assert seen[-1] == 0.9 and all(b >= a for a, b in zip(seen, seen[1:]))
+
+
+def test_exponential_lr_matches_torch():
+    """ExponentialLRHip against torch.optim.lr_scheduler.ExponentialLR (what get_optimizer pairs with Adam, learning_utils.py:142) over 12
+    epochs, and through a state_dict round trip"""
+    from diffusesg_amd.train import ExponentialLRHip
+
+    class _Opt:   # AdamHip's only attribute the scheduler touches
+        lr = 2.0e-4
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.Adam([p], lr=2.0e-4)
+    tsch = torch.optim.lr_scheduler.ExponentialLR(topt, gamma=0.97)
+    o = _Opt()
+    sch = ExponentialLRHip(o, gamma=0.97)
+    for ep in range(12):
+        topt.step()
+        tsch.step(); sch.step()
+        assert abs(o.lr - topt.param_groups[0]["lr"]) <= 1e-12 * 2.0e-4 + 1e-18, ep
+        assert abs(sch.get_last_lr()[0] - tsch.get_last_lr()[0]) <= 1e-15
+        if ep == 5:
+            o2 = _Opt()
+            sch2 = ExponentialLRHip(o2, gamma=0.5)
+            sch2.load_state_dict(sch.state_dict())
+            assert o2.lr == o.lr and sch2.last_epoch == 6
