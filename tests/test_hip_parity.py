@@ -1149,7 +1149,7 @@ def test_training_step_gradients_vs_reference_autograd(case, cfg_name, B, max_sa
     to loss.backward() -- objective, self-conditioning coin, the network in training form, the sigma-weighted loss with the IoU term
     -- against dsg_train_step_grads: the preconditioned outputs, the loss, and the gradient of EVERY parameter (95 tensors of the tiny
     model, 233 of the Visual Genome model, 314 of the COCO-Stuff model: L2 norm and a strided sample each) plus the total gradient norm clip_grad_norm_ reports.
-    `tinysc` / `vg`: the coin fires, the detached self-conditioning pass (sampling path) feeds the differentiated one."""
+    `tinysc` / `vg`: the coin fires, the detached self-conditioning pass (training form too: dsg_train_self_cond) feeds the differentiated one."""
     from diffusesg_amd.model import build_network
     from diffusesg_amd.train import NodeAdjEDMObjectiveGeneratorHip, NodeAdjRainbowLossHip, train_step_grads
     g = load("train_backward.npz")
