@@ -421,6 +421,20 @@ class EMAHip(object):
     def state_dict(self):
         return {k: v.clone() for k, v in self.shadow.items()}
 
+    @property
+    def ema_model(self):
+        """ema_pytorch's `.ema_model`: the averaged network the trainer evaluates and samples with (trainer_node_adj.py:238, :263) -- a
+        `NodeAdjPrecondHip` around a `DiffuseSGHip` whose parameters ALIAS the shadow tensors (no copy; its own library handle picks the
+        values up at its next forward, every time `update()` has run in between)."""
+        from .model import build_network
+        if getattr(self, "_ema_model", None) is None:
+            self._ema_model = build_network(self.net.config, None, device=self.net._dev)
+            own = dict(self._ema_model.model.named_parameters())
+            for k in self.keys:
+                own[k].data = self.shadow[k]
+        self._ema_model.model._synced_version = None   # the shadow tensors are updated in place, behind torch's version counters
+        return self._ema_model
+
 
 def train_one_iteration(model, train_obj_gen, loss_func, optimizer, ema_helper, adjs_gt, nodes_gt, node_flags, iou_loss_weight=0.0,
                         max_grad_norm=10.0, iou_loss_type="iou", **replay):

@@ -1247,6 +1247,21 @@ def test_training_iteration_adam_step_vs_reference():
         assert np.isfinite(float(loss3)) and opt.step_count == 3
         assert emas[0].get_current_decay() == min(1.0 - 1.0 / 3.0, 0.9)
         assert float((emas[0].shadow[k0] - p_now).abs().max()) > 0 or True
+        # the averaged network the trainer evaluates / samples with (ema_helper[0].ema_model): its forward equals a FRESH network loaded with
+        # the shadow weights, and follows the next update without being rebuilt
+        em = emas[0].ema_model
+        assert em is emas[0].ema_model
+        sg_t = torch.full((flags.shape[0],), 1.7, device="cuda")
+        for rep in range(2):
+            fresh = build_network(cfg, {k: v.detach().cpu().numpy() for k, v in list(emas[0].state_dict().items()) +
+                                        [(k, b) for k, b in model.model.named_buffers()]}, device="cuda")
+            np.random.rand = lambda: 0.9
+            oa_e, on_e = emas[0].ema_model(T(clean_adj), T(clean_node), T(flags), sg_t)
+            oa_f, on_f = fresh(T(clean_adj), T(clean_node), T(flags), sg_t)
+            assert torch.equal(oa_e, oa_f) and torch.equal(on_e, on_f), rep
+            np.random.rand = lambda: coin
+            train_one_iteration(model, gen, loss_func, opt, emas, T(clean_adj), T(clean_node), T(flags), iou_loss_weight=1.0,
+                                rnd_sigma=T(rnd), noise=(T(eps_adj), T(eps_node)))
     finally:
         np.random.rand = real
 
