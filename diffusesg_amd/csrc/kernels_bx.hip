@@ -557,18 +557,22 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
     for (int ct = 0; ct < CT; ct++)
 #pragma unroll
         for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
+    // Staging schedule (proj chunks, then hidden chunks: items 0, 1, ... alternate between the two stage buffers): ONE register set, the
+    // item after next requested as soon as the next one has been written to LDS, and that write placed AFTER the barrier -- a wave that
+    // reaches the barrier never waits for global loads in front of it, and a request has a whole item's products + the barrier to land.
+    //   barrier | write item i + 1 (registers -> the buffer item i - 1 was read from) | request item i + 2 | products of item i
     if (PROJ) {
         write_p(0);
-        __syncthreads();
+        if (CT > 1) issue_p(1); else issue(0);
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
-            if (ct + 1 < CT) issue_p(ct + 1); else issue(0);
+            __syncthreads();
+            if (ct + 1 < CT) write_p((ct + 1) & 1); else write(CT & 1);
+            if (ct + 2 < CT) issue_p(ct + 2); else if (ct + 2 - CT < NCH) issue(ct + 2 - CT);
             const __bf16 *wps = lds + (ct & 1) * STAGE;
 #pragma unroll
             for (int s = 0; s < KS; s++)
                 oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(wps + lrow * LD1 + 16 * s + 8 * lhalf), xf[s], oacc[ct], 0, 0, 0);
-            if (ct + 1 < CT) write_p((ct + 1) & 1); else write(CT & 1);
-            __syncthreads();
         }
         // x1 = x + proj + bp (the shortcut and fc2's initial value), LayerNorm-2 of it -> fc1's B operand
         const rsrc_t rsXi = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
@@ -601,11 +605,15 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
         }
     } else {
         write(0);
-        __syncthreads();
+        issue(1);
     }
     for (int hc = 0; hc < NCH; hc++) {
         const int cur = (hc + (PROJ ? CT : 0)) & 1;
-        if (hc + 1 < NCH) issue(hc + 1);
+        __syncthreads();
+        if (hc + 1 < NCH) {
+            write(1 - cur);                     // chunk hc + 1 (requested one item ago; PROJ: chunk 1 by the last proj item)
+            if (hc + 2 < NCH) issue(hc + 2);
+        }
         const __bf16 *w1s = lds + cur * STAGE, *w2s = w1s + 32 * LD1;
         const float *b1s = reinterpret_cast<const float *>(w2s + C * LD2);
         f32x16 hacc;
@@ -623,9 +631,8 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
             for (int s2i = 0; s2i < 2; s2i++)
                 oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w2s + (32 * ct + lrow) * LD2 + 16 * s2i + 8 * lhalf),
                                                                    __builtin_bit_cast(bf16x8, hf[s2i]), oacc[ct], 0, 0, 0);
-        if (hc + 1 < NCH) write(1 - cur);
-        __syncthreads();
     }
+    __syncthreads();   // the stages are free for the output transposition
     // ---- epilogue: lane (token, half) holds channels 32 ct + 8 q + 4 half + {0..3} in oacc[ct][4 q ..]
     const rsrc_t rsX = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
     __bf16 *xo = static_cast<__bf16 *>(g.xn_out);
