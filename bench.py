@@ -306,7 +306,8 @@ def worker(args):
                         traffic_src = f"profiles/{rnd}/{fname} (committed rocprofv3 --pmc passes of this command from an earlier run of this build's kernels, not this process)"
         # peak of the pipe the dominant kernel runs on, in ALGORITHMIC (2*M*N*K) FLOP/s: the split kernel issues six bf16
         # MFMA products per algorithmic product, so its ceiling is the bf16 dense peak / 6
-        bf16_kern = ("mlp384_bx_kernel + mlp_bx_kernel (proj + MLP half of a Swin block)" if bx_pipe else
+        bf16_kern = ("mlp384_bx_kernel + mlp_bx_kernel (proj + MLP half of a Swin block; the class's brackets also hold the PatchEmbed and "
+                     "read-out launches, 2 of 20 on COCO)" if bx_pipe else
                      ("gemm_bx_kernel" if (mode == "bf16" and h.get_option("bf16_pipe")) else "gemm_bf16_kernel"))
         kern, peak = {"f32": ("gemm4_f32_kernel", PEAK_F32_MFMA_TFLOPS), "bf16": (bf16_kern, PEAK_BF16_MFMA_TFLOPS),
                       "f32-split": ("gemm_split2_kernel", PEAK_BF16_MFMA_TFLOPS / 6.0)}[mode]
