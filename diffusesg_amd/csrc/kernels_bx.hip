@@ -1267,7 +1267,8 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
     constexpr int KB = 64, LDP = KB + 8, Wp = 32 * KT, Wt = WS * WS, UPB = 4 / KT, KLD = 40, VLD = Wp + 8;
     constexpr int STAGE = (128 + 96) * LDP, OLD = 40;
     static_assert(128 * KLD + UPB * 32 * VLD <= STAGE, "k / v^T live in the tile stage after the K loop");
-    __shared__ __attribute__((aligned(16))) __bf16 lds[STAGE];
+    __shared__ __attribute__((aligned(16))) __bf16 lds[STAGE + 2 * 96];
+    float *colv = reinterpret_cast<float *>(lds + STAGE);      // the head's 96 bias values (q | k | v)
     __bf16 *kl = lds, *vtl = lds + 128 * KLD;
     const unsigned OOB = 0x7fffffffu;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1312,17 +1313,11 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
 #pragma unroll
         for (int p = 0; p < 3; p++) *reinterpret_cast<u32x4 *>(lds + (128 + sr + 32 * p) * LDP + 8 * sc) = st.w[p];
     };
-    // the accumulators start at the head's bias (register r of tile nt <-> feature 32 nt + (r & 3) + 8 (r >> 2) + 4 half of q | k | v):
-    // no bias pass, no LDS staging of it and no barrier for it after the K loop
     f32x16 acc[3];
 #pragma unroll
     for (int nt = 0; nt < 3; nt++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(a.bias + nt * C + head * 32 + 8 * q + 4 * lhalf);
-#pragma unroll
-            for (int e = 0; e < 4; e++) acc[nt][4 * q + e] = b4[e];
-        }
+        for (int r = 0; r < 16; r++) acc[nt][r] = 0.f;
     const __bf16 *Afr = lds + (32 * wave + lrow) * LDP + 8 * lhalf;
     const __bf16 *Wfr = lds + (128 + lrow) * LDP + 8 * lhalf;
     auto compute = [&]() {
@@ -1339,6 +1334,8 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
     Stage s0, s1;
     issue(s0, 0);
     issue(s1, 1);
+    float cvb = 0.f;
+    if (tid < 96) cvb = a.bias[(tid >> 5) * C + head * 32 + (tid & 31)];
     write(s0);
     __syncthreads();
     for (int kc = 0; kc < nk; kc += 2) {   // LDS holds chunk kc, s1 holds chunk kc + 1, s0 is free
@@ -1363,6 +1360,16 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
     u32x4 bb[KT][2];
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) { bb[kt][0] = bp[2 * kt]; bb[kt][1] = bp[2 * kt + 1]; }
+    if (tid < 96) colv[tid] = cvb;
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 3; nt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(colv + 32 * nt + 8 * q + 4 * lhalf);
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[nt][4 * q + e] += b4[e];
+        }
     bf16x8 qf[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
