@@ -126,7 +126,8 @@ def test_attn_bx_vs_torch(B, res, ws, shift, heads):
 
 
 @pytest.mark.parametrize("B,res,ws,shift,heads", [(3, 10, 10, 0, 12), (5, 20, 10, 5, 6), (2, 40, 10, 0, 3), (4, 16, 8, 4, 12), (3, 8, 8, 0, 24),
-                                                  (5, 16, 8, 0, 3), (2, 16, 4, 2, 3), (7, 4, 4, 0, 6), (3, 10, 5, 2, 3)])
+                                                  (5, 16, 8, 0, 3), (2, 16, 4, 2, 3), (7, 4, 4, 0, 6), (3, 10, 5, 2, 3),
+                                                  (48, 20, 10, 5, 6), (41, 16, 8, 4, 12)])   # > 512 (window group, head) tiles
 def test_qkv_attn_bx_vs_torch(B, res, ws, shift, heads):
     """QKV projection + window attention in one kernel against fp64 on the bf16-rounded operands: q, k, v are formed in fp32, rounded
     to bf16 (as the kernel hands them to the second and third product) and then follow test_attn_bx_vs_torch's reference.  Odd unit
