@@ -21,6 +21,7 @@
 #include <functional>
 #include <unordered_map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "kernels.h"
@@ -90,6 +91,7 @@ struct Workspace {
     // per (self-cond slot, output slots, Euler/Heun update, coin of stage 1, coin of stage 2) combination that occurs
     RunCtl *ctl = nullptr;
     std::map<int, std::pair<hipGraphExec_t, int>> step_graphs;   // key -> (exec, network forwards inside)
+    long plan_gen = -1;   // h->plan_gen this workspace's launch plan was last validated against (validate_plan)
 };
 
 struct Tap { std::string name; float *dst; int64_t cap; };
@@ -104,6 +106,12 @@ struct dsg_handle_s {
     bool finalized = false;
     bool ever_finalized = false;                                  // block plans exist and every weight has been set at least once (training entries read raw weights only)
     std::string err;
+    // first launch of the current forward whose shape / argument combination no kernel covers ("" = none).  Filled by the launch
+    // wrappers below instead of terminating the process; validate_plan() walks a whole forward in a dry run (kernels.h: g_dry_run)
+    // when a batch size is first used and whenever an option changes, so the entry points return DSG_ERR_INVALID before any work
+    // is enqueued or captured
+    std::string plan_err;
+    long plan_gen = 0;   // bumped by everything that changes which kernels a forward launches (options, weights, debug taps)
     // derived
     std::vector<BlockPlan> down[DSG_MAX_LAYERS], up[DSG_MAX_LAYERS];
     float *aff_w = nullptr, *aff_b = nullptr;  // concatenated affine linears [aff_n, 512]
@@ -176,6 +184,17 @@ int fail(dsg_handle h, int code, const char *fmt, ...) {
     return code;
 }
 
+// a launcher declined its arguments: remember the first one of this forward (layer / shape in the message)
+void plan_fail(dsg_handle h, const char *fmt, ...) {
+    if (!h->plan_err.empty()) return;
+    char buf[384];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    h->plan_err = buf;
+}
+
 #define HIP_TRY(h, expr)                                                                          \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \
@@ -207,6 +226,7 @@ struct ProfScope {
 
 // captured graphs bake weight pointers, kernel selection and table addresses: drop them whenever one of those changes
 void drop_graphs(dsg_handle h) {
+    h->plan_gen++;   // ... and the launch plans are validated again before their next use (validate_plan)
     for (auto &kv : h->ws) {
         Workspace *w = kv.second.get();
         if (w->graph) { (void)hipGraphExecDestroy(w->graph); w->graph = nullptr; }
@@ -515,17 +535,21 @@ bool env_on(const char *name, bool dflt) {
 
 extern "C" {
 
-const char *dsg_version(void) { return "dsg-gfx950 0.1 (fp32 MFMA)"; }
+const char *dsg_version(void) { return "dsg-gfx950 0.4 (fp32 MFMA; ABI 4)"; }
+int32_t dsg_abi_version(void) { return DSG_ABI_VERSION; }
+// dsg_last_error(NULL): why the last dsg_create on this thread failed (there is no handle to ask then)
+static thread_local std::string g_create_err;
 
 int dsg_create(const dsg_config *cfg, dsg_handle *out) {
-    if (!cfg || !out) return DSG_ERR_INVALID;
+    if (!cfg || !out) { g_create_err = "dsg_create: null argument"; return DSG_ERR_INVALID; }
     *out = nullptr;
+    g_create_err.clear();
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return DSG_ERR_HIP;  // no CPU fallback
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "dsg_create: no HIP device (there is no CPU path)"; return DSG_ERR_HIP; }
     auto h = new dsg_handle_s();
     h->cfg = *cfg;
     h->N = cfg->max_node_num; h->Ca = cfg->c_adj; h->Cn = cfg->c_node; h->E = cfg->embed_dim; h->L = cfg->num_layers;
-    auto bad = [&](const char *m) { delete h; (void)m; return DSG_ERR_INVALID; };
+    auto bad = [&](const char *m) { delete h; g_create_err = std::string("dsg_create: ") + m; return DSG_ERR_INVALID; };
     if (h->L < 1 || h->L > DSG_MAX_LAYERS) return bad("num_layers");
     if (h->E % 32 != 0 || h->E < 64) return bad("embed_dim must be a multiple of 32");
     if (cfg->mlp_ratio < 1 || h->N < 1 || h->Ca < 1 || h->Cn < 1) return bad("sizes");
@@ -580,7 +604,7 @@ void dsg_destroy(dsg_handle h) {
     delete h;
 }
 
-const char *dsg_last_error(dsg_handle h) { return h ? h->err.c_str() : "null handle"; }
+const char *dsg_last_error(dsg_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 int dsg_num_weight_keys(dsg_handle h) { return h ? (int)h->specs.size() : 0; }
 const char *dsg_weight_key(dsg_handle h, int32_t i) {
@@ -837,9 +861,10 @@ size_t per_sample_floats(dsg_handle h, std::vector<size_t> *parts = nullptr) {
     return tot;
 }
 
+int validate_plan(dsg_handle h, Workspace *w);
 int get_workspace(dsg_handle h, int B, Workspace **out) {
     auto it = h->ws.find(B);
-    if (it != h->ws.end()) { *out = it->second.get(); return 0; }
+    if (it != h->ws.end()) { *out = it->second.get(); return validate_plan(h, *out); }
     auto w = std::make_unique<Workspace>();
     w->B = B;
     const size_t T0 = (size_t)h->N * h->N, E = h->E;
@@ -876,10 +901,11 @@ int get_workspace(dsg_handle h, int B, Workspace **out) {
     w->ctl = (RunCtl *)q;
     *out = w.get();
     h->ws[B] = std::move(w);
-    return 0;
+    return validate_plan(h, *out);
 }
 
 void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStream_t s) {
+    if (g_dry_run) return;
     for (auto &t : h->taps)
         if (t.name == name && (int64_t)numel <= t.cap)
             (void)hipMemcpyAsync(t.dst, src, sizeof(float) * numel, hipMemcpyDeviceToDevice, s);
@@ -893,7 +919,8 @@ void tap(dsg_handle h, const char *name, const float *src, size_t numel, hipStre
 #define P_GEMM(g) do { (g).Ws3 = split_of(h, (g).W); (g).Wb = nullptr; P_GEMM_(g); } while (0)
 #define P_GEMM_(g) do { char tg_[96]; if (h->prof_stamps && h->prof_gemm && h->prof_gemm_used < h->prof_gemm_cap) (g).prof = h->prof_gemm + 4 * (h->prof_gemm_used++); else (g).prof = nullptr; \
     if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm M=%d N=%d K=%d ln=%d act=%d res=%d", (g).M, (g).N, (g).K, ((g).ln_stats != nullptr) + 2 * ((g).ln_part != nullptr) + 4 * ((g).stats_out != nullptr) + 8 * ((g).mod_aff != nullptr), (g).act, (g).res != nullptr); \
-    ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)(g).M * (double)(g).N * (double)(g).K, tg_); launch_gemm((g), s); } while (0)
+    ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)(g).M * (double)(g).N * (double)(g).K, tg_); \
+    if (!launch_gemm((g), s)) plan_fail(h, "gemm: argument combination not built (M=%d N=%d K=%d ln=%d act=%d res=%d bf16 A/C=%d/%d)", (g).M, (g).N, (g).K, ((g).ln_stats != nullptr) + 2 * ((g).ln_part != nullptr), (g).act, (g).res != nullptr, (g).a_bf16, (g).c_bf16); } while (0)
 #define P_KERN(kind, flops, call) do { ProfScope ps_(h, s, (kind), (flops), #call); call; } while (0)
 
 // Row-kernel fusion (fp32 GEMM kernel only; off while debug taps want the un-modulated block outputs): the GEMM that produces
@@ -961,7 +988,8 @@ BlockOut run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, 
             g.c_bf16 = qkv_bf16;
             P_GEMM_LP(g);
             P_KERN(PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C,
-                   launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s, att_bf16, qkv_bf16));
+                   if (!launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s, att_bf16, qkv_bf16))
+                       plan_fail(h, "%s: window attention not built (window %d, C=%d, bf16 in/out=%d/%d)", p.c_str(), b.ws, C, qkv_bf16, att_bf16));
         }
         g = GemmArgs();
         g.A = w->att; g.lda = C; g.K1 = C; g.K = C; g.M = M; g.N = C;
@@ -1045,7 +1073,8 @@ bool patch_embed_stage(dsg_handle h, Workspace *w, bool fp32_rule, hipStream_t s
         g = GemmArgs();
         g.A = w->tok_in; g.lda = h->Kp; g.K1 = h->Kp; g.K = h->Kp; g.M = B * T0; g.N = E;
         g.W = h->pe_w; g.bias = WT(h, "patch_embed.proj.bias"); g.C = w->y; g.ldc = E;
-        P_KERN(PK_GEMM, 2.0 * (double)g.M * (double)g.N * (double)h->Cin, launch_gemm(g, s));  // padded K is not algorithmic work
+        P_KERN(PK_GEMM, 2.0 * (double)g.M * (double)g.N * (double)h->Cin,   // padded K is not algorithmic work
+               if (!launch_gemm(g, s)) plan_fail(h, "patch_embed.proj: GEMM not built (M=%d N=%d K=%d)", g.M, g.N, g.K));
         P_KERN(PK_ROW, 0.0, launch_ln_mod(w->y, WT(h, "patch_embed.norm.weight"), WT(h, "patch_embed.norm.bias"), w->aff, w->aff_ld, h->pe_aff_off,
                       w->x, B, T0, E, s));
     }
@@ -1120,7 +1149,7 @@ bool bx_on(dsg_handle h) { return h->opt_gemm_bf16 && !h->opt_gemm_split && h->o
         char tg_[96];                                                                                                          \
         if (h->prof_on) snprintf(tg_, sizeof(tg_), "gemm_bx %s M=%d N=%d K=%d ln=%d", tag, (g).M, (g).N, (g).K, (g).ln_out);   \
         ProfScope ps_(h, s, PK_GEMM, 2.0 * (double)(g).M * (double)(g).N * (double)(g).K, tg_);                               \
-        if (!launch_gemm_bx((g), s)) { fprintf(stderr, "dsg: gemm_bx: shape not covered (%s M=%d N=%d K=%d)\n", tag, (g).M, (g).N, (g).K); abort(); } \
+        if (!launch_gemm_bx((g), s)) plan_fail(h, "bf16 pipeline: gemm_bx shape not covered (%s M=%d N=%d K=%d K1=%d ln=%d)", tag, (g).M, (g).N, (g).K, (g).K1, (g).ln_out); \
     } while (0)
 
 bool bx_full_row(int C) { return C == 96 || C == 192 || C == 384; }   // widths a single GEMM tile spans: LayerNorm in the epilogue
@@ -1160,7 +1189,8 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
         g.W = bf16_of(h, b.qkv_wf); g.bias = b.qkv_bf; g.Cb = w->qkv; g.ldcb = 3 * C;
         P_BX(g, "qkv");
         ProfScope ps_(h, s, PK_ATTN, 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, "attn_bx");
-        if (!launch_attn_bx(w->qkv, b.biasT, w->att, B, wg, s)) launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s, true, true);
+        if (!launch_attn_bx(w->qkv, b.biasT, w->att, B, wg, s) && !launch_window_attn(w->qkv, b.biasT, w->att, B, wg, s, true, true))
+            plan_fail(h, "bf16 pipeline: %s: window attention not built (window %d, C=%d)", p.c_str(), b.ws, C);
     }
     // the fused MLP kernel can take the proj linear, the residual and LayerNorm-2 in front (x + proj(att) never goes to HBM)
     const bool mlp_fused = h->opt_bf16_mlp && h->cfg.mlp_ratio == 4 && (C == 96 || C == 192 || (C == 384 && h->opt_bf16_mlp != 3));
@@ -1191,7 +1221,7 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
             m.xn_out = w->xn; m.out_mode = 1; out = BX_READY;
         } else if (!next && want_copy) { m.xn_out = w->xn; m.out_mode = 2; }
         ProfScope ps_(h, s, PK_FUSED, 4.0 * (double)M * (double)C * (double)Hd + (proj_in_mlp ? 2.0 * (double)M * C * C : 0.0), proj_in_mlp ? "proj_mlp_bx" : "mlp_bx");
-        if (!launch_mlp_bx(m, s)) { fprintf(stderr, "dsg: mlp_bx: shape not covered (M=%d C=%d)\n", M, C); abort(); }
+        if (!launch_mlp_bx(m, s)) plan_fail(h, "bf16 pipeline: %s: fused MLP shape not covered (M=%d C=%d proj=%d)", p.c_str(), M, C, (int)proj_in_mlp);
         return out;
     }
     g = BxGemm();
@@ -1367,9 +1397,43 @@ void forward_fixed(dsg_handle h, Workspace *w, hipStream_t s) {
     readout_stage(h, w, s);
 }
 
+// DSG_ERR_INVALID (and the message) if a launcher declined its arguments since the last check
+int plan_status(dsg_handle h, Workspace *w) {
+    if (h->plan_err.empty()) return 0;
+    const std::string m = h->plan_err;
+    h->plan_err.clear();
+    return fail(h, DSG_ERR_INVALID, "unsupported configuration at batch %d: %s", w->B, m.c_str());
+}
+
+// Plan-time shape coverage: walk the whole forward of this workspace's batch size in a dry run -- every launcher checks its arguments
+// and picks its instantiation, nothing is enqueued (kernels.h: g_dry_run) -- in both noise-label forms (per-sample rows: dsg_denoise /
+// dsg_precond; the sampler's batch-uniform row) and with / without a self-conditioning input.  Runs when a batch size is first used and
+// again after anything that changes the kernel selection (dsg_set_option, dsg_finalize_weights, debug taps): an uncovered shape is
+// reported as DSG_ERR_INVALID by the entry point before any work is enqueued or captured -- never by terminating the process.
+int validate_plan(dsg_handle h, Workspace *w) {
+    if (w->plan_gen == h->plan_gen) return 0;
+    const bool uni = w->uniform, prof_on = h->prof_on, prof_stamps = h->prof_stamps;
+    const float *sca = w->cur_sc_adj, *scn = w->cur_sc_node; const int *hs = w->cur_has_sc;
+    h->prof_on = false; h->prof_stamps = false;
+    h->plan_err.clear();
+    g_dry_run = true;
+    for (int v = 0; v < 4; v++) {
+        w->uniform = (v & 1) != 0;
+        w->cur_sc_adj = (v & 2) ? w->sc_adj : nullptr; w->cur_sc_node = (v & 2) ? w->sc_node : nullptr; w->cur_has_sc = (v & 1) ? nullptr : w->has_sc;
+        forward_fixed(h, w, nullptr);
+    }
+    g_dry_run = false;
+    w->uniform = uni; h->prof_on = prof_on; h->prof_stamps = prof_stamps;
+    w->cur_sc_adj = sca; w->cur_sc_node = scn; w->cur_has_sc = hs;
+    if (int rc = plan_status(h, w)) return rc;
+    w->plan_gen = h->plan_gen;
+    return 0;
+}
+
 // run forward_fixed either eagerly or by replaying a captured graph
 int run_forward(dsg_handle h, Workspace *w, bool use_graph, hipStream_t s) {
-    if (!use_graph || !h->taps.empty()) { forward_fixed(h, w, s); return 0; }
+    // (plan_err: validate_plan has already walked this forward in a dry run, so these checks are the second line of defence)
+    if (!use_graph || !h->taps.empty()) { forward_fixed(h, w, s); return plan_status(h, w); }
     hipGraphExec_t &exec = w->uniform ? w->graph_uniform : w->graph;
     if (!exec) {
         if (!w->cap_stream) HIP_TRY(h, hipStreamCreateWithFlags(&w->cap_stream, hipStreamNonBlocking));
@@ -1377,6 +1441,7 @@ int run_forward(dsg_handle h, Workspace *w, bool use_graph, hipStream_t s) {
         HIP_TRY(h, hipStreamBeginCapture(w->cap_stream, hipStreamCaptureModeThreadLocal));
         forward_fixed(h, w, w->cap_stream);
         HIP_TRY(h, hipStreamEndCapture(w->cap_stream, &graph));
+        if (int rc = plan_status(h, w)) { (void)hipGraphDestroy(graph); return rc; }
         hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         if (e != hipSuccess) { exec = nullptr; return fail(h, DSG_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
@@ -1512,7 +1577,7 @@ int ensure_step_graph(dsg_handle h, Workspace *w, const StepPlan &p) {
     HIP_TRY(h, hipStreamBeginCapture(w->cap_stream, hipStreamCaptureModeThreadLocal));
     const int rc = enqueue_step(h, w, p, nullptr, nullptr, w->cap_stream, &n);
     const hipError_t ec = hipStreamEndCapture(w->cap_stream, &graph);
-    if (rc) return rc;
+    if (rc) { if (ec == hipSuccess) (void)hipGraphDestroy(graph); return rc; }
     if (ec != hipSuccess) return fail(h, DSG_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ec));
     hipGraphExec_t exec = nullptr;
     const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -1546,6 +1611,13 @@ size_t dsg_workspace_bytes(dsg_handle h, int32_t B) {
 int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     if (!h || !name) return DSG_ERR_INVALID;
     const std::string n(name);
+    // the option set as it stands: restored if the new selection meets a shape no kernel covers (below)
+    auto opts = [h]() {
+        return std::tie(h->opt_fused_attn, h->opt_fused_mlp, h->opt_fused_mlp_maxc, h->opt_fused_readout, h->opt_fused_pe, h->opt_fused_rowstats,
+                        h->opt_fused_qkv_attn, h->opt_loop_graph, h->opt_bf16_act, h->opt_bf16_pipe, h->opt_bf16_mlp, h->opt_bf16_qkv_attn,
+                        h->opt_bf16_proj_mlp, h->opt_bf16_readout, h->opt_fused_merge, h->opt_fused_merge_small, h->opt_gemm_bf16, h->opt_gemm_split);
+    };
+    const std::tuple<bool, bool, int, bool, bool, bool, bool, bool, int, bool, int, bool, bool, bool, bool, bool, bool, bool> saved = opts();
     if (n == "fused_attn") h->opt_fused_attn = value != 0;
     else if (n == "fused_mlp") h->opt_fused_mlp = value != 0;
     else if (n == "fused_mlp_maxc") h->opt_fused_mlp_maxc = value;
@@ -1571,6 +1643,16 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     }
     else return fail(h, DSG_ERR_INVALID, "unknown option '%s'", name);
     drop_graphs(h);   // captured graphs bake the kernel selection
+    // plan time: every batch size in use must still be covered by the kernels the new selection launches; if not, the option keeps
+    // its old value and the caller gets DSG_ERR_INVALID with the layer / shape in dsg_last_error
+    if (h->finalized)
+        for (auto &kv : h->ws)
+            if (int rc = validate_plan(h, kv.second.get())) {
+                const std::string why = h->err;
+                opts() = saved;
+                drop_graphs(h);
+                return fail(h, rc, "option '%s' = %d rejected: %s", name, value, why.c_str());
+            }
     return DSG_OK;
 }
 
@@ -1585,7 +1667,7 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "fused_rowstats") *value = h->opt_fused_rowstats;
     else if (n == "fused_qkv_attn") *value = h->opt_fused_qkv_attn;
     else if (n == "loop_graph") *value = h->opt_loop_graph;
-    else if (n == "bf16_act") *value = (h->opt_gemm_bf16 && !h->opt_gemm_split && !h->opt_bf16_pipe) ? h->opt_bf16_act : 0;   // acts in round 2's bf16 path only
+    else if (n == "bf16_act") *value = (h->opt_gemm_bf16 && !h->opt_gemm_split && !bx_on(h)) ? h->opt_bf16_act : 0;   // acts whenever round 2's bf16 path is what runs (pipeline off, or a width it does not take)
     else if (n == "bf16_pipe") *value = bx_on(h);   // the bf16 block pipeline runs (bf16 mode only)
     else if (n == "bf16_mlp") *value = bx_on(h) ? h->opt_bf16_mlp : 0;
     else if (n == "bf16_qkv_attn") *value = (bx_on(h) && h->opt_bf16_qkv_attn) ? 1 : 0;
@@ -1611,9 +1693,10 @@ int dsg_gen_noise(dsg_handle h, int32_t B, const uint8_t *flags, uint64_t seed, 
 int dsg_debug_tap(dsg_handle h, const char *stage, float *dst, int64_t capacity) {
     if (!h || !stage || !dst) return DSG_ERR_INVALID;
     h->taps.push_back({stage, dst, capacity});
+    h->plan_gen++;   // taps switch the row-kernel fusions off: the launch plan changes
     return DSG_OK;
 }
-void dsg_debug_clear_taps(dsg_handle h) { if (h) h->taps.clear(); }
+void dsg_debug_clear_taps(dsg_handle h) { if (h) { h->taps.clear(); h->plan_gen++; } }
 
 int dsg_denoise(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, const float *noise_labels,
                 const float *sc_adj, const float *sc_node, float *out_adj, float *out_node, void *stream) {
@@ -1880,9 +1963,10 @@ int dsg_debug_gemm(int32_t M, int32_t N, int32_t K, const float *A, const float 
     g.C = C; g.ldc = N;
     if (mode == 1) g.Wb = wlp;
     if (mode == 2) g.Ws3 = wlp;
-    launch_gemm(g, s);
+    const bool built = launch_gemm(g, s);
     const hipError_t e = hipStreamSynchronize(s);
     if (wlp) (void)hipFree(wlp);
+    if (!built) return DSG_ERR_INVALID;
     return (e == hipSuccess && hipGetLastError() == hipSuccess) ? DSG_OK : DSG_ERR_HIP;
 }
 

@@ -5,6 +5,11 @@
 
 namespace dsg {
 
+// Plan validation (dsg_api.cpp: validate_plan): while this is set on the calling thread, every launcher of the forward path checks
+// its arguments and picks its kernel as usual but launches nothing.  A launcher that does not cover a shape returns false -- it never
+// terminates the process; the host turns that into DSG_ERR_INVALID at plan time (first use of a batch size / dsg_set_option).
+extern thread_local bool g_dry_run;
+
 enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2,
            // training-form products of the fp32 GEMM only (launch_gemm): GELU whose pre-activation is kept in C2 (the backward needs it);
            // the product multiplied by GELU'(res) -- `res` is that kept pre-activation (the backward through fc2 and the GELU in one pass)
@@ -60,7 +65,7 @@ struct GemmArgs {
     const float *gelu_tab = nullptr;             // filled in by launch_gemm (table-driven GELU of the split kernel)
     unsigned long long *prof = nullptr;          // measurement mode: {min block start, max block end} in 100 MHz ticks
 };
-void launch_gemm(const GemmArgs &g, hipStream_t s);
+bool launch_gemm(const GemmArgs &g, hipStream_t s);   // false: the argument combination is not built (nothing launched)
 // fused LN1 -> QKV -> window attention for 64-token windows (fp32 kernel); returns false if the geometry is not supported
 bool launch_gemm_qkv_attn(const GemmArgs &g, hipStream_t s);
 void launch_f32_to_bf16(const float *src, void *dst, size_t n, hipStream_t s);
@@ -136,7 +141,7 @@ void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, co
                          const float *bqkv, const float *biasT, const float *Wpp, const float *bproj, int B, const WinGeom &g,
                          bool premod, hipStream_t s);   // premod: x is already modulated by the producing kernel
 // qkv [B*T, 3C] token order -> out [B*T, C] token order; biasT [nWt][heads][Wp][Wp] (key-major)
-void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s, bool out_bf16 = false, bool in_bf16 = false);
+bool launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s, bool out_bf16 = false, bool in_bf16 = false);   // false: not built (nothing launched)
 
 // x <- silu(shift + x*(1+scale)), (scale,shift) = aff[b][off .. off+2C); stats of the new rows
 void launch_mod_stats(float *x, const float *aff, int aff_ld, int aff_off, float *stats, int B, int T, int C, hipStream_t s);

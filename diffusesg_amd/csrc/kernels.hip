@@ -576,38 +576,41 @@ const float *gelu_table() {
     return g_gelu_tab_dev;
 }
 
-void launch_gemm(const GemmArgs &g, hipStream_t s) {
-    if ((g.Ws3 || g.Wb) && launch_gemm_lp(g, s)) return;   // opt-in bf16-MFMA modes (kernels_lp.hip)
-    if (g.a_bf16 || g.c_bf16) { fprintf(stderr, "dsg: launch_gemm: bf16 tensors need the bf16 GEMM kernel\n"); abort(); }
+thread_local bool g_dry_run = false;
+
+// false = this argument combination is not built; nothing has been launched and the caller reports DSG_ERR_INVALID (the host
+// validates a whole forward's launches in a dry run at plan time, so a forward never meets this half-way)
+bool launch_gemm(const GemmArgs &g, hipStream_t s) {
+    if (g.M < 1 || g.N < 1 || g.K < GBK || g.K % GBK != 0 || !g.A || !g.W || !g.C) return false;
+    if ((g.Ws3 || g.Wb) && launch_gemm_lp(g, s)) return true;   // opt-in bf16-MFMA modes (kernels_lp.hip)
+    if (g.a_bf16 || g.c_bf16) return false;   // bf16 tensors need the bf16 GEMM kernel
     const int tiles_m = (g.M + GBM - 1) / GBM, tiles_n = (g.N + GBN - 1) / GBN;
     const dim3 grid(((tiles_m + 7) / 8) * 8 * tiles_n), block(256);
     const bool ln = g.ln_stats != nullptr || g.ln_part != nullptr, res = g.res != nullptr;
     if (g.batch > 1) {   // split-K slices of a training weight-gradient product: plain epilogue only
-        if (ln || res || g.act != ACT_NONE || g.stats_out || g.a4_res > 0 || g.A2 || g.C2 || g.bias) { fprintf(stderr, "dsg: launch_gemm: unsupported batched GEMM\n"); abort(); }
+        if (ln || res || g.act != ACT_NONE || g.stats_out || g.a4_res > 0 || g.A2 || g.C2 || g.bias) return false;
         const dim3 gridb(grid.x * (unsigned)g.batch);
-        hipLaunchKernelGGL((gemm4_f32_kernel<false, ACT_NONE, false, 0, 8, 2>), gridb, block, 0, s, g, tiles_m, tiles_n);
-        return;
+        DSG_LAUNCH((gemm4_f32_kernel<false, ACT_NONE, false, 0, 8, 2>), gridb, block, 0, s, g, tiles_m, tiles_n);
+        return true;
     }
-#define GEMM_CASE(L, A, R) hipLaunchKernelGGL((gemm4_f32_kernel<L, A, R, 0>), grid, block, 0, s, g, tiles_m, tiles_n)
-#define GEMM_EPI(R, E) hipLaunchKernelGGL((gemm4_f32_kernel<false, ACT_NONE, R, E>), grid, block, 0, s, g, tiles_m, tiles_n)
+#define GEMM_CASE(L, A, R) DSG_LAUNCH((gemm4_f32_kernel<L, A, R, 0>), grid, block, 0, s, g, tiles_m, tiles_n)
+#define GEMM_EPI(R, E) DSG_LAUNCH((gemm4_f32_kernel<false, ACT_NONE, R, E>), grid, block, 0, s, g, tiles_m, tiles_n)
     if (g.a4_res > 0) {   // PatchMerging gather + LayerNorm(4C) from partials; epilogue: plain, or premod + stats (dual store allowed)
-        if (!g.ln_part || g.A2 || g.act != ACT_NONE || res || (g.K >> 2) % GBK != 0 || (g.stats_out && !g.mod_aff)) {
-            fprintf(stderr, "dsg: launch_gemm: unsupported PatchMerging-gather GEMM\n"); abort();
-        }
-#define GEMM_MERGE(E) hipLaunchKernelGGL((gemm4_f32_kernel<true, ACT_NONE, false, E, 8, 1>), grid, block, 0, s, g, tiles_m, tiles_n)
+        if (!g.ln_part || g.A2 || g.act != ACT_NONE || res || (g.K >> 2) % GBK != 0 || (g.stats_out && !g.mod_aff)) return false;
+#define GEMM_MERGE(E) DSG_LAUNCH((gemm4_f32_kernel<true, ACT_NONE, false, E, 8, 1>), grid, block, 0, s, g, tiles_m, tiles_n)
         if (!g.stats_out) GEMM_MERGE(0); else if (g.mod_ld == 0) GEMM_MERGE(2); else GEMM_MERGE(3);
 #undef GEMM_MERGE
-        return;
+        return true;
     }
     if (g.stats_out) {   // epilogue extensions: only the shapes the forward uses (plain A path, no activation)
-        if (ln || g.act != ACT_NONE) { fprintf(stderr, "dsg: launch_gemm: stats_out with LN/activation is not built\n"); abort(); }
+        if (ln || g.act != ACT_NONE) return false;   // stats_out with LayerNorm / an activation is not built
         const int epi = !g.mod_aff ? 1 : (g.mod_ld == 0 ? 2 : 3);
         if (res) { if (epi == 1) GEMM_EPI(true, 1); else if (epi == 2) GEMM_EPI(true, 2); else GEMM_EPI(true, 3); }
         else { if (epi == 1) GEMM_EPI(false, 1); else if (epi == 2) GEMM_EPI(false, 2); else GEMM_EPI(false, 3); }
-        return;
+        return true;
     }
     if (g.act == ACT_GELU_KEEP || g.act == ACT_DGELU) {
-        if (ln || (g.act == ACT_GELU_KEEP && (res || !g.C2)) || (g.act == ACT_DGELU && (!res || g.C2))) { fprintf(stderr, "dsg: launch_gemm: unsupported training-form epilogue\n"); abort(); }
+        if (ln || (g.act == ACT_GELU_KEEP && (res || !g.C2)) || (g.act == ACT_DGELU && (!res || g.C2))) return false;
         if (g.act == ACT_GELU_KEEP) GEMM_CASE(false, ACT_GELU_KEEP, false); else GEMM_CASE(false, ACT_DGELU, true);
     }
     else if (ln && g.act == ACT_NONE && !res) GEMM_CASE(true, ACT_NONE, false);
@@ -624,6 +627,7 @@ void launch_gemm(const GemmArgs &g, hipStream_t s) {
     else GEMM_CASE(false, ACT_SILU, true);
 #undef GEMM_EPI
 #undef GEMM_CASE
+    return true;
 }
 
 bool launch_gemm_qkv_attn(const GemmArgs &g, hipStream_t s) {
@@ -635,8 +639,8 @@ bool launch_gemm_qkv_attn(const GemmArgs &g, hipStream_t s) {
     const int wpt = wg.ws == 8 ? 2 : 1;   // windows per 128-row tile: two of 64 tokens, or one of 100 padded to 128
     const int tiles_m = (n_windows + wpt - 1) / wpt, tiles_n = wg.heads;
     const dim3 grid(((tiles_m + 7) / 8) * 8 * tiles_n), block(256);
-    if (wg.ws == 8) hipLaunchKernelGGL((gemm4_f32_kernel<true, ACT_NONE, false, 4, 8>), grid, block, 0, s, g, tiles_m, tiles_n);
-    else hipLaunchKernelGGL((gemm4_f32_kernel<true, ACT_NONE, false, 4, 10>), grid, block, 0, s, g, tiles_m, tiles_n);
+    if (wg.ws == 8) DSG_LAUNCH((gemm4_f32_kernel<true, ACT_NONE, false, 4, 8>), grid, block, 0, s, g, tiles_m, tiles_n);
+    else DSG_LAUNCH((gemm4_f32_kernel<true, ACT_NONE, false, 4, 10>), grid, block, 0, s, g, tiles_m, tiles_n);
     return true;
 }
 
@@ -754,8 +758,8 @@ __global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float
 void launch_fused_mlp(float *x, const float *gam, const float *bet, const float *W1p, const float *b1, const float *W2p,
                       const float *b2, int M, int C, float *stats_out, hipStream_t s) {
     const dim3 grid((M + 127) / 128), block(256);
-    if (C == 96) hipLaunchKernelGGL(fused_mlp_kernel<96>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, M, stats_out);
-    else if (C == 192) hipLaunchKernelGGL(fused_mlp_kernel<192>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, M, stats_out);
+    if (C == 96) DSG_LAUNCH(fused_mlp_kernel<96>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, M, stats_out);
+    else if (C == 192) DSG_LAUNCH(fused_mlp_kernel<192>, grid, block, 0, s, x, gam, bet, W1p, b1, W2p, b2, M, stats_out);
 }
 
 // =================================================================================================
@@ -971,7 +975,7 @@ void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, co
     const int nW = (g.res / g.ws) * (g.res / g.ws), n_windows = B * nW;
     const int MB = (g.ws * g.ws + 31) / 32;
     const dim3 grid((n_windows + 3) / 4), block(256);
-#define FA(MB_, PM_) hipLaunchKernelGGL((fused_attn96_kernel<MB_, PM_>), grid, block, 0, s, x, aff, aff_ld, aff_off, gam, bet, Wqp, bqkv, biasT, Wpp, bproj, g, n_windows)
+#define FA(MB_, PM_) DSG_LAUNCH((fused_attn96_kernel<MB_, PM_>), grid, block, 0, s, x, aff, aff_ld, aff_off, gam, bet, Wqp, bqkv, biasT, Wpp, bproj, g, n_windows)
     if (MB == 1) { if (premod) FA(1, true); else FA(1, false); }
     else { if (premod) FA(2, true); else FA(2, false); }
 #undef FA
@@ -1146,13 +1150,13 @@ void launch_fused_readout96(const float *x, const float *gam, const float *bet, 
                             int Ca, hipStream_t s, bool bf16_frags) {
     const int M = B * N * N, nseg = readout_pool_segments(N);
     if (bf16_frags)
-        hipLaunchKernelGGL(fused_readout96_kernel<true>, dim3((M + 127) / 128), dim3(256), 0, s, x, gam, bet, Wfp, fa, W2p, f2, flags, out_adj,
+        DSG_LAUNCH(fused_readout96_kernel<true>, dim3((M + 127) / 128), dim3(256), 0, s, x, gam, bet, Wfp, fa, W2p, f2, flags, out_adj,
                            pool_part, nseg, B, N, Ca);
     else
-        hipLaunchKernelGGL(fused_readout96_kernel<false>, dim3((M + 127) / 128), dim3(256), 0, s, x, gam, bet, Wfp, fa, W2p, f2, flags, out_adj,
+        DSG_LAUNCH(fused_readout96_kernel<false>, dim3((M + 127) / 128), dim3(256), 0, s, x, gam, bet, Wfp, fa, W2p, f2, flags, out_adj,
                            pool_part, nseg, B, N, Ca);
     const int n = B * N * 128;
-    hipLaunchKernelGGL(pool_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flags, pool_part, nseg, pool_ext, B, N);
+    DSG_LAUNCH(pool_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, flags, pool_part, nseg, pool_ext, B, N);
 }
 
 // =================================================================================================
@@ -1289,10 +1293,10 @@ bool launch_fused_patch_embed96(const float *adj, const float *node, const float
     const int M = B * N * N;
     const dim3 grid((M + 127) / 128), block(256);
 #define PE_ARGS adj, node, sc_adj, sc_node, has_sc, flags, Wp, bias, gam, bet, aff, aff_ld, aff_off, aff_off2, x, B, N, Ca, Cn, self_cond, xn
-    if (Kp == 64 && Ca == 6 && Cn == 12) hipLaunchKernelGGL((fused_patch_embed96_kernel<64, 6, 12>), grid, block, 0, s, PE_ARGS);       // VG bits
-    else if (Kp == 64 && Ca == 3 && Cn == 12) hipLaunchKernelGGL((fused_patch_embed96_kernel<64, 3, 12>), grid, block, 0, s, PE_ARGS);  // COCO bits
-    else if (Kp == 32) hipLaunchKernelGGL((fused_patch_embed96_kernel<32>), grid, block, 0, s, PE_ARGS);
-    else if (Kp == 64) hipLaunchKernelGGL((fused_patch_embed96_kernel<64>), grid, block, 0, s, PE_ARGS);
+    if (Kp == 64 && Ca == 6 && Cn == 12) DSG_LAUNCH((fused_patch_embed96_kernel<64, 6, 12>), grid, block, 0, s, PE_ARGS);       // VG bits
+    else if (Kp == 64 && Ca == 3 && Cn == 12) DSG_LAUNCH((fused_patch_embed96_kernel<64, 3, 12>), grid, block, 0, s, PE_ARGS);  // COCO bits
+    else if (Kp == 32) DSG_LAUNCH((fused_patch_embed96_kernel<32>), grid, block, 0, s, PE_ARGS);
+    else if (Kp == 64) DSG_LAUNCH((fused_patch_embed96_kernel<64>), grid, block, 0, s, PE_ARGS);
     else return false;
 #undef PE_ARGS
     return true;
@@ -1437,16 +1441,17 @@ __global__ __launch_bounds__(256) void window_attn_kernel(const float *__restric
     }
 }
 
-void launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s, bool out_bf16, bool in_bf16) {
+bool launch_window_attn(const float *qkv, const float *biasT, float *out, int B, const WinGeom &g, hipStream_t s, bool out_bf16, bool in_bf16) {
+    if (g.ws < 1 || g.res % g.ws != 0 || g.C != 32 * g.heads || B < 1) return false;
     const int nW = (g.res / g.ws) * (g.res / g.ws);
     const int n_units = B * nW * g.heads;
     const dim3 grid((n_units + 3) / 4), block(256);
-    if (in_bf16 && !out_bf16) { fprintf(stderr, "dsg: launch_window_attn: bf16 qkv is only built with a bf16 output\n"); abort(); }
+    if (in_bf16 && !out_bf16) return false;   // bf16 qkv is only built with a bf16 output
 #define WA(KT_, WS_)                                                                                                                \
     do {                                                                                                                            \
-        if (in_bf16) hipLaunchKernelGGL((window_attn_kernel<KT_, WS_, true, true>), grid, block, 0, s, qkv, biasT, out, B, g, n_units);  \
-        else if (out_bf16) hipLaunchKernelGGL((window_attn_kernel<KT_, WS_, true>), grid, block, 0, s, qkv, biasT, out, B, g, n_units);  \
-        else hipLaunchKernelGGL((window_attn_kernel<KT_, WS_, false>), grid, block, 0, s, qkv, biasT, out, B, g, n_units);               \
+        if (in_bf16) DSG_LAUNCH((window_attn_kernel<KT_, WS_, true, true>), grid, block, 0, s, qkv, biasT, out, B, g, n_units);  \
+        else if (out_bf16) DSG_LAUNCH((window_attn_kernel<KT_, WS_, true>), grid, block, 0, s, qkv, biasT, out, B, g, n_units);  \
+        else DSG_LAUNCH((window_attn_kernel<KT_, WS_, false>), grid, block, 0, s, qkv, biasT, out, B, g, n_units);               \
     } while (0)
     switch (g.ws) {
         case 2: WA(1, 2); break;
@@ -1454,9 +1459,10 @@ void launch_window_attn(const float *qkv, const float *biasT, float *out, int B,
         case 5: WA(1, 5); break;
         case 8: WA(2, 8); break;
         case 10: WA(4, 10); break;
-        default: break;  // dsg_create only admits these window sizes
+        default: return false;  // (dsg_create only admits these window sizes)
     }
 #undef WA
+    return true;
 }
 
 // =================================================================================================
@@ -1500,7 +1506,7 @@ __global__ __launch_bounds__(256) void mod_stats_kernel(float *x, const float *a
 }
 void launch_mod_stats(float *x, const float *aff, int aff_ld, int aff_off, float *stats, int B, int T, int C, hipStream_t s) {
     const int M = B * T;
-    hipLaunchKernelGGL(mod_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, aff, aff_ld, aff_off, stats, T, C, M);
+    DSG_LAUNCH(mod_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, aff, aff_ld, aff_off, stats, T, C, M);
 }
 
 __global__ __launch_bounds__(256) void ln_stats_kernel(const float *x, float *stats, int C, int M) {
@@ -1528,7 +1534,7 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const float *x, float *st
     if (lane == 0) { stats[2 * m] = mean; stats[2 * m + 1] = fast_rsqrt(var + LN_EPS); }
 }
 void launch_ln_stats(const float *x, float *stats, int M, int C, hipStream_t s) {
-    hipLaunchKernelGGL(ln_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, stats, C, M);
+    DSG_LAUNCH(ln_stats_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, stats, C, M);
 }
 
 // PatchEmbed tail (diffusesg.py:570-576): y = silu(shift + LN(x)*(1+scale))
@@ -1568,7 +1574,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float *x, const float
 void launch_ln_mod(const float *x, const float *g, const float *b, const float *aff, int aff_ld, int aff_off, float *y,
                    int B, int T, int C, hipStream_t s) {
     const int M = B * T;
-    hipLaunchKernelGGL(ln_mod_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, aff, aff_ld, aff_off, y, T, C, M);
+    DSG_LAUNCH(ln_mod_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, aff, aff_ld, aff_off, y, T, C, M);
 }
 
 // PatchMerging (diffusesg.py:323-332): out row (i,j) = LN_4C(cat[x(2i,2j), x(2i+1,2j), x(2i,2j+1), x(2i+1,2j+1)])
@@ -1617,8 +1623,8 @@ __global__ __launch_bounds__(256) void merge_ln_kernel(const float *x, const flo
 }
 void launch_merge_ln(const float *x, const float *g, const float *b, float *y, int B, int res, int C, hipStream_t s, bool out_bf16) {
     const int M = B * (res / 2) * (res / 2);
-    if (out_bf16) hipLaunchKernelGGL(merge_ln_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y, res, C, M);
-    else hipLaunchKernelGGL(merge_ln_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y, res, C, M);
+    if (out_bf16) DSG_LAUNCH(merge_ln_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y, res, C, M);
+    else DSG_LAUNCH(merge_ln_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, x, g, b, y, res, C, M);
 }
 
 // PatchBreakup middle (diffusesg.py:386-400): LN_D(row) -> chunk q -> token (2i+(q&1), 2j+(q>>1)) -> LN_{D/4}
@@ -1702,8 +1708,8 @@ __global__ __launch_bounds__(256) void breakup_ln_kernel(const float *y, const f
 void launch_breakup_ln(const float *y, const float *g, const float *b, const float *pg, const float *pb, float *z, int B,
                        int res, int D, hipStream_t s, bool out_bf16) {
     const int M = B * res * res;
-    if (out_bf16) hipLaunchKernelGGL(breakup_ln_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, y, g, b, pg, pb, z, res, D, M);
-    else hipLaunchKernelGGL(breakup_ln_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, y, g, b, pg, pb, z, res, D, M);
+    if (out_bf16) DSG_LAUNCH(breakup_ln_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, s, y, g, b, pg, pb, z, res, D, M);
+    else DSG_LAUNCH(breakup_ln_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, s, y, g, b, pg, pb, z, res, D, M);
 }
 
 // PositionalEmbedding (diffusesg.py:507-513): freqs = (1/10000)^(k/(E/2)); [cos(x f), sin(x f)]
@@ -1719,7 +1725,7 @@ __global__ void noise_pe_kernel(const float *c_noise, float *pe, int B, int E) {
 }
 void launch_noise_pe(const float *c_noise, float *pe, int B, int E, hipStream_t s) {
     const int n = B * (E / 2);
-    hipLaunchKernelGGL(noise_pe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, c_noise, pe, B, E);
+    DSG_LAUNCH(noise_pe_kernel, dim3((n + 255) / 256), dim3(256), 0, s, c_noise, pe, B, E);
 }
 
 // Input assembly (diffusesg.py:784-802), token-major with the K dim zero-padded to Kp.
@@ -1755,7 +1761,7 @@ __global__ void assemble_kernel(const float *adj, const float *node, const float
 void launch_assemble(const float *adj, const float *node, const float *sc_adj, const float *sc_node, const int *has_sc,
                      const uint8_t *flags, float *out, int B, int N, int Ca, int Cn, int self_cond, int Kp, hipStream_t s) {
     const size_t total = (size_t)B * N * N * Kp;
-    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, adj, node, sc_adj, sc_node,
+    DSG_LAUNCH(assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, adj, node, sc_adj, sc_node,
                        has_sc, flags, out, B, N, Ca, Cn, self_cond, Kp);
 }
 
@@ -1780,7 +1786,7 @@ __global__ __launch_bounds__(256) void head_adj_kernel(const float *h, const flo
 void launch_head_adj(const float *h, const float *W, const float *bias, const uint8_t *flags, float *out, int B, int N,
                      int E, int Ca, hipStream_t s) {
     const int M = B * N * N;
-    hipLaunchKernelGGL(head_adj_kernel, dim3((M + 3) / 4), dim3(256), 0, s, h, W, bias, flags, out, N, E, Ca, M);
+    DSG_LAUNCH(head_adj_kernel, dim3((M + 3) / 4), dim3(256), 0, s, h, W, bias, flags, out, N, E, Ca, M);
 }
 
 // Padding-aware pooling (diffusesg.py:812-813): mean over j of the row/col-masked rep, divided by N_pad
@@ -1796,7 +1802,7 @@ __global__ void pool_kernel(const float *rep, const uint8_t *flags, float *pool,
 }
 void launch_pool(const float *rep, const uint8_t *flags, float *pool, int B, int N, int E, hipStream_t s) {
     const int n = B * N * E;
-    hipLaunchKernelGGL(pool_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rep, flags, pool, B, N, E);
+    DSG_LAUNCH(pool_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rep, flags, pool, B, N, E);
 }
 
 __global__ __launch_bounds__(256) void head_node_kernel(const float *h, const float *W, const float *bias,
@@ -1817,7 +1823,7 @@ __global__ __launch_bounds__(256) void head_node_kernel(const float *h, const fl
 void launch_head_node(const float *h, const float *W, const float *bias, const uint8_t *flags, float *out, int B, int N,
                       int E, int Cn, hipStream_t s) {
     const int M = B * N;
-    hipLaunchKernelGGL(head_node_kernel, dim3((M + 3) / 4), dim3(256), 0, s, h, W, bias, flags, out, N, E, Cn, M);
+    DSG_LAUNCH(head_node_kernel, dim3((M + 3) / 4), dim3(256), 0, s, h, W, bias, flags, out, N, E, Cn, M);
 }
 
 // =================================================================================================
@@ -1865,11 +1871,11 @@ __global__ void cnoise_kernel(const float *sigmas, float *c_noise, int n) {
     if (i < n) c_noise[i] = __fdiv_rn(logf(sigmas[i]), 4.0f);  // objectives/edm.py:126
 }
 void launch_cnoise(const float *sigmas, float *c_noise, int n, hipStream_t s) {
-    hipLaunchKernelGGL(cnoise_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sigmas, c_noise, n);
+    DSG_LAUNCH(cnoise_kernel, dim3((n + 255) / 256), dim3(256), 0, s, sigmas, c_noise, n);
 }
 void launch_precond_in(CStatePtrs x, const float *sigmas, StatePtrs in, float *c_noise, Dims d, hipStream_t s) {
     const size_t n = total_elems(d);
-    hipLaunchKernelGGL(precond_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, sigmas, in, c_noise, d);
+    DSG_LAUNCH(precond_in_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, sigmas, in, c_noise, d);
 }
 
 __global__ void precond_out_kernel(CStatePtrs x, CStatePtrs F, const float *sigmas, const uint8_t *flags, StatePtrs D,
@@ -1890,7 +1896,7 @@ __global__ void precond_out_kernel(CStatePtrs x, CStatePtrs F, const float *sigm
 void launch_precond_out(CStatePtrs x, CStatePtrs F, const float *sigmas, const uint8_t *flags, StatePtrs D, StatePtrs D2,
                         Dims d, hipStream_t s) {
     const size_t n = total_elems(d);
-    hipLaunchKernelGGL(precond_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, F, sigmas, flags, D, D2, d);
+    DSG_LAUNCH(precond_out_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, F, sigmas, flags, D, D2, d);
 }
 
 // Philox4x32-10 counter-based generator -> one N(0,1) per (seed, stream, element)
@@ -1924,7 +1930,7 @@ __global__ void init_kernel(CStatePtrs init, float scale, uint64_t seed, uint32_
 }
 void launch_init(CStatePtrs init, float scale, uint64_t seed, uint32_t stream, const uint8_t *flags, StatePtrs x, Dims d, hipStream_t s) {
     const size_t n = total_elems(d);
-    hipLaunchKernelGGL(init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, init, scale, seed, stream, flags, x, d);
+    DSG_LAUNCH(init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, init, scale, seed, stream, flags, x, d);
 }
 
 // ---- reverse-loop kernels: scalars from StepRow[ctl->step] (one captured step body serves every step; edm.py:355-427) ----
@@ -1945,7 +1951,7 @@ __global__ void churn_tab_kernel(CStatePtrs x, const StepRow *tab, const RunCtl 
 }
 void launch_churn_tab(CStatePtrs x, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs xhat, Dims d, hipStream_t s) {
     const size_t n = total_elems(d);
-    hipLaunchKernelGGL(churn_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, tab, ctl, flags, xhat, d);
+    DSG_LAUNCH(churn_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, tab, ctl, flags, xhat, d);
 }
 __global__ void precond_in_tab_kernel(CStatePtrs x, const StepRow *tab, const RunCtl *ctl, StatePtrs in, Dims d) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1958,7 +1964,7 @@ __global__ void precond_in_tab_kernel(CStatePtrs x, const StepRow *tab, const Ru
 }
 void launch_precond_in_tab(CStatePtrs x, const StepRow *tab, const RunCtl *ctl, StatePtrs in, Dims d, hipStream_t s) {
     const size_t n = total_elems(d);
-    hipLaunchKernelGGL(precond_in_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, tab, ctl, in, d);
+    DSG_LAUNCH(precond_in_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, tab, ctl, in, d);
 }
 __global__ void precond_out_tab_kernel(CStatePtrs x, CStatePtrs F, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags,
                                        StatePtrs D, Dims d) {
@@ -1977,7 +1983,7 @@ __global__ void precond_out_tab_kernel(CStatePtrs x, CStatePtrs F, const StepRow
 void launch_precond_out_tab(CStatePtrs x, CStatePtrs F, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs D, Dims d,
                             hipStream_t s) {
     const size_t n = total_elems(d);
-    hipLaunchKernelGGL(precond_out_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, F, tab, ctl, flags, D, d);
+    DSG_LAUNCH(precond_out_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, F, tab, ctl, flags, D, d);
 }
 __global__ void euler_tab_kernel(CStatePtrs xhat, CStatePtrs D, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs x,
                                  Dims d) {
@@ -1994,7 +2000,7 @@ __global__ void euler_tab_kernel(CStatePtrs xhat, CStatePtrs D, const StepRow *t
 void launch_euler_tab(CStatePtrs xhat, CStatePtrs D, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags, StatePtrs x, Dims d,
                       hipStream_t s) {
     const size_t n = total_elems(d);
-    hipLaunchKernelGGL(euler_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xhat, D, tab, ctl, flags, x, d);
+    DSG_LAUNCH(euler_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xhat, D, tab, ctl, flags, x, d);
 }
 __global__ void heun_tab_kernel(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, const StepRow *tab, const RunCtl *ctl,
                                 const uint8_t *flags, StatePtrs x, Dims d) {
@@ -2015,17 +2021,17 @@ __global__ void heun_tab_kernel(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, c
 void launch_heun_tab(CStatePtrs xhat, CStatePtrs D1, CStatePtrs D2, const StepRow *tab, const RunCtl *ctl, const uint8_t *flags,
                      StatePtrs x, Dims d, hipStream_t s) {
     const size_t n = total_elems(d);
-    hipLaunchKernelGGL(heun_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xhat, D1, D2, tab, ctl, flags, x, d);
+    DSG_LAUNCH(heun_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, xhat, D1, D2, tab, ctl, flags, x, d);
 }
 __global__ void step_row_kernel(const float *table, int n, const RunCtl *ctl, float *dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = table[(size_t)ctl->step * n + i];
 }
 void launch_step_row(const float *table, int n, const RunCtl *ctl, float *dst, hipStream_t s) {
-    hipLaunchKernelGGL(step_row_kernel, dim3((n + 255) / 256), dim3(256), 0, s, table, n, ctl, dst);
+    DSG_LAUNCH(step_row_kernel, dim3((n + 255) / 256), dim3(256), 0, s, table, n, ctl, dst);
 }
 __global__ void step_advance_kernel(RunCtl *ctl) { ctl->step += 1; }
-void launch_step_advance(RunCtl *ctl, hipStream_t s) { hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, ctl); }
+void launch_step_advance(RunCtl *ctl, hipStream_t s) { DSG_LAUNCH(step_advance_kernel, dim3(1), dim3(1), 0, s, ctl); }
 
 // Training-time objective (forward): R/runner/objectives/edm.py:160-180 (sigma ~ exp(N(P_mean, P_std)), loss weight) and
 // :239-281 / graph_utils.add_sym_normal_noise with non_symmetric=True (noisy inputs).  Op-by-op fp32 rounding like torch.
@@ -2052,7 +2058,7 @@ __global__ void train_inputs_kernel(CStatePtrs clean, const float *rnd, CStatePt
 void launch_train_inputs(CStatePtrs clean, const float *rnd, CStatePtrs eps, uint64_t seed, const uint8_t *flags, float *sigmas,
                          float *weights, StatePtrs noisy, Dims d, hipStream_t s) {
     const size_t n = total_elems(d);
-    hipLaunchKernelGGL(train_inputs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, clean, rnd, eps, seed, flags, sigmas,
+    DSG_LAUNCH(train_inputs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, clean, rnd, eps, seed, flags, sigmas,
                        weights, noisy, d);
 }
 
@@ -2220,7 +2226,7 @@ __global__ __launch_bounds__(256) void rainbow_loss_kernel(CStatePtrs pred, CSta
 }
 void launch_rainbow_loss(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w, float iou_w,
                          int iou_type, float *loss_adj, float *loss_node, Dims d, hipStream_t s) {
-    hipLaunchKernelGGL(rainbow_loss_kernel, dim3(d.B), dim3(256), 0, s, pred, tgt, flags, w, edge_w, node_w, iou_w, iou_type, loss_adj,
+    DSG_LAUNCH(rainbow_loss_kernel, dim3(d.B), dim3(256), 0, s, pred, tgt, flags, w, edge_w, node_w, iou_w, iou_type, loss_adj,
                        loss_node, d);
 }
 
@@ -2272,7 +2278,7 @@ __global__ __launch_bounds__(256) void rainbow_loss_backward_kernel(CStatePtrs p
 }
 void launch_rainbow_loss_backward(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w,
                                   float iou_w, int iou_type, const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d, hipStream_t s) {
-    hipLaunchKernelGGL(rainbow_loss_backward_kernel, dim3(d.B), dim3(256), 0, s, pred, tgt, flags, w, edge_w, node_w, iou_w, iou_type, sigmas,
+    DSG_LAUNCH(rainbow_loss_backward_kernel, dim3(d.B), dim3(256), 0, s, pred, tgt, flags, w, edge_w, node_w, iou_w, iou_type, sigmas,
                        grad, gradF, d);
 }
 
@@ -2307,7 +2313,7 @@ __global__ void decode_bits_kernel(const float *adj, const float *node, const ui
 void launch_decode_bits(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,
                         int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d, hipStream_t s) {
     const size_t n = (size_t)d.B * d.N * d.N + (size_t)d.B * d.N;
-    hipLaunchKernelGGL(decode_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, adj, node, flags, n_adj_type,
+    DSG_LAUNCH(decode_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, adj, node, flags, n_adj_type,
                        n_node_type, node_bits, out_adj, out_node, out_bbox, d);
 }
 

@@ -436,13 +436,13 @@ bool launch_gemm_bx(const BxGemm &g, hipStream_t s) {
 #define BX_LAUNCH(WM_, WN_, KB_, NT_, MT_)                                                                                                 \
     do {                                                                                                                                   \
         if (g.res) {                                                                                                                       \
-            if (mod == 0) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 0, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);        \
-            else if (mod == 1) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 1, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);   \
-            else hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, true, 2, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);                 \
+            if (mod == 0) DSG_LAUNCH((gemm_bx_kernel<WM_, WN_, KB_, true, 0, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);        \
+            else if (mod == 1) DSG_LAUNCH((gemm_bx_kernel<WM_, WN_, KB_, true, 1, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);   \
+            else DSG_LAUNCH((gemm_bx_kernel<WM_, WN_, KB_, true, 2, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);                 \
         } else {                                                                                                                           \
-            if (mod == 0) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 0, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);       \
-            else if (mod == 1) hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 1, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);  \
-            else hipLaunchKernelGGL((gemm_bx_kernel<WM_, WN_, KB_, false, 2, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);                \
+            if (mod == 0) DSG_LAUNCH((gemm_bx_kernel<WM_, WN_, KB_, false, 0, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);       \
+            else if (mod == 1) DSG_LAUNCH((gemm_bx_kernel<WM_, WN_, KB_, false, 1, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);  \
+            else DSG_LAUNCH((gemm_bx_kernel<WM_, WN_, KB_, false, 2, MT_>), grid, dim3(NT_), 0, s, g, tiles_m, tiles_n, tiles_total);                \
         }                                                                                                                                  \
     } while (0)
     // (MT = 1 -- 32 x 96 wave tiles, ~125 registers, four waves per SIMD on the same block tiles -- measured within 3 % of these on
@@ -987,13 +987,13 @@ bool launch_mlp_bx(const BxMlp &g, hipStream_t s) {
 #define MLP_LAUNCH(C_)                                                                                   \
     do {                                                                                                 \
         if (proj) {                                                                                      \
-            if (mod == 0) hipLaunchKernelGGL((mlp_bx_kernel<C_, 0, true>), grid, block, 0, s, g);        \
-            else if (mod == 1) hipLaunchKernelGGL((mlp_bx_kernel<C_, 1, true>), grid, block, 0, s, g);   \
-            else hipLaunchKernelGGL((mlp_bx_kernel<C_, 2, true>), grid, block, 0, s, g);                 \
+            if (mod == 0) DSG_LAUNCH((mlp_bx_kernel<C_, 0, true>), grid, block, 0, s, g);        \
+            else if (mod == 1) DSG_LAUNCH((mlp_bx_kernel<C_, 1, true>), grid, block, 0, s, g);   \
+            else DSG_LAUNCH((mlp_bx_kernel<C_, 2, true>), grid, block, 0, s, g);                 \
         } else {                                                                                         \
-            if (mod == 0) hipLaunchKernelGGL((mlp_bx_kernel<C_, 0>), grid, block, 0, s, g);              \
-            else if (mod == 1) hipLaunchKernelGGL((mlp_bx_kernel<C_, 1>), grid, block, 0, s, g);         \
-            else hipLaunchKernelGGL((mlp_bx_kernel<C_, 2>), grid, block, 0, s, g);                       \
+            if (mod == 0) DSG_LAUNCH((mlp_bx_kernel<C_, 0>), grid, block, 0, s, g);              \
+            else if (mod == 1) DSG_LAUNCH((mlp_bx_kernel<C_, 1>), grid, block, 0, s, g);         \
+            else DSG_LAUNCH((mlp_bx_kernel<C_, 2>), grid, block, 0, s, g);                       \
         }                                                                                                \
     } while (0)
     switch (g.C) {
@@ -1003,13 +1003,13 @@ bool launch_mlp_bx(const BxMlp &g, hipStream_t s) {
             if (g.wide8) {   // eight waves per 128 tokens (mlp384_bx_kernel)
                 const dim3 block8(512);
                 if (proj) {
-                    if (mod == 0) hipLaunchKernelGGL((mlp384_bx_kernel<0, true>), grid, block8, 0, s, g);
-                    else if (mod == 1) hipLaunchKernelGGL((mlp384_bx_kernel<1, true>), grid, block8, 0, s, g);
-                    else hipLaunchKernelGGL((mlp384_bx_kernel<2, true>), grid, block8, 0, s, g);
+                    if (mod == 0) DSG_LAUNCH((mlp384_bx_kernel<0, true>), grid, block8, 0, s, g);
+                    else if (mod == 1) DSG_LAUNCH((mlp384_bx_kernel<1, true>), grid, block8, 0, s, g);
+                    else DSG_LAUNCH((mlp384_bx_kernel<2, true>), grid, block8, 0, s, g);
                 } else {
-                    if (mod == 0) hipLaunchKernelGGL((mlp384_bx_kernel<0>), grid, block8, 0, s, g);
-                    else if (mod == 1) hipLaunchKernelGGL((mlp384_bx_kernel<1>), grid, block8, 0, s, g);
-                    else hipLaunchKernelGGL((mlp384_bx_kernel<2>), grid, block8, 0, s, g);
+                    if (mod == 0) DSG_LAUNCH((mlp384_bx_kernel<0>), grid, block8, 0, s, g);
+                    else if (mod == 1) DSG_LAUNCH((mlp384_bx_kernel<1>), grid, block8, 0, s, g);
+                    else DSG_LAUNCH((mlp384_bx_kernel<2>), grid, block8, 0, s, g);
                 }
             } else {
                 MLP_LAUNCH(384);
@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(256) void ln_bx_kernel(float *x, const float *aff, 
 }
 void launch_ln_bx(float *x, const float *aff, int aff_ld, int aff_off, void *xn, int B, int T, int C, bool ln, hipStream_t s) {
     const int M = B * T;
-    hipLaunchKernelGGL(ln_bx_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, aff, aff_ld, aff_off, (__bf16 *)xn, T, C, M, ln ? 1 : 0);
+    DSG_LAUNCH(ln_bx_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, aff, aff_ld, aff_off, (__bf16 *)xn, T, C, M, ln ? 1 : 0);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(256) void bias_permute_bx_kernel(const float *__res
 }
 void launch_bias_permute_bx(const float *biasT, void *out, int n_tiles, int Wp, hipStream_t s) {
     const size_t n = (size_t)n_tiles * Wp * Wp;
-    hipLaunchKernelGGL(bias_permute_bx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, biasT, (_Float16 *)out, n_tiles, Wp);
+    DSG_LAUNCH(bias_permute_bx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, biasT, (_Float16 *)out, n_tiles, Wp);
 }
 
 template <int KT, int WS>
@@ -1471,7 +1471,7 @@ bool launch_qkv_attn_bx(const BxQkvAttn &a, hipStream_t s) {
     switch (g.ws) { case 4: case 5: kt = 1; break; case 8: kt = 2; break; case 10: kt = 4; break; default: return false; }
     const int upb = 4 / kt, nblk = (U + upb - 1) / upb;
     const dim3 grid((unsigned)(((nblk + 7) / 8) * 8 * g.heads)), block(256);
-#define QA(KT_, WS_) hipLaunchKernelGGL((qkv_attn_bx_kernel<KT_, WS_>), grid, block, 0, s, a, nblk, U)
+#define QA(KT_, WS_) DSG_LAUNCH((qkv_attn_bx_kernel<KT_, WS_>), grid, block, 0, s, a, nblk, U)
     switch (g.ws) {
         case 4: QA(1, 4); break;
         case 5: QA(1, 5); break;
@@ -1489,7 +1489,7 @@ bool launch_attn_bx(const void *qkv, const float *biasT, void *out, int B, const
     const int pairs = nW * g.heads;
     int split = std::max(1, std::min((B + 3) / 4, (2 * bx_cu_count() + pairs - 1) / pairs));
     const dim3 grid(pairs * split), block(256);
-#define AX(KT_, WS_) hipLaunchKernelGGL((attn_bx_kernel<KT_, WS_>), grid, block, 0, s, (const __bf16 *)qkv, biasT, (__bf16 *)out, B, g, split)
+#define AX(KT_, WS_) DSG_LAUNCH((attn_bx_kernel<KT_, WS_>), grid, block, 0, s, (const __bf16 *)qkv, biasT, (__bf16 *)out, B, g, split)
     switch (g.ws) {
         case 4: AX(1, 4); break;
         case 5: AX(1, 5); break;

@@ -6,6 +6,10 @@
 #include <stdlib.h>
 #include <cmath>
 
+// Every kernel launch of the forward path goes through this macro: under a plan-validation dry run (kernels.h: g_dry_run) the
+// launchers run all their shape checks and select their instantiation, but enqueue nothing.
+#define DSG_LAUNCH(...) do { if (!::dsg::g_dry_run) hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 namespace dsg {
 
 

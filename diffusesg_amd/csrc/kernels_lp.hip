@@ -495,7 +495,7 @@ __global__ void f32_split3_kernel(const float *src, __bf16 *dst, size_t n) {
     }
 }
 void launch_f32_split3(const float *src, void *dst, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(f32_split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (__bf16 *)dst, n);
+    DSG_LAUNCH(f32_split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (__bf16 *)dst, n);
 }
 
 // fp32 [n] -> bf16 [n] (RNE), used once per weight at pack time
@@ -504,7 +504,7 @@ __global__ void f32_to_bf16_kernel(const float *src, __bf16 *dst, size_t n) {
     if (i < n) reinterpret_cast<unsigned short *>(dst)[i] = (unsigned short)(bf16_rne_hi(src[i]) >> 16);
 }
 void launch_f32_to_bf16(const float *src, void *dst, size_t n, hipStream_t s) {
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (__bf16 *)dst, n);
+    DSG_LAUNCH(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (__bf16 *)dst, n);
 }
 
 
@@ -513,7 +513,7 @@ __global__ void bf16_to_f32_kernel(const unsigned short *src, float *dst, size_t
     if (i < n) dst[i] = __uint_as_float((unsigned)src[i] << 16);
 }
 void launch_bf16_to_f32(const void *src, float *dst, size_t n, hipStream_t s) {   // test / debug entries only
-    hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned short *)src, dst, n);
+    DSG_LAUNCH(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned short *)src, dst, n);
 }
 
 static int round_up8(int x) { return (x + 7) / 8 * 8; }
@@ -533,15 +533,15 @@ bool launch_gemm_lp(const GemmArgs &g_in, hipStream_t s) {
     const dim3 grid(round_up8(tiles_m) * tiles_n), block(256);
 #define LAUNCH_BF16(L, A, R, E, AB, CB)                                                                                           \
     do {                                                                                                                          \
-        if (wide) hipLaunchKernelGGL((gemm_bf16_kernel<L, A, R, E, AB, CB, 2>), grid, block, 0, s, g, tiles_m, tiles_n);          \
-        else hipLaunchKernelGGL((gemm_bf16_kernel<L, A, R, E, AB, CB, 1>), grid, block, 0, s, g, tiles_m, tiles_n);               \
+        if (wide) DSG_LAUNCH((gemm_bf16_kernel<L, A, R, E, AB, CB, 2>), grid, block, 0, s, g, tiles_m, tiles_n);          \
+        else DSG_LAUNCH((gemm_bf16_kernel<L, A, R, E, AB, CB, 1>), grid, block, 0, s, g, tiles_m, tiles_n);               \
     } while (0)
     const bool ln = g.ln_stats != nullptr || g.ln_part != nullptr, res = g.res != nullptr;
     if (g.a4_res > 0 || g.attn_bias) return false;               // fp32-kernel-only features
     if (g.a_bf16 || g.c_bf16) {   // bf16 tensors between kernels: only the shapes the forward uses; anything else is a caller bug
         const bool a_ok = g.a_bf16 && !g.c_bf16 && !split && !ln && g.act == ACT_NONE && res && !g.A2 && g.K % HBK == 0;
         const bool c_ok = g.c_bf16 && !g.a_bf16 && !split && ln && (g.act == ACT_GELU || g.act == ACT_NONE) && !res && !g.stats_out && !g.C2;
-        if (!a_ok && !c_ok) { fprintf(stderr, "dsg: launch_gemm_lp: unsupported bf16-tensor GEMM\n"); abort(); }
+        if (!a_ok && !c_ok) return false;   // not built: launch_gemm reports it to the caller (nothing launched)
         if (c_ok) {
             if (g.act == ACT_GELU) LAUNCH_BF16(true, ACT_GELU, false, 0, false, true);
             else LAUNCH_BF16(true, ACT_NONE, false, 0, false, true);
@@ -565,7 +565,7 @@ bool launch_gemm_lp(const GemmArgs &g_in, hipStream_t s) {
     }
 #define GEMM_CASE(L, A, R)                                                                                     \
     do {                                                                                                       \
-        if (split) hipLaunchKernelGGL((gemm_split2_kernel<L, A, R, 4>), grid, block, 0, s, g, tiles_m, tiles_n); \
+        if (split) DSG_LAUNCH((gemm_split2_kernel<L, A, R, 4>), grid, block, 0, s, g, tiles_m, tiles_n); \
         else LAUNCH_BF16(L, A, R, 0, false, false);                                                                \
     } while (0)
     if (ln && g.act == ACT_NONE && !res) GEMM_CASE(true, ACT_NONE, false);

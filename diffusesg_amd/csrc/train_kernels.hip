@@ -335,7 +335,7 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
             else if (accumulate) { g.res = C; g.ldres = ldc; }
             g.act = act;
             if (act == ACT_GELU_KEEP) { g.C2 = c2; g.ldc2 = ldc; }
-            launch_gemm(g, s);
+            if (!launch_gemm(g, s)) ts.failed = true;   // reported by the entry point as DSG_ERR_HIP / INVALID (t_scratch_failed)
             act_after.done = true;
             return;
         }

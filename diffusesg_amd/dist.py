@@ -64,12 +64,12 @@ def all_reduce_mean(grads, bucket_bytes: int = 256 << 20):
     all-reduces beat one per tensor -- summed with one `all_reduce` each (RCCL with backend "nccl"; gloo in the CPU test) and
     divided by the world size, in place.  Identity when not distributed."""
     tensors = list(grads.values()) if isinstance(grads, dict) else list(grads)
-    if not (dist.is_available() and dist.is_initialized()) or not tensors:
+    flat = getattr(grads, "flat", None)   # looked at BEFORE the emptiness shortcut: a GradDict's payload is its flat buffer
+    if not (dist.is_available() and dist.is_initialized()) or (not tensors and flat is None):
         return grads
     if dist.get_world_size() == 1 and not os.environ.get("DSG_FORCE_COLLECTIVE"):   # (the world-size-1 RCCL test sets it)
         return grads
     world = dist.get_world_size()
-    flat = getattr(grads, "flat", None)
     if flat is not None:   # train_step_grads' GradDict: every gradient is a view into one flat buffer -- one collective, no packing
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat.div_(world)

@@ -12,7 +12,7 @@ MAX_LAYERS = 8
 
 # every symbol include/dsg.h declares (tests/test_abi.py checks the built library exports them)
 EXPORTS = [
-    "dsg_create", "dsg_destroy", "dsg_last_error", "dsg_version", "dsg_set_weight", "dsg_finalize_weights",
+    "dsg_create", "dsg_destroy", "dsg_last_error", "dsg_version", "dsg_abi_version", "dsg_set_weight", "dsg_finalize_weights",
     "dsg_num_weight_keys", "dsg_weight_key", "dsg_workspace_bytes", "dsg_denoise", "dsg_precond", "dsg_sample",
     "dsg_sigma_schedule", "dsg_debug_tap", "dsg_debug_clear_taps", "dsg_decode_bits", "dsg_profile_forward", "dsg_set_option",
     "dsg_get_option", "dsg_gen_noise", "dsg_train_inputs", "dsg_rainbow_loss", "dsg_rainbow_loss_backward", "dsg_noise_embed", "dsg_affine_width", "dsg_block_train", "dsg_train_grads", "dsg_train_step_grads", "dsg_train_self_cond", "dsg_train_bind_params", "dsg_adam_step", "dsg_ema_update", "dsg_debug_gemm", "dsg_debug_gemm_bx", "dsg_debug_attn_bx", "dsg_debug_qkv_attn_bx", "dsg_debug_projmlp_bx", "dsg_debug_mlp_bx", "dsg_profile_clock_ghz",
@@ -43,22 +43,40 @@ class DsgSampleStats(C.Structure):
 _lib = None
 
 
-def load() -> C.CDLL:
-    """dlopen libdsg.so and declare the prototypes of include/dsg.h."""
+# ABI generation of include/dsg.h this binding was written against (DSG_ABI_VERSION there): argument lists changed between rounds
+# (e.g. iou_loss_type in the loss entries), and a stale libdsg.so would take shifted arguments without any error
+ABI_VERSION = 4
+
+
+def load(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libdsg.so and declare the prototypes of include/dsg.h.  `path`: another build of the library -- the kernel-variant
+    A/B builds of the dev tools pass it explicitly (tools/bx_bench.py); the product and the tests always load the in-tree one, and
+    no environment variable redirects the load."""
     global _lib
     if _lib is not None:
+        if path is not None and os.path.abspath(path) != getattr(_lib, "_dsg_path", None):
+            raise DsgError(f"libdsg.so is already loaded from {_lib._dsg_path}; cannot switch to {path}")
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise DsgError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    lib_path = os.path.abspath(path) if path is not None else LIB_PATH
+    if not os.path.exists(lib_path):
+        raise DsgError(f"{lib_path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  Importing torch first makes the
     # dynamic loader resolve libdsg.so's NEEDED libamdhip64.so.7 to that already-loaded copy, so streams and device
     # pointers are shared with torch.  (Loaded the other way round, two runtimes end up in the process and the second
     # one to initialise cannot see the GPU.)
     import torch  # noqa: F401
-    # (DSG_LIB_PATH: kernel-variant A/B builds of the dev tools, e.g. tools/bx_exp.sh; never set by the product or the tests)
-    L = C.CDLL(os.environ.get("DSG_LIB_PATH") or LIB_PATH)
+    L = C.CDLL(lib_path)
+    L._dsg_path = lib_path
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    try:
+        L.dsg_abi_version.restype = i32
+        abi = int(L.dsg_abi_version())
+    except AttributeError:
+        abi = -1
+    if abi != ABI_VERSION:
+        raise DsgError(f"{lib_path} has ABI generation {abi}, this binding needs {ABI_VERSION}: rebuild it "
+                       f"(python -c 'import __graft_entry__ as g; g.build()')")
     L.dsg_create.argtypes = [C.POINTER(DsgConfig), C.POINTER(vp)]
     L.dsg_destroy.argtypes = [vp]
     L.dsg_destroy.restype = None
@@ -150,8 +168,8 @@ class Handle:
         self._h = C.c_void_p()
         rc = self.L.dsg_create(C.byref(self._c), C.byref(self._h))
         if rc != 0:
-            raise DsgError(f"dsg_create failed with status {rc} (no MI355X visible, or unsupported configuration); "
-                           f"there is no CPU fallback")
+            why = self.L.dsg_last_error(None)
+            raise DsgError(f"dsg_create failed with status {rc}: {why.decode() if why else ''} (there is no CPU fallback)")
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -36,6 +36,11 @@ extern "C" {
 #endif
 
 #define DSG_MAX_LAYERS 8
+/* Generation of this header's argument lists; dsg_abi_version() returns the one the library was built with.  A binding compares the two
+ * at load time (diffusesg_amd/lib.py does): round 3 inserted `iou_loss_type` into three entries, and a caller built against the older
+ * header would otherwise pass shifted arguments without any error.  History: 1-3 = rounds 1-3 (unversioned), 4 = round 4
+ * (dsg_decode with an encoding argument, dsg_abi_version, dsg_last_error(NULL)). */
+#define DSG_ABI_VERSION 4
 
 typedef enum {
     DSG_OK = 0,
@@ -84,8 +89,10 @@ typedef struct dsg_sample_stats {
 
 int dsg_create(const dsg_config *cfg, dsg_handle *out);
 void dsg_destroy(dsg_handle h);
+/* h == NULL: the reason the last dsg_create on the calling thread failed (there is no handle to ask then) */
 const char *dsg_last_error(dsg_handle h);
 const char *dsg_version(void);
+int32_t dsg_abi_version(void);   /* DSG_ABI_VERSION of the header the library was built from */
 
 /* `key` is the reference state-dict name, with or without the 'model.' prefix of the precond
  * wrapper (precond.py:15) and/or the 'module.' prefix of DDP (sampling_utils.py:47-53).

@@ -51,17 +51,42 @@ def main():
     ua, un, uf, ub = IO.unpack_decoded(out16, N, True)
     assert torch.equal(ua, a_int) and torch.equal(un, n_int) and torch.equal(uf, nflags) and torch.equal(ub, bbox)
     # gradient all-reduce (bucketed): sum over one rank / 1 == identity, through RCCL; two buckets forced
+    # (at world size 1 the sum is the identity, so equality alone would also hold if no collective ran: count the calls)
+    calls = []
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(t, *a, **k):
+        calls.append((t.data_ptr(), t.numel()))
+        return real_all_reduce(t, *a, **k)
+
+    dist.all_reduce = counting_all_reduce
     grads = {f"p{i}": torch.randn(n_, generator=g).to(dev) for i, n_ in enumerate((1000, 70000, 3, 512 * 512))}
     ref = {k: v.clone() for k, v in grads.items()}
     D.all_reduce_mean(grads, bucket_bytes=300000)
+    assert len(calls) == 2 and sum(c[1] for c in calls) == sum(v.numel() for v in ref.values()), calls   # two buckets forced
     for k in grads:
         assert torch.equal(grads[k], ref[k]), k
-    from diffusesg_amd.train import GradDict   # the flat form train_step_grads returns: one collective on the flat buffer
+    # the flat form train_step_grads returns (what every multi-GPU training step reduces): the dict entries are VIEWS into one flat
+    # buffer and ONE collective runs on that buffer, with no packing copy
+    from diffusesg_amd.train import GradDict
     fg = GradDict()
     fg.flat = torch.cat([ref[k].reshape(-1) for k in ref]).clone()
-    flat_ref = fg.flat.clone()
+    off = 0
+    for k, v in ref.items():
+        fg[k] = fg.flat[off:off + v.numel()].view_as(v)
+        off += v.numel()
+    del calls[:]
     D.all_reduce_mean(fg)
-    assert torch.equal(fg.flat, flat_ref)
+    assert calls == [(fg.flat.data_ptr(), fg.flat.numel())], calls
+    for k in ref:
+        assert torch.equal(fg[k], ref[k]) and fg[k].data_ptr() >= fg.flat.data_ptr(), k
+    # ... and a GradDict with no dict entries at all still reduces its flat buffer (the emptiness shortcut used to return first)
+    bare = GradDict()
+    bare.flat = fg.flat.clone()
+    del calls[:]
+    D.all_reduce_mean(bare)
+    assert calls == [(bare.flat.data_ptr(), bare.flat.numel())] and torch.equal(bare.flat, fg.flat)
+    dist.all_reduce = real_all_reduce
     t = torch.tensor([1.25], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)   # bench.py's max-over-ranks timing reduction
     assert float(t) == 1.25

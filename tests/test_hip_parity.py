@@ -705,6 +705,72 @@ def test_empty_graph_in_batch_vs_oracle(name):
     assert_close(on.cpu().numpy(), rn, FWD_RTOL, f"{name} node with an empty graph")
 
 
+# ---- stream contract (include/dsg.h:21-22: "all work is enqueued on the caller's stream") ----
+def _park_default_stream(seconds=2.0):
+    """a spin kernel of roughly `seconds` on the DEFAULT stream, plus an event behind it: while the event has not fired, stream 0 is busy"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(50_000_000); e1.record(); e1.synchronize()
+    per_cycle_ms = e0.elapsed_time(e1) / 50_000_000
+    torch.cuda._sleep(int(seconds * 1000.0 / max(per_cycle_ms, 1e-12)))
+    done = torch.cuda.Event()
+    done.record()
+    return done
+
+
+@pytest.mark.parametrize("name,B,T_", [("tiny", 4, 12), ("small", 3, 6)])
+def test_stream_contract_nothing_touches_the_default_stream(name, B, T_):
+    """dsg_denoise, dsg_precond, dsg_sample (step graphs CAPTURED during a call on stream A, REPLAYED by a call on stream B, then by a
+    call on the default stream) and dsg_decode_bits under torch.cuda.stream(s) while a long spin kernel is parked on the default stream:
+    (1) results are bitwise those of the default-stream run; (2) every call's work completes while the parked kernel is still running,
+    i.e. nothing was enqueued on (or waited for) stream 0.  torch's side streams are non-blocking streams, so there is no implicit
+    ordering with the null stream that could hide a misplaced launch."""
+    from diffusesg_amd import io as IO
+    from diffusesg_amd.model import build_network
+    cfg = Y.CONFIGS[name]()
+    n = cfg.max_node_num
+    net = build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")   # a private handle: no graphs captured yet
+    valid = [n, max(n // 2, 1), 3, n][:B]
+    flags, adj, node, sc_adj, sc_node = Y.case_inputs(cfg, B, valid, 51, f"stream/{name}")
+    c_noise = np.linspace(-1.0, 1.0, B).astype(np.float32)
+    sig = np.linspace(0.3, 20.0, B).astype(np.float32)
+    fl, ia, inn, na, nn, coin_vals = Y.sampler_case(cfg, T_, B, valid, 9, f"stream/{name}/smp", "heun")
+    coins = (coin_vals < 0.5).astype(np.uint8)
+    dv = [T(x) for x in (flags, adj, node, sc_adj, sc_node, c_noise, sig, fl, ia, inn, na, nn)]
+    dflags, dadj, dnode, dsca, dscn, dcn, dsig, dfl, dia, dinn, dna, dnn = dv
+
+    def run_all(use_graph):
+        out = list(net.model(dadj, dnode, dflags, dcn, dsca, dscn))
+        np.random.seed(5)   # the precond wrapper draws its coin from NumPy's global generator (precond.py:90)
+        out += list(net(dadj, dnode, dflags, dsig, dsca, dscn))
+        smp = make_sampler(T_, use_graph=use_graph)
+        sa, sn = smp.sample(net, dfl, init_adjs=dia, init_nodes=dinn, churn_noise=(dna, dnn), coins=coins, return_device=True,
+                            flag_node_multi_channel=True, flag_adj_multi_channel=True, num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+        if use_graph:
+            assert smp.last_stats["graph_replays"] == smp.last_stats["net_forwards"]
+        out += [sa, sn]
+        qa, qn, bb = IO.decode_bits(net, sa.reshape(B, cfg.c_adj, n, n), sn.reshape(B, n, cfg.c_node), dfl, 7, 9, bbox=cfg.c_node > 4)
+        out += [qa, qn] + ([bb] if bb is not None else [])
+        return [o.clone() for o in out]
+
+    ref = run_all(use_graph=False)   # default stream, eager: also creates the workspace and the sampler's tables (allocation may sync the device)
+    torch.cuda.synchronize()
+    parked = _park_default_stream(3.0)
+    results = {}
+    for tag in ("A", "B"):            # A: the step graphs are captured during this call and replayed on A; B: replayed on another stream
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            results[tag] = run_all(use_graph=True)
+            fin = torch.cuda.Event(); fin.record(st)
+        fin.synchronize()
+        assert not parked.query(), f"stream {tag}: the call outlived the kernel parked on the default stream -- it waited for stream 0"
+    parked.synchronize()
+    results["default"] = run_all(use_graph=True)   # the same captured graphs, now replayed on the default stream
+    torch.cuda.synchronize()
+    for tag, outs in results.items():
+        for i, (o, r) in enumerate(zip(outs, ref)):
+            assert torch.equal(o, r), f"stream {tag}: output {i} differs from the default-stream eager run"
+
+
 # ---- error behaviour of the boundary (SURVEY §8b: status codes + dsg_last_error; host mirrors raise like the reference) ----
 def _dev_handle(cfg):
     from diffusesg_amd import lib as L
@@ -741,6 +807,80 @@ def test_abi_strict_weight_loading_errors():
     with pytest.raises(L.DsgError, match="unknown option"):
         h.set_option("no_such_option", 1)
     h.close()
+
+
+# configurations nobody planned the kernels for: window sides 2 and 5, a 64-token window at C = 192 only, mlp_ratio 2, embed_dim 128
+# (no narrow-level fused kernel applies, the bf16 block pipeline steps aside), three levels on a 16-node grid
+_ODD_CONFIGS = {
+    "win5": dict(max_node_num=20, c_adj=3, c_node=5, depths=(1, 1), num_heads=(3, 6), window_size=5),
+    "win2_shifted": dict(max_node_num=8, c_adj=2, c_node=3, depths=(2, 1), num_heads=(3, 6), window_size=2),
+    "ratio2_3lvl": dict(max_node_num=16, c_adj=3, c_node=5, depths=(1, 1, 1), num_heads=(3, 6, 12), window_size=4, mlp_ratio=2),
+    "embed128": dict(max_node_num=8, c_adj=3, c_node=4, embed_dim=128, depths=(1, 1), num_heads=(4, 8), window_size=4),
+    "win8_c192": dict(max_node_num=16, c_adj=6, c_node=12, depths=(1, 2), num_heads=(3, 6), window_size=8),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_ODD_CONFIGS))
+def test_unplanned_configs_run_or_return_a_status(name):
+    """include/dsg.h:15,25: every entry returns a status -- the library never terminates the host process (round 3 still had nine
+    abort() sites behind 'shape not covered' checks).  Shape coverage is now decided at plan time (validate_plan in dsg_api.cpp: a dry
+    run of the forward when a batch size is first used and after every dsg_set_option).  Each configuration here must, in fp32 mode,
+    match the oracle; in the bf16 modes (block pipeline on / off, fused kernels on / off) it must either run within the mode's bar or
+    raise DsgError carrying DSG_ERR_INVALID and a message naming the shape (reference behaviour: Python exceptions,
+    R/model/diffusesg/diffusesg.py:235,564-567)."""
+    from oracle.oracle import Oracle
+    from diffusesg_amd import lib as L
+    from diffusesg_amd import spec as S
+    from diffusesg_amd.model import build_network
+    cfg = S.ModelConfig(self_condition=True, **_ODD_CONFIGS[name])
+    n = cfg.max_node_num
+    sd = W.synth_state_dict(cfg, 0)
+    flags, adj, node, sc_adj, sc_node = Y.case_inputs(cfg, 3, [n, max(n // 2, 1), 2], 41, f"odd/{name}")
+    c_noise = np.array([0.25, -0.8, 1.1], np.float32)
+    ra, rn = Oracle(cfg, sd).forward(adj, node, flags, c_noise, sc_adj, sc_node)
+    net = build_network(cfg, sd, device="cuda").model
+    h = net._ensure_handle()
+    run = lambda: net(T(adj), T(node), T(flags), T(c_noise), T(sc_adj), T(sc_node))
+    oa, on = run()
+    assert_close(oa.cpu().numpy(), ra, FWD_RTOL, f"{name} adj fp32")
+    assert_close(on.cpu().numpy(), rn, FWD_RTOL, f"{name} node fp32")
+    ran = refused = 0
+    for pipe in (1, 0):
+        for fused in (1, 0):
+            try:
+                h.set_option("gemm_bf16", 1)
+                h.set_option("bf16_pipe", pipe)
+                h.set_option("bf16_mlp", fused)
+                h.set_option("bf16_qkv_attn", fused)
+                h.set_option("bf16_proj_mlp", fused)
+                oa, on = run()
+            except L.DsgError as e:   # a status code with the shape in the message -- acceptable; a dead interpreter is not
+                assert "status -1" in str(e) and ("not covered" in str(e) or "not built" in str(e)), str(e)
+                refused += 1
+                h.set_option("gemm_bf16", 0)
+                continue
+            ran += 1
+            ea, en = rel_err(oa.cpu().numpy(), ra), rel_err(on.cpu().numpy(), rn)
+            assert torch.isfinite(oa).all() and torch.isfinite(on).all()
+            assert ea <= BF16_MAX_RTOL and en <= BF16_MAX_RTOL, f"{name} bf16 pipe={pipe} fused={fused}: {ea:.2e} / {en:.2e}"
+    print(f"{name}: bf16 variants ran {ran}, refused with a status {refused}")
+    h.set_option("gemm_bf16", 0)
+    oa, on = run()
+    assert_close(oa.cpu().numpy(), ra, FWD_RTOL, f"{name} adj back in fp32")
+
+
+def test_unsupported_geometry_is_a_status_with_a_reason():
+    """dsg_create refuses geometries no kernel is built for with DSG_ERR_INVALID, and dsg_last_error(NULL) says why"""
+    from diffusesg_amd import lib as L
+    from diffusesg_amd import spec as S
+    with pytest.raises(L.DsgError, match="window"):
+        L.Handle(S.ModelConfig(max_node_num=12, c_adj=3, c_node=5, depths=(1, 1), num_heads=(3, 6), window_size=6))
+    with pytest.raises(L.DsgError, match="1536"):   # five levels at embed_dim 96: PatchBreakup rows of 3072 channels
+        L.Handle(S.ModelConfig(max_node_num=32, c_adj=3, c_node=5, depths=(1, 1, 1, 1, 1), num_heads=(3, 6, 12, 24, 48), window_size=2))
+    # a GEMM argument combination that is not built is a status too (it used to abort): K not a multiple of 32
+    a = torch.zeros(64, 40, device="cuda"); w = torch.zeros(96, 40, device="cuda"); c = torch.zeros(64, 96, device="cuda")
+    rc = L.load().dsg_debug_gemm(64, 96, 40, a.data_ptr(), w.data_ptr(), None, None, None, 0, 0, c.data_ptr(), None)
+    assert rc == -1
 
 
 def test_host_mirrors_reject_unsupported_reference_options():

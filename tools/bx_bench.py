@@ -11,7 +11,7 @@ import torch
 
 from diffusesg_amd import lib as L
 
-lib = L.load()
+lib = L.load(os.environ.get("BX_LIB") or None)   # BX_LIB: a kernel-variant build (tools/bx_exp.sh)
 p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
 ITERS = int(os.environ.get("BX_ITERS", "20"))
 

@@ -1,11 +1,11 @@
 #!/bin/bash
 # Dev container: build libdsg variants with a timing experiment compiled into the bf16 GEMM (kernels_bx.hip DSG_BX_EXP) -> tools/bin/ab/
-# GPU box: tools/bx_exp.sh run  -- runs tools/bx_bench.py against each variant (DSG_LIB_PATH)
+# GPU box: tools/bx_exp.sh run  -- runs tools/bx_bench.py against each variant (BX_LIB -> lib.load(path))
 cd "$(dirname "$0")/.."
 if [ "$1" = "run" ]; then
   for v in ${BX_EXPS:-0 1 2 3 4}; do
     echo "=== DSG_BX_EXP=$v"
-    DSG_BX_DBG=$([ $v = 4 ] && echo 1) DSG_LIB_PATH=$PWD/tools/bin/ab/libdsg_bxexp$v.so BX_ITERS=10 BX_ONLY=gemm python tools/bx_bench.py 2>&1 | grep -v "^B=\|amdgpu.ids"
+    DSG_BX_DBG=$([ $v = 4 ] && echo 1) BX_LIB=$PWD/tools/bin/ab/libdsg_bxexp$v.so BX_ITERS=10 BX_ONLY=gemm python tools/bx_bench.py 2>&1 | grep -v "^B=\|amdgpu.ids"
   done
   exit 0
 fi
