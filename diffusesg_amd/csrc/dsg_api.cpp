@@ -2668,14 +2668,36 @@ int dsg_ema_update(int32_t n_tensors, float *const *ema, const float *const *par
 
 double dsg_profile_clock_ghz(dsg_handle h) { return h ? h->prof_clock_ghz : 0.0; }
 
+int dsg_decode(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, int32_t edge_encoding,
+               int32_t node_encoding, int32_t n_adj_type, int32_t n_node_type, int32_t node_chans, int32_t *out_adj, int32_t *out_node,
+               float *out_bbox, void *stream) {
+    if (!h || B < 1 || !adj || !node || !flags || !out_adj || !out_node) return fail(h, DSG_ERR_INVALID, "null tensor");
+    if (edge_encoding < DSG_ENC_BITS || edge_encoding > DSG_ENC_DDPM || node_encoding < DSG_ENC_BITS || node_encoding > DSG_ENC_DDPM)
+        return fail(h, DSG_ERR_INVALID, "encoding must be DSG_ENC_BITS, DSG_ENC_ONE_HOT or DSG_ENC_DDPM");
+    if (n_adj_type < 2 || n_node_type < 2) return fail(h, DSG_ERR_INVALID, "fewer than two types");   // attribute_code.py:132
+    if (node_chans < 1 || node_chans > h->Cn || (out_bbox && h->Cn < node_chans + 4)) return fail(h, DSG_ERR_INVALID, "node_chans");
+    // the channel counts an encoding implies (sg_utils.py:348-409): one channel per type, or a single one
+    if ((edge_encoding == DSG_ENC_ONE_HOT && h->Ca != n_adj_type) || (edge_encoding == DSG_ENC_DDPM && h->Ca != 1) ||
+        (edge_encoding == DSG_ENC_BITS && (h->Ca > 30 || (1 << h->Ca) < n_adj_type)))
+        return fail(h, DSG_ERR_INVALID, "edge encoding %d with %d types does not fit %d adjacency channels", edge_encoding, n_adj_type, h->Ca);
+    if ((node_encoding == DSG_ENC_ONE_HOT && node_chans != n_node_type) || (node_encoding == DSG_ENC_DDPM && node_chans != 1) ||
+        (node_encoding == DSG_ENC_BITS && (node_chans > 30 || (1 << node_chans) < n_node_type)))
+        return fail(h, DSG_ERR_INVALID, "node encoding %d with %d types does not fit %d attribute channels", node_encoding, n_node_type, node_chans);
+    launch_decode(adj, node, flags, edge_encoding, node_encoding, n_adj_type, n_node_type, node_chans, out_adj, out_node, out_bbox,
+                  dims_of(h, B), (hipStream_t)stream);
+    HIP_TRY(h, hipGetLastError());
+    return DSG_OK;
+}
+
 int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, int32_t n_adj_type,
                     int32_t n_node_type, int32_t node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, void *stream) {
     if (!h || B < 1 || !adj || !node || !flags || !out_adj || !out_node) return fail(h, DSG_ERR_INVALID, "null tensor");
     if (node_bits < 1 || node_bits > h->Cn || (out_bbox && h->Cn < node_bits + 4)) return fail(h, DSG_ERR_INVALID, "node_bits");
-    launch_decode_bits(adj, node, flags, n_adj_type, n_node_type, node_bits, out_adj, out_node, out_bbox, dims_of(h, B),
-                       (hipStream_t)stream);
+    launch_decode(adj, node, flags, DSG_ENC_BITS, DSG_ENC_BITS, n_adj_type, n_node_type, node_bits, out_adj, out_node, out_bbox, dims_of(h, B),
+                  (hipStream_t)stream);
     HIP_TRY(h, hipGetLastError());
     return DSG_OK;
 }
+
 
 }  // extern "C"

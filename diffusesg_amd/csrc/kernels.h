@@ -268,7 +268,8 @@ bool t_ema_update(int n, float *const *ema, const float *const *params, const in
 
 void launch_rainbow_loss_backward(CStatePtrs pred, CStatePtrs tgt, const uint8_t *flags, const float *w, float edge_w, float node_w,
                                   float iou_w, int iou_type, const float *sigmas, StatePtrs grad, StatePtrs gradF, Dims d, hipStream_t s);
-void launch_decode_bits(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,
-                        int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d, hipStream_t s);
+// post-decode of the samples; enc_*: 0 'bits', 1 'one_hot', 2 'ddpm' (DSG_ENC_* of dsg.h); node_chans = attribute channels of a node row
+void launch_decode(const float *adj, const float *node, const uint8_t *flags, int enc_adj, int enc_node, int n_adj_type, int n_node_type,
+                   int node_chans, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d, hipStream_t s);
 
 }  // namespace dsg

@@ -2282,19 +2282,47 @@ void launch_rainbow_loss_backward(CStatePtrs pred, CStatePtrs tgt, const uint8_t
                        grad, gradF, d);
 }
 
-// Post-decode of 'bits' samples (sampler_node_adj.py:222-285, attribute_code.py:319-328):
-// value > 0 -> bit 1, channel 0 is the MSB; clamp to [0, n_type-1]; masked; adjacency diagonal zeroed;
-// bbox = node[..., -4:]*0.5+0.5 masked (sampler_node_adj.py:201-209)
-__global__ void decode_bits_kernel(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,
-                                   int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d) {
+// Post-decode of the samples (sampler_node_adj.py:222-285), one thread per adjacency entry / node, for the three encodings of
+// `--node_encoding` / `--edge_encoding` (R/utils/attribute_code.py):
+//   bits    (enc 0; bin2dec :319-328): value > 0 -> bit 1, channel 0 is the MSB; clamp to [0, n_type-1]
+//   one_hot (enc 1; attribute_one_hot_to_int :212-237 after the +-1 threshold of :225 / :245): the FIRST channel whose value is > 0
+//           (torch.argmax over 0/1 entries returns the first maximum), 0 when none is
+//   ddpm    (enc 2; attribute_ddpm_to_int :121-177): the single channel clamped to [-1, 1] is assigned the class i whose interval
+//           (lo_i, hi_i] holds it, lo/hi = center_i -+ L/2 with L = 2/(k-1), center_i = -1 + i L formed in DOUBLE by the reference's
+//           Python floats and compared in fp32 (torch casts the scalar to the tensor's dtype): the same double operations are issued
+//           here with the correctly rounded intrinsics; classes are tried in ascending order and the last match wins, like the
+//           reference's loop; a NaN matches nothing and stays -1, the reference's fill value
+// masked entries and the adjacency diagonal are 0; bbox = node[..., -4:]*0.5+0.5 masked (sampler_node_adj.py:201-209)
+__device__ __forceinline__ int ddpm_class(float x, int k) {
+    if (x != x) return -1;
+    x = fminf(fmaxf(x, -1.0f), 1.0f);
+    const double L = __ddiv_rn(2.0, (double)(k - 1)), half = __dmul_rn(L, 0.5);
+    const int guess = (int)rintf((x + 1.0f) * 0.5f * (float)(k - 1));
+    int out = -1;
+    for (int i = max(guess - 2, 0); i <= min(guess + 2, k - 1); i++) {
+        const double center = __dadd_rn(-1.0, __dmul_rn((double)i, L));
+        const float lo = i == 0 ? -INFINITY : __double2float_rn(__dsub_rn(center, half));
+        const float hi = i == k - 1 ? INFINITY : __double2float_rn(__dadd_rn(center, half));
+        if (x > lo && x <= hi) out = i;
+    }
+    return out;
+}
+__global__ void decode_kernel(const float *adj, const float *node, const uint8_t *flags, int enc_adj, int enc_node, int n_adj_type,
+                              int n_node_type, int node_chans, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n_a = (size_t)d.B * d.N * d.N, n_n = (size_t)d.B * d.N;
     if (idx < n_a) {
         const int j = idx % d.N, i = (idx / d.N) % d.N, b = idx / ((size_t)d.N * d.N);
         int v = 0;
         if (flags[(size_t)b * d.N + i] && flags[(size_t)b * d.N + j] && i != j) {
-            for (int c = 0; c < d.Ca; c++) v = (v << 1) | (adj[(((size_t)b * d.Ca + c) * d.N + i) * d.N + j] > 0.f ? 1 : 0);
-            v = min(max(v, 0), n_adj_type - 1);
+            const float *a = adj + ((size_t)b * d.Ca * d.N + i) * d.N + j;
+            const size_t cs = (size_t)d.N * d.N;
+            if (enc_adj == 0) {
+                for (int c = 0; c < d.Ca; c++) v = (v << 1) | (a[c * cs] > 0.f ? 1 : 0);
+                v = min(max(v, 0), n_adj_type - 1);
+            } else if (enc_adj == 1) {
+                for (int c = d.Ca - 1; c >= 0; c--) if (a[c * cs] > 0.f) v = c;
+            } else v = ddpm_class(a[0], n_adj_type);
         }
         out_adj[idx] = v;
     } else if (idx < n_a + n_n) {
@@ -2302,19 +2330,24 @@ __global__ void decode_bits_kernel(const float *adj, const float *node, const ui
         const bool ok = flags[m];
         int v = 0;
         if (ok) {
-            for (int c = 0; c < node_bits; c++) v = (v << 1) | (node[m * d.Cn + c] > 0.f ? 1 : 0);
-            v = min(max(v, 0), n_node_type - 1);
+            const float *x = node + m * d.Cn;
+            if (enc_node == 0) {
+                for (int c = 0; c < node_chans; c++) v = (v << 1) | (x[c] > 0.f ? 1 : 0);
+                v = min(max(v, 0), n_node_type - 1);
+            } else if (enc_node == 1) {
+                for (int c = node_chans - 1; c >= 0; c--) if (x[c] > 0.f) v = c;
+            } else v = ddpm_class(x[0], n_node_type);
         }
         out_node[m] = v;
         if (out_bbox)
             for (int c = 0; c < 4; c++) out_bbox[m * 4 + c] = ok ? node[m * d.Cn + (d.Cn - 4) + c] * 0.5f + 0.5f : 0.f;
     }
 }
-void launch_decode_bits(const float *adj, const float *node, const uint8_t *flags, int n_adj_type, int n_node_type,
-                        int node_bits, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d, hipStream_t s) {
+void launch_decode(const float *adj, const float *node, const uint8_t *flags, int enc_adj, int enc_node, int n_adj_type, int n_node_type,
+                   int node_chans, int32_t *out_adj, int32_t *out_node, float *out_bbox, Dims d, hipStream_t s) {
     const size_t n = (size_t)d.B * d.N * d.N + (size_t)d.B * d.N;
-    DSG_LAUNCH(decode_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, adj, node, flags, n_adj_type,
-                       n_node_type, node_bits, out_adj, out_node, out_bbox, d);
+    DSG_LAUNCH(decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, adj, node, flags, enc_adj, enc_node, n_adj_type,
+               n_node_type, node_chans, out_adj, out_node, out_bbox, d);
 }
 
 }  // namespace dsg

@@ -123,6 +123,36 @@ def decode_bits(net, adj: torch.Tensor, node: torch.Tensor, node_flags: torch.Te
     return qa, qn, bb
 
 
+def decode(net, adj: torch.Tensor, node: torch.Tensor, node_flags: torch.Tensor, n_adj_type: int, n_node_type: int,
+           edge_encoding: str = "bits", node_encoding: str = "bits", bbox: bool = True):
+    """On-device post-decode for any of the reference's attribute encodings ('bits' | 'one_hot' | 'ddpm';
+    R/runner/sampler/sampler_node_adj.py:222-285 -> attribute_converter, R/utils/attribute_code.py:13) -> (q_adj [B,N,N] int32,
+    q_node [B,N] int32, bbox [B,N,4] | None).  'ddpm' adjacencies may come squeezed to [B,N,N] as the sampler returns them."""
+    from .lib import ENCODINGS
+    for e in (edge_encoding, node_encoding):
+        if e not in ENCODINGS:
+            raise ValueError("encoding should be 'int', 'ddpm', 'bits' or 'one_hot'")   # attribute_code.py:43
+    from .lib import Handle
+    if isinstance(net, Handle):   # the decode needs the handle only for N / C_adj / C_node: a bare handle (no weights) will do
+        h, cfg, dev = net, net.cfg, torch.device("cuda", torch.cuda.current_device())
+    else:
+        m = getattr(net, "model", net)
+        h, cfg, dev = m._ensure_handle(), m.config, m._dev
+    B, n = node_flags.shape[0], cfg.max_node_num
+    a = adj.to(device=dev, dtype=torch.float32).reshape(B, cfg.c_adj, n, n).contiguous()
+    x = node.to(device=dev, dtype=torch.float32).reshape(B, n, cfg.c_node).contiguous()
+    fl = node_flags.to(device=dev).to(torch.uint8).contiguous()
+    node_chans = cfg.c_node - 4 if bbox else cfg.c_node
+    qa = torch.empty((B, n, n), dtype=torch.int32, device=dev)
+    qn = torch.empty((B, n), dtype=torch.int32, device=dev)
+    bb = torch.empty((B, n, 4), dtype=torch.float32, device=dev) if bbox else None
+    st = torch.cuda.current_stream(dev).cuda_stream
+    h.check(h.L.dsg_decode(h.raw, B, a.data_ptr(), x.data_ptr(), fl.data_ptr(), ENCODINGS[edge_encoding], ENCODINGS[node_encoding],
+                           int(n_adj_type), int(n_node_type), node_chans, qa.data_ptr(), qn.data_ptr(),
+                           None if bb is None else bb.data_ptr(), C.c_void_p(st)), "dsg_decode")
+    return qa, qn, bb
+
+
 def pack_decoded(q_adj: torch.Tensor, q_node: torch.Tensor, bbox: Optional[torch.Tensor], node_flags: torch.Tensor) -> torch.Tensor:
     """Decoded graphs as one int16 row per sample, the unit of the single all-gather of decoded results:
     [ q_adj N*N | q_node N | flags N | bbox 4N fp32 viewed as 8N int16 ]  -- VG: 2*(4096+64+64)+1024 = 9.3 KB, COCO 4.6 KB

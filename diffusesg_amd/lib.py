@@ -14,7 +14,7 @@ MAX_LAYERS = 8
 EXPORTS = [
     "dsg_create", "dsg_destroy", "dsg_last_error", "dsg_version", "dsg_abi_version", "dsg_set_weight", "dsg_finalize_weights",
     "dsg_num_weight_keys", "dsg_weight_key", "dsg_workspace_bytes", "dsg_denoise", "dsg_precond", "dsg_sample",
-    "dsg_sigma_schedule", "dsg_debug_tap", "dsg_debug_clear_taps", "dsg_decode_bits", "dsg_profile_forward", "dsg_set_option",
+    "dsg_sigma_schedule", "dsg_debug_tap", "dsg_debug_clear_taps", "dsg_decode_bits", "dsg_decode", "dsg_profile_forward", "dsg_set_option",
     "dsg_get_option", "dsg_gen_noise", "dsg_train_inputs", "dsg_rainbow_loss", "dsg_rainbow_loss_backward", "dsg_noise_embed", "dsg_affine_width", "dsg_block_train", "dsg_train_grads", "dsg_train_step_grads", "dsg_train_self_cond", "dsg_train_bind_params", "dsg_adam_step", "dsg_ema_update", "dsg_debug_gemm", "dsg_debug_gemm_bx", "dsg_debug_attn_bx", "dsg_debug_qkv_attn_bx", "dsg_debug_projmlp_bx", "dsg_debug_mlp_bx", "dsg_profile_clock_ghz",
 ]
 
@@ -124,8 +124,13 @@ def load(path: Optional[str] = None) -> C.CDLL:
     L.dsg_rainbow_loss_backward.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, C.c_float, i32, vp, vp, vp, vp, vp, vp]
     L.dsg_profile_forward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     L.dsg_decode_bits.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.dsg_decode.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     _lib = L
     return L
+
+
+# `--edge_encoding` / `--node_encoding` of the reference (R/utils/arg_parser.py) -> DSG_ENC_* (include/dsg.h)
+ENCODINGS = {"bits": 0, "one_hot": 1, "ddpm": 2}
 
 
 # iou_loss_type of the trainer's bounding-box term (trainer_node_adj.py:138-153) -> DSG_IOU_* (include/dsg.h)

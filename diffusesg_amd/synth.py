@@ -123,6 +123,24 @@ BIG_TRAJ = {
 }
 
 
+# Trajectories of REALISTIC length on the full-size networks ("looser stated bound + decoded-bit agreement rate at
+# T >= 50"): 50 Heun + churn steps = 99 preconditioned calls + the coins' extra forwards through the reference's own sampler;
+# the fixture holds the final raw (adj, node) and the reference-decoded integer graphs ('bits'; dataset, #edge types, #node types)
+LONG_TRAJ = {
+    "vg_heun50": ("vg", 50, "heun", 40.0, [30, 11], 71, "vg/long50", None, ("visual_genome", 51, 150)),
+    "coco_heun50": ("coco", 50, "heun", 40.0, [20, 40], 73, "coco/long50", None, ("coco_stuff", 7, 171)),
+}
+
+
+def long_traj_case(tag: str):
+    """cfg, T, solver, S_churn, flags, init_adj, init_node, noise_adj, noise_node, coins (uint8), (dataset, n_adj_type, n_node_type)"""
+    name, T, solver, churn, valid, seed, stream, coins, types = LONG_TRAJ[tag]
+    cfg = CONFIGS[name]()
+    flags, ia, inn, na, nn, cv = sampler_case(cfg, T, len(valid), valid, seed, stream, solver)
+    c = np.asarray(coins, np.uint8) if coins is not None else (cv < 0.5).astype(np.uint8)
+    return cfg, T, solver, churn, flags, ia, inn, na, nn, c, types
+
+
 def big_traj_case(tag: str):
     """cfg, T, solver, S_churn, flags, init_adj, init_node, noise_adj, noise_node, coins (uint8) of a BIG_TRAJ case"""
     name, T, solver, churn, valid, seed, stream, coins = BIG_TRAJ[tag]
@@ -154,6 +172,76 @@ def decode_case(name: str):
     adj.reshape(-1)[::7] = 0.0
     node.reshape(-1)[::5] = 0.0
     return cfg, flags, adj, node
+
+
+# ---- post-decode fixture for the other two encodings (`--edge_encoding` / `--node_encoding` = 'one_hot' | 'ddpm';
+# sampler_node_adj.py:222-285 -> attribute_converter, attribute_code.py:13).  (dataset, edge enc, node enc, N, valid counts) ----
+DECODE_ENC_CASES = {
+    "vg_onehot": ("visual_genome", "one_hot", "one_hot", 64, [30, 64, 2]),
+    "vg_ddpm": ("visual_genome", "ddpm", "ddpm", 64, [30, 64, 2]),
+    "coco_onehot": ("coco_stuff", "one_hot", "one_hot", 40, [20, 40, 1]),
+    "coco_ddpm": ("coco_stuff", "ddpm", "ddpm", 40, [20, 40, 1]),
+    "vg_bits_ddpm": ("visual_genome", "bits", "ddpm", 64, [30, 64, 2]),      # mixed: the two flags are independent in the reference
+    "coco_onehot_bits": ("coco_stuff", "one_hot", "bits", 40, [20, 40, 1]),
+}
+
+
+def _ddpm_edges(k: int) -> np.ndarray:
+    """fp32 values on and right next to every interval edge of attribute_ddpm_to_int's k classes (the reference builds the edges
+    with Python floats and compares in fp32), plus the class centres"""
+    L = 2.0 / (k - 1)
+    vals = []
+    for i in range(k):
+        c = -1.0 + i * L
+        for e in (c - 0.5 * L, c + L * 0.5, c):
+            f = np.float32(e)
+            vals += [f, np.nextafter(f, np.float32(-2)), np.nextafter(f, np.float32(2))]
+    return np.array(vals, np.float32)
+
+
+def decode_enc_case(name: str):
+    """cfg (channel counts of the encoding: one channel per type, or a single one, + 4 bbox channels), flags, raw adj, raw node as the
+    sampler would return them.  one_hot: several channels positive (the FIRST wins), none positive (class 0), exact zeros (0 is not
+    > 0), values beyond [-1,1].  ddpm: values on and one ulp either side of every interval edge, exact -1 / +1, values beyond the range."""
+    dataset, e_adj, e_node, n, valid = DECODE_ENC_CASES[name]
+    ch_a, ch_n = S.sg_channels(dataset, e_adj), S.sg_channels(dataset, e_node)
+    raw = S.sg_channels(dataset, "one_hot")
+    n_adj_type, n_node_type = raw["c_adj"], raw["c_node"] - 4
+    cfg = S.ModelConfig(max_node_num=n, c_adj=ch_a["c_adj"], c_node=ch_n["c_node"], depths=(1, 1), num_heads=(3, 6),
+                        window_size=8 if n == 64 else 10, self_condition=True)
+    B = 3
+    flags = W.synth_flags(B, n, valid)
+    adj = (W.normal(11, f"decenc/{name}/adj", (B, cfg.c_adj, n, n)) * np.float32(1.5)).astype(np.float32)
+    node = (W.normal(11, f"decenc/{name}/node", (B, n, cfg.c_node)) * np.float32(1.5)).astype(np.float32)
+    if e_adj == "one_hot":
+        adj -= np.float32(2.2)                     # mostly negative: a handful of positive channels per entry, sometimes none
+        adj.reshape(-1)[::7] = 0.0
+    elif e_adj == "ddpm":
+        adj *= np.float32(0.6)
+        ed = _ddpm_edges(n_adj_type)
+        st = adj.size // len(ed)
+        adj.reshape(-1)[: st * len(ed): st] = ed
+        adj.reshape(-1)[3::97] = 1.0
+        adj.reshape(-1)[5::89] = -1.0
+    else:
+        adj.reshape(-1)[::7] = 0.0
+    attr = node[..., :-4]
+    if e_node == "one_hot":
+        attr -= np.float32(2.6)
+        attr.reshape(B, -1)[:, ::5] = 0.0
+    elif e_node == "ddpm":
+        attr *= np.float32(0.6)
+        ed = _ddpm_edges(n_node_type)
+        flat = attr.reshape(-1)
+        take = min(len(ed), len(flat))
+        flat[:take] = ed[np.linspace(0, len(ed) - 1, take).astype(int)]
+        flat[1::13] = 1.0
+        flat[2::17] = -1.0
+        attr = flat.reshape(attr.shape)
+    else:
+        attr.reshape(-1)[::5] = 0.0
+    node[..., :-4] = attr
+    return cfg, flags, adj, node, e_adj, e_node, n_adj_type, n_node_type
 
 
 # ---- training-time forward fixture (SURVEY G7; trainer_node_adj.py:96-163 in 'test' mode: objective -> model -> loss) ----

@@ -195,8 +195,20 @@ double dsg_profile_clock_ghz(dsg_handle h);
 int dsg_debug_tap(dsg_handle h, const char *stage, float *dst, int64_t capacity);
 void dsg_debug_clear_taps(dsg_handle h);
 
-/* On-device post-decode of 'bits'-encoded samples (sampler_node_adj.py:222-285):
- * clamp(-1,1) -> >0 -> MSB-first integer -> clamp to [0, n_type-1]; adjacency diagonal zeroed. */
+/* On-device post-decode of the samples (sampler_node_adj.py:222-285) for the reference's three attribute encodings
+ * (`--edge_encoding` / `--node_encoding`; R/utils/attribute_code.py:13 attribute_converter(..., out_encoding='int')):
+ *   DSG_ENC_BITS     clamp(-1,1) -> > 0 -> MSB-first integer (bin2dec, :319) -> clamp to [0, n_type-1]
+ *   DSG_ENC_ONE_HOT  clamp -> +-1 threshold at 0 -> argmax over the channels (:212-237): the first positive channel, 0 if none
+ *   DSG_ENC_DDPM     clamp -> the class whose interval (lo_i, hi_i] of width 2/(n_type-1) around -1 + 2i/(n_type-1) holds the
+ *                    value (:121-177; the reference's double-precision thresholds compared in fp32), -1 for NaN
+ * Rows / columns of padded nodes and the adjacency diagonal are 0.  adj [B,C_adj,N,N] (C_adj = bits | n_adj_type | 1), node
+ * [B,N,C_node]: the first node_chans channels are the attribute (bits | n_node_type | 1), the last four the bounding box when
+ * out_bbox != NULL (-> *0.5+0.5, masked; :201-209).  Needs the handle only for N / C_adj / C_node (no weights). */
+enum { DSG_ENC_BITS = 0, DSG_ENC_ONE_HOT = 1, DSG_ENC_DDPM = 2 };
+int dsg_decode(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags, int32_t edge_encoding,
+               int32_t node_encoding, int32_t n_adj_type, int32_t n_node_type, int32_t node_chans,
+               int32_t *out_adj /*[B,N,N]*/, int32_t *out_node /*[B,N]*/, float *out_bbox /*[B,N,4] or NULL*/, void *stream);
+/* dsg_decode with both encodings 'bits' (the README's recipe) */
 int dsg_decode_bits(dsg_handle h, int32_t B, const float *adj, const float *node, const uint8_t *flags,
                     int32_t n_adj_type, int32_t n_node_type, int32_t node_bits,
                     int32_t *out_adj /*[B,N,N]*/, int32_t *out_node /*[B,N]*/, float *out_bbox /*[B,N,4] or NULL*/,

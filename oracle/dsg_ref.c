@@ -751,6 +751,97 @@ int dsgref_decode_bits(dsgref *h, int B, const float *adj, const float *node, co
     return 0;
 }
 
+/* The other two attribute encodings of the post-decode (`--node_encoding` / `--edge_encoding` = 'one_hot' | 'ddpm'):
+ * _decode_node / _decode_adj (R/runner/sampler/sampler_node_adj.py:222-285) hand the clamped sample to
+ * attribute_converter(in_encoding=..., out_encoding='int', flag_in_ddpm_range=True) (R/utils/attribute_code.py:13-58).
+ *   one_hot  :225 / :245 threshold to +-1, mask -> attribute_one_hot_to_int (:212-237): (x+1)/2, mask, argmax over the channels
+ *            (torch.argmax: the first maximal value), mask.
+ *   ddpm     attribute_ddpm_to_int (:121-177): _get_intervals builds, with Python floats (doubles), L = 2.0/(k-1),
+ *            center_i = -1.0 + i*L, min_i = center_i - 0.5*L (i = 0: -inf), max_i = center_i + L*0.5 (i = k-1: +inf);
+ *            _assign_integers fills -1 and, for i ascending, sets i where (x > min_i) & (x <= max_i) -- torch compares an fp32
+ *            tensor with a Python scalar in fp32, i.e. the thresholds are rounded to float first; then mask_nodes / mask_adjs.
+ * enc: 0 'bits' (above), 1 'one_hot', 2 'ddpm'.  The adjacency diagonal is zeroed last (:279-283).  The threshold arithmetic goes
+ * through volatile doubles, so center_i is a rounded product plus a rounded sum like CPython's (no FMA contraction).  Pinned by tests/golden/decode_enc.npz (the imported attribute_converter itself). */
+static int dsgref_ddpm_class(float x, int k) {
+    if (x != x) return -1;                                       /* NaN lies in no interval: the fill value stays */
+    x = fminf(fmaxf(x, -1.0f), 1.0f);                            /* sampler_node_adj.py:223 / :243 */
+    const double L = 2.0 / (double)(k - 1);
+    int out = -1;
+    for (int i = 0; i < k; i++) {
+        volatile double prod = (double)i * L;                    /* (volatile: one rounding per Python operation) */
+        volatile double center = -1.0 + prod;
+        volatile double half = L * 0.5;
+        volatile double dlo = center - half, dhi = center + half;
+        const float lo = i == 0 ? -INFINITY : (float)dlo, hi = i == k - 1 ? INFINITY : (float)dhi;
+        if (x > lo && x <= hi) out = i;
+    }
+    return out;
+}
+int dsgref_decode(dsgref *h, int B, const float *adj, const float *node, const uint8_t *flags, int enc_adj, int enc_node, int n_adj_type,
+                  int n_node_type, int node_chans, int32_t *out_adj, int32_t *out_node, float *out_bbox) {
+    const int N = h->N, Ca = h->c_adj, Cn = h->c_node;
+    if (enc_adj == 0 && enc_node == 0)
+        return dsgref_decode_bits(h, B, adj, node, flags, n_adj_type, n_node_type, node_chans, out_adj, out_node, out_bbox);
+    if (n_adj_type < 2 || n_node_type < 2) return -1;
+    /* bits on one side only: decode both as bits first, then overwrite the other side below */
+    if (enc_adj == 0 || enc_node == 0) {
+        int32_t *ta = (int32_t *)malloc(sizeof(int32_t) * (size_t)B * N * N), *tn = (int32_t *)malloc(sizeof(int32_t) * (size_t)B * N);
+        dsgref_decode_bits(h, B, adj, node, flags, n_adj_type, n_node_type, enc_node == 0 ? node_chans : 1, ta, tn, NULL);
+        if (enc_adj == 0) memcpy(out_adj, ta, sizeof(int32_t) * (size_t)B * N * N);
+        if (enc_node == 0) memcpy(out_node, tn, sizeof(int32_t) * (size_t)B * N);
+        free(ta); free(tn);
+    }
+    for (int b = 0; b < B; b++) {
+        const uint8_t *f = flags + (size_t)b * N;
+        if (enc_adj != 0)
+            for (int i = 0; i < N; i++)
+                for (int j = 0; j < N; j++) {
+                    const int ok = f[i] && f[j];
+                    int v = 0;
+                    if (enc_adj == 1) {
+                        float best = -1.0f;
+                        for (int c = 0; c < Ca; c++) {
+                            float x = adj[(((size_t)b * Ca + c) * N + i) * N + j];
+                            x = fminf(fmaxf(x, -1.0f), 1.0f);                       /* :243 */
+                            float y = x > 0.0f ? 1.0f : -1.0f;                       /* :245-246 */
+                            if (!ok) y = 0.0f;                                       /* :247 mask_adjs */
+                            y = (y + 1.0f) / 2.0f;                                   /* attribute_code.py:225 */
+                            if (!ok) y = 0.0f;                                       /* :226 */
+                            if (y > best) { best = y; v = c; }                       /* :230 argmax, first maximum */
+                        }
+                    } else v = dsgref_ddpm_class(adj[(((size_t)b * Ca) * N + i) * N + j], n_adj_type);
+                    if (!ok) v = 0;                                                  /* :232 / :172-173 mask */
+                    if (i == j) v = 0;                                               /* sampler_node_adj.py:281 */
+                    out_adj[((size_t)b * N + i) * N + j] = v;
+                }
+        for (int i = 0; i < N; i++) {
+            if (enc_node != 0) {
+                int v = 0;
+                if (enc_node == 1) {
+                    float best = -1.0f;
+                    for (int c = 0; c < node_chans; c++) {
+                        float x = node[((size_t)b * N + i) * Cn + c];
+                        x = fminf(fmaxf(x, -1.0f), 1.0f);                           /* :223 */
+                        float y = x > 0.0f ? 1.0f : -1.0f;                           /* :225 */
+                        if (!f[i]) y = 0.0f;                                         /* :226 mask_nodes */
+                        y = (y + 1.0f) / 2.0f;
+                        if (!f[i]) y = 0.0f;
+                        if (y > best) { best = y; v = c; }
+                    }
+                } else v = dsgref_ddpm_class(node[((size_t)b * N + i) * Cn], n_node_type);
+                if (!f[i]) v = 0;
+                out_node[(size_t)b * N + i] = v;
+            }
+            if (out_bbox)
+                for (int c = 0; c < 4; c++) {                                       /* :201-209 */
+                    const float x = node[((size_t)b * N + i) * Cn + (Cn - 4) + c];
+                    out_bbox[((size_t)b * N + i) * 4 + c] = f[i] ? x * 0.5f + 0.5f : 0.0f;
+                }
+        }
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* training-time objective and loss, forward only (first half)                   */
 /* ------------------------------------------------------------------------------------------ */

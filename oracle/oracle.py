@@ -54,6 +54,7 @@ def lib():
         L.dsgref_rainbow_loss_backward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_int] + [C.c_void_p] * 5
         L.dsgref_noise_embed.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
         L.dsgref_decode_bits.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 3
+        L.dsgref_decode.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p] * 3
         _lib = L
     return _lib
 
@@ -169,6 +170,23 @@ class Oracle:
         bb = np.empty((B, c.max_node_num, 4), np.float32) if bbox else None
         lib().dsgref_decode_bits(self._h, B, _p(adj), _p(node), _p(fl), int(n_adj_type), int(n_node_type),
                                  c.c_node - 4 if bbox else c.c_node, _p(qa), _p(qn), _p(bb))
+        return qa, qn, bb
+
+    def decode(self, adj, node, flags, edge_encoding, node_encoding, n_adj_type, n_node_type, bbox=True):
+        """samples in any of the reference's encodings ('bits' | 'one_hot' | 'ddpm') -> (q_adj, q_node, bbox | None);
+        sampler_node_adj.py:222-285 with attribute_code.py:13 (attribute_converter(..., out_encoding='int'))"""
+        enc = {"bits": 0, "one_hot": 1, "ddpm": 2}
+        B = flags.shape[0]
+        sa, sn = self._shapes(B)
+        c = self.cfg
+        adj, node = _f32(adj).reshape(sa), _f32(node).reshape(sn)
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        qa = np.empty((B, c.max_node_num, c.max_node_num), np.int32)
+        qn = np.empty((B, c.max_node_num), np.int32)
+        bb = np.empty((B, c.max_node_num, 4), np.float32) if bbox else None
+        rc = lib().dsgref_decode(self._h, B, _p(adj), _p(node), _p(fl), enc[edge_encoding], enc[node_encoding], int(n_adj_type),
+                                 int(n_node_type), c.c_node - 4 if bbox else c.c_node, _p(qa), _p(qn), _p(bb))
+        assert rc == 0
         return qa, qn, bb
 
     def train_inputs(self, clean_adj, clean_node, flags, rnd, eps_adj, eps_node):

@@ -346,6 +346,36 @@ def test_decode_bits_vs_reference_fixture(name):
     assert torch.equal(a2, oa) and torch.equal(n2, on) and torch.equal(b2, ob) and torch.equal(f2.cpu(), torch.from_numpy(flags))
 
 
+@pytest.mark.parametrize("name", sorted(Y.DECODE_ENC_CASES))
+def test_decode_one_hot_and_ddpm_vs_reference_fixture(name):
+    """dsg_decode for `--edge_encoding` / `--node_encoding` in {'one_hot', 'ddpm'} (and mixed with 'bits') against
+    tests/golden/decode_enc.npz -- the reference's own attribute_converter inside the restated _decode_node / _decode_adj closures
+    (tools/gen_golden.py::gen_decode_enc; sampler_node_adj.py:222-285, attribute_code.py:13): BIT-EXACT on the integer graphs and the
+    bbox.  Inputs: several / no positive one_hot channels (the first wins / class 0), exact zeros, values beyond [-1,1]; ddpm values on
+    and one ulp either side of every interval edge (the reference's double-precision edges compared in fp32).  The handle has no
+    weights: the decode only needs the dimensions."""
+    from diffusesg_amd import io as dio
+    from diffusesg_amd import lib as L
+    g = load("decode_enc.npz")
+    cfg, flags, adj, node, e_adj, e_node, n_adj, n_node = Y.decode_enc_case(name)
+    h = L.Handle(cfg)
+    oa, on, ob = dio.decode(h, T(adj), T(node), T(flags), n_adj, n_node, edge_encoding=e_adj, node_encoding=e_node)
+    assert np.array_equal(oa.cpu().numpy(), g[f"{name}_q_adj"].astype(np.int32)), "q_adj"
+    assert np.array_equal(on.cpu().numpy(), g[f"{name}_q_node"].astype(np.int32)), "q_node"
+    assert np.array_equal(ob.cpu().numpy(), g[f"{name}_bbox"]), "bbox"
+    # NaN lies in no ddpm interval: the reference's fill value -1 stays (attribute_code.py:153); one_hot / bits treat it as "not > 0"
+    bad = adj.copy(); bad[0, :, 0, 1] = np.nan
+    oa2, _, _ = dio.decode(h, T(bad), T(node), T(flags), n_adj, n_node, edge_encoding=e_adj, node_encoding=e_node)
+    assert int(oa2[0, 0, 1]) == (-1 if e_adj == "ddpm" else 0)
+    # the packed int16 hand-off is lossless for these codes too
+    a2, n2, f2, b2 = dio.unpack_decoded(dio.pack_decoded(oa, on, ob, T(flags)), cfg.max_node_num, True)
+    assert torch.equal(a2, oa) and torch.equal(n2, on) and torch.equal(b2, ob)
+    # an encoding that does not fit the channel counts is a status, not a wrong answer
+    with pytest.raises(L.DsgError, match="does not fit"):
+        dio.decode(h, T(adj), T(node), T(flags), n_adj + 1, n_node, edge_encoding="one_hot" if e_adj != "one_hot" else "ddpm", node_encoding=e_node)
+    h.close()
+
+
 def test_end_to_end_checkpoint_sample_decode_npz(tmp_path):
     """§8f hand-offs around the hot path: reference-format checkpoint -> strict load -> sample -> device decode -> npz."""
     from diffusesg_amd import io as dio
@@ -1000,6 +1030,52 @@ def test_coco_short_trajectory_vs_reference(mode):
         # (measured 3e-2..6e-2 max / 5e-3..7e-3 RMS, moving with every fp32-level reordering upstream of a bf16 rounding)
         assert ea <= 1.5e-1 and en <= 1.5e-1
         assert rms_rel(oa.numpy(), ra) <= 2e-2 and rms_rel(on.numpy(), rn) <= 2e-2
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("tag", sorted(Y.LONG_TRAJ))
+def test_long_trajectory_vs_reference_with_decoded_agreement(tag, mode):
+    """SURVEY §8c G4 on the FULL-SIZE networks at realistic length: VG and COCO-Stuff, B = 2, T = 50 Heun + churn (99 preconditioned calls
+    + the coins' extra forwards) against the reference's own sampler run with replayed noise and coins, and the decoded integer graphs
+    against the REFERENCE's decode of its own result (tests/golden/traj_long.npz, tools/gen_golden.py::gen_long_trajectories;
+    R/runner/mcmc_sampler/edm.py:350-427, R/runner/sampler/sampler_node_adj.py:222-285).
+    fp32: continuous outputs to 1e-3 of the output scale (the stated looser bar for T >= 50), decoded agreement >= 99.9 %.
+    bf16 mode: continuous bar 1.5e-1 max / 2e-2 RMS (the trajectory bar of the mode), and the decoded agreement WITH THE REFERENCE is printed
+    and floored -- a +-1-thresholded decode flips wherever the continuous output lies within the mode's error of 0."""
+    from diffusesg_amd.model import build_network
+    from diffusesg_amd import io as dio
+    cfg, T_, solver, churn, flags, ia, inn, na, nn, coins, (dataset, n_adj, n_node) = Y.long_traj_case(tag)
+    g = load("traj_long.npz")
+    ra, rn = g[f"{tag}_adj"], g[f"{tag}_node"]
+    rqa, rqn, rbb = g[f"{tag}_q_adj"].astype(np.int32), g[f"{tag}_q_node"].astype(np.int32), g[f"{tag}_bbox"]
+    name = Y.LONG_TRAJ[tag][0]
+    net = net_for(name) if mode == "f32" else build_network(cfg, W.synth_state_dict(cfg, 0), device="cuda")
+    if mode == "bf16":
+        net.model._ensure_handle().set_option("gemm_bf16", 1)
+        assert net.model._ensure_handle().precision_mode() == "bf16" and net.model._ensure_handle().get_option("bf16_pipe") == 1
+    smp = make_sampler(T_, solver, churn)
+    oa, on = smp.sample(net, T(flags), init_adjs=T(ia), init_nodes=T(inn), churn_noise=(T(na), T(nn)), coins=coins,
+                        num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    assert smp.last_stats["precond_calls"] == int(g[f"{tag}_coins_used"]) == 2 * T_ - 1
+    qa, qn, bb = dio.decode_bits(net.model, oa.cuda(), on.cuda(), T(flags), n_adj_type=n_adj, n_node_type=n_node)
+    qa, qn, bb = qa.cpu().numpy(), qn.cpu().numpy(), bb.cpu().numpy()
+    f = flags.astype(bool)
+    valid_e = f[:, :, None] & f[:, None, :] & ~np.eye(cfg.max_node_num, dtype=bool)[None]
+    agree_a, agree_n = float((qa == rqa)[valid_e].mean()), float((qn == rqn)[f].mean())
+    # per-bit agreement of the thresholded channels (a wrong class = at least one flipped bit)
+    bits_a = float(((oa.numpy() > 0) == (ra > 0))[np.broadcast_to(valid_e[:, None], ra.shape)].mean())
+    ea, en = rel_err(oa.numpy(), ra), rel_err(on.numpy(), rn)
+    print(f"{tag} {mode}: max {ea:.2e}/{en:.2e} rms {rms_rel(oa.numpy(), ra):.2e}/{rms_rel(on.numpy(), rn):.2e}; decoded agreement with the "
+          f"reference: edges {agree_a:.5f} ({int(valid_e.sum())} entries), nodes {agree_n:.5f} ({int(f.sum())}), adjacency bits {bits_a:.5f}")
+    assert np.array_equal(qa[~(f[:, :, None] & f[:, None, :])], rqa[~(f[:, :, None] & f[:, None, :])])   # padded region: zeros on both sides
+    if mode == "f32":
+        assert ea <= 1e-3 and en <= 1e-3
+        assert agree_a >= 0.999 and agree_n >= 0.999
+        assert np.abs(bb - rbb).max() <= 1e-3
+    else:
+        assert ea <= 1.5e-1 and en <= 1.5e-1
+        assert rms_rel(oa.numpy(), ra) <= 2e-2 and rms_rel(on.numpy(), rn) <= 2e-2
+        assert agree_a >= 0.95 and agree_n >= 0.95   # floors; the measured rates are in DESIGN.md §3
 
 
 def test_coco_bf16_full_schedule_decoded_agreement():

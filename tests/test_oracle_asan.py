@@ -31,6 +31,9 @@ assert all(np.isfinite(t).all() for t in g)
 dcfg, dfl, dadj, dnode = Y.decode_case("coco")
 _, n_adj, n_node, _ = Y.DECODE_CASES["coco"]
 Oracle(dcfg, W.synth_state_dict(dcfg, 0)).decode_bits(dadj, dnode, dfl, n_adj, n_node)
+for nm in ("coco_ddpm", "coco_onehot_bits"):
+    ecfg, efl, eadj, enode, e_a, e_n, k_a, k_n = Y.decode_enc_case(nm)
+    Oracle(ecfg, W.synth_state_dict(ecfg, 0)).decode(eadj, enode, efl, e_a, e_n, k_a, k_n)
 print("asan child ok")
 """
 

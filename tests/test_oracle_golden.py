@@ -154,6 +154,21 @@ def test_decode_bits_matches_reference(name):
     assert (qa == n_adj - 1).sum() > 0 and (qn == n_node - 1).sum() > 0   # the clamp is exercised
 
 
+@pytest.mark.parametrize("name", sorted(Y.DECODE_ENC_CASES))
+def test_decode_one_hot_and_ddpm_match_reference(name):
+    """post-decode of 'one_hot' / 'ddpm' samples (and mixed with 'bits'): the oracle against tests/golden/decode_enc.npz, which the
+    reference's own attribute_converter produced inside the restated _decode_node / _decode_adj closures (sampler_node_adj.py:
+    222-285) -- BIT-EXACT, with several / no positive one_hot channels, exact zeros, and ddpm values on and one ulp either side of
+    every interval edge"""
+    g = load("decode_enc.npz")
+    cfg, flags, adj, node, e_adj, e_node, n_adj, n_node = Y.decode_enc_case(name)
+    qa, qn, bb = make_oracle(cfg).decode(adj, node, flags, e_adj, e_node, n_adj, n_node)
+    assert np.array_equal(qa, g[f"{name}_q_adj"].astype(np.int32)), f"{name} q_adj: {(qa != g[f'{name}_q_adj']).sum()} differ"
+    assert np.array_equal(qn, g[f"{name}_q_node"].astype(np.int32)), f"{name} q_node: {(qn != g[f'{name}_q_node']).sum()} differ"
+    assert np.array_equal(bb, g[f"{name}_bbox"])
+    assert len(np.unique(qa)) == n_adj   # every edge class occurs
+
+
 def test_train_forward_matches_reference():
     """forward half of a training / test-loss step (trainer_node_adj.py:96-163 in 'test' mode) against tests/golden/
     train_forward.npz: the objective generator's sigmas / weights / noisy inputs from replayed draws, the preconditioned

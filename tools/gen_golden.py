@@ -280,6 +280,57 @@ def gen_big_trajectories(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, out):
     np.savez_compressed(os.path.join(out, "traj_big.npz"), **res)
 
 
+def ref_decode_bits(adj, node, flags, raw_num_adj_type, raw_num_node_type):
+    """`_decode_node` / `_decode_adj`, 'bits' branch (sampler_node_adj.py:194-209, :222-233, :242-247, :265-275, :279-283), restated
+    statement by statement around the reference's OWN bin2dec / mask_nodes / mask_adjs -> (q_adj, q_node, bbox) as numpy"""
+    from utils.attribute_code import bin2dec
+    from utils.graph_utils import mask_adjs, mask_nodes
+    node_flags = t(flags)
+    final_samples_adjs, final_samples_nodes = t(adj.copy()), t(node.copy())
+    final_samples_nodes, final_samples_nodes_bbox = final_samples_nodes[..., :-4], final_samples_nodes[..., -4:]
+    final_samples_nodes_bbox = final_samples_nodes_bbox * 0.5 + 0.5
+    final_samples_nodes_bbox = mask_nodes(final_samples_nodes_bbox.cpu(), node_flags.cpu())
+    node_samples = final_samples_nodes.clamp(-1.0, 1.0)
+    node_samples = torch.where(node_samples > 0.0, torch.ones_like(node_samples), -torch.ones_like(node_samples))
+    node_samples = mask_nodes(node_samples, node_flags)
+    _q_binary_node = node_samples.gt(0.0).cpu().float()
+    _q_binary_node = mask_nodes(_q_binary_node, node_flags.cpu())
+    _q_node = bin2dec(_q_binary_node, num_bits=np.ceil(np.log2(raw_num_node_type)).astype(int))
+    _q_node = mask_nodes(_q_node, node_flags.cpu()).clamp(min=0, max=raw_num_node_type - 1)
+    adj_samples = final_samples_adjs.clamp(-1.0, 1.0)
+    adj_samples = torch.where(adj_samples > 0.0, torch.ones_like(adj_samples), -torch.ones_like(adj_samples))
+    adj_samples = mask_adjs(adj_samples, node_flags)
+    _q_binary_adj = adj_samples.gt(0.0).cpu().float()
+    _q_binary_adj = mask_adjs(_q_binary_adj, node_flags.cpu())
+    _q_binary_adj = _q_binary_adj.permute(0, 2, 3, 1)
+    _q_adj = bin2dec(_q_binary_adj, num_bits=np.ceil(np.log2(raw_num_adj_type)).astype(int))
+    _q_adj = mask_adjs(_q_adj, node_flags.cpu()).clamp(min=0, max=raw_num_adj_type - 1)
+    b, n = node_flags.shape[:2]
+    _q_adj[:, torch.eye(n, device=_q_adj.device).bool()] = 0.0
+    return _q_adj.contiguous().numpy(), _q_node.numpy(), final_samples_nodes_bbox.numpy().astype(np.float32)
+
+
+def gen_long_trajectories(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, out):
+    """SURVEY §8c G4 at realistic length on the full-size networks: the VG and COCO-Stuff nets, B = 2, T = 50 Heun + churn through the
+    REFERENCE's own sampler with replayed noise and coins (Y.LONG_TRAJ; ~150 network forwards of 2 graphs each), and the reference's
+    'bits' decode of the result (ref_decode_bits).  Stored: the final raw (adj, node) in full (padded rows / columns are zeros and
+    compress away) and the decoded integer graphs + bbox.  The GPU tests compare the fp32 and the bf16 HIP paths with these: a stated
+    continuous bound and the decoded agreement as a RATE against the reference's decode."""
+    res = {}
+    for tag, (name, T, solver, churn, valid, seed, stream, coins, (dataset, n_adj, n_node)) in Y.LONG_TRAJ.items():
+        cfg = CONFIGS[name]()
+        a, nd, _sig, used = run_ref_sampler(NodeAdjEDMSampler, NodeAdjPrecond, DiffuseSG, cfg, T=T, B=len(valid), valid=valid, seed=seed,
+                                            tag=stream, solver=solver, S_churn=churn, coins=coins)
+        flags = W.synth_flags(len(valid), cfg.max_node_num, valid)
+        qa, qn, bb = ref_decode_bits(a, nd, flags, n_adj, n_node)
+        res[f"{tag}_adj"], res[f"{tag}_node"], res[f"{tag}_coins_used"] = a, nd, np.array(used)
+        res[f"{tag}_q_adj"], res[f"{tag}_q_node"], res[f"{tag}_bbox"] = qa.astype(np.int16), qn.astype(np.int16), bb
+        near0 = float((np.abs(a[a != 0]) < 1e-3).mean())
+        print(f"long trajectory {tag}: max|adj| {np.abs(a).max():.3f} max|node| {np.abs(nd).max():.3f} coins used {used}; "
+              f"|adj| < 1e-3 on {near0:.2%} of the valid entries; edge classes {len(np.unique(qa))}, node classes {len(np.unique(qn))}", flush=True)
+    np.savez_compressed(os.path.join(out, "traj_long.npz"), **res)
+
+
 def gen_decode(out):
     """G6: the post-decode of 'bits' samples.  `_decode_node` / `_decode_adj` are closures inside sg_go_sampling
     (R/runner/sampler/sampler_node_adj.py:222-285; that module itself needs torchvision/pyemd and cannot be imported), so
@@ -327,6 +378,101 @@ def gen_decode(out):
         print(f"decode {name}: q_adj max {qa.max():.0f} (clamped at {raw_num_adj_type - 1}: {(qa == raw_num_adj_type - 1).sum()}), "
               f"q_node max {qn.max():.0f} (clamped at {raw_num_node_type - 1}: {(qn == raw_num_node_type - 1).sum()})")
     np.savez_compressed(os.path.join(out, "decode.npz"), **res)
+
+
+def gen_decode_enc(out):
+    """The post-decode for `--edge_encoding` / `--node_encoding` in {'one_hot', 'ddpm'} (and mixed with 'bits'): the closures
+    `_decode_node` / `_decode_adj` of sg_go_sampling (R/runner/sampler/sampler_node_adj.py:222-285; the module needs torchvision /
+    pyemd and cannot be imported) restated statement by statement -- every branch, with flag_node_only = flag_binary_edge = False as
+    for scene graphs -- around the reference's OWN `attribute_converter` and `bin2dec` (R/utils/attribute_code.py:13, :319) and
+    `mask_nodes` / `mask_adjs` (R/utils/graph_utils.py), which are imported and do the arithmetic."""
+    from utils.attribute_code import attribute_converter, bin2dec
+    from utils.graph_utils import mask_adjs, mask_nodes
+    from utils.sg_utils import get_node_adj_num_type
+    flag_node_only = flag_binary_edge = False
+    res = {}
+    for name, (dataset, edge_encoding, node_encoding, _n, _valid) in Y.DECODE_ENC_CASES.items():
+        cfg, flags, adj, node, e_adj, e_node, n_adj_type, n_node_type = Y.decode_enc_case(name)
+        for enc, c_have, key in ((edge_encoding, cfg.c_adj, "out_chans_adj"), (node_encoding, cfg.c_node, "out_chans_node")):
+            info = get_node_adj_num_type(dataset, flag_sg=True, encoding=enc, flag_node_only=False, flag_node_bbox=True)
+            assert info[key] == c_have, (name, key, info[key], c_have)
+        raw_num_node_type, raw_num_adj_type = info["raw_num_node_type"], info["raw_num_adj_type"]
+        assert (raw_num_adj_type, raw_num_node_type) == (n_adj_type, n_node_type)
+
+        def _decode_node(node_samples, node_flags, encoding_method):   # sampler_node_adj.py:222-240
+            node_samples = node_samples.clamp(-1.0, 1.0)
+            if encoding_method in ['bits', 'one_hot']:
+                node_samples = torch.where(node_samples > 0.0, torch.ones_like(node_samples), -torch.ones_like(node_samples))
+                node_samples = mask_nodes(node_samples, node_flags)
+            if encoding_method == 'bits':
+                _q_binary_node = node_samples.gt(0.0).cpu().float()
+                _q_binary_node = mask_nodes(_q_binary_node, node_flags.cpu())
+                _q_node = bin2dec(_q_binary_node, num_bits=np.ceil(np.log2(raw_num_node_type)).astype(int))
+                _q_node = mask_nodes(_q_node, node_flags.cpu()).clamp(min=0, max=raw_num_node_type - 1)
+            else:
+                if len(node_samples.shape) == 3 and node_samples.shape[-1] == 1:
+                    node_samples = node_samples.squeeze(-1)
+                _q_node = attribute_converter(in_attr=node_samples, attr_flags=node_flags.cpu(),
+                                              in_encoding=encoding_method, out_encoding='int', num_attr_type=raw_num_node_type,
+                                              flag_nodes=True, flag_adjs=False,
+                                              flag_in_ddpm_range=True, flag_out_ddpm_range=False)
+            return _q_node
+
+        def _decode_adj(adj_samples, node_flags, encoding_method):     # sampler_node_adj.py:242-285
+            adj_samples = adj_samples.clamp(-1.0, 1.0)
+            if encoding_method in ['bits', 'one_hot']:
+                adj_samples = torch.where(adj_samples > 0.0, torch.ones_like(adj_samples), -torch.ones_like(adj_samples))
+                adj_samples = mask_adjs(adj_samples, node_flags)
+            if encoding_method in ['ddpm', 'one_hot']:
+                if encoding_method == 'ddpm':
+                    _num_attr_type = raw_num_adj_type
+                    if flag_node_only:
+                        _num_attr_type = raw_num_node_type
+                    if flag_binary_edge:
+                        _num_attr_type = 2
+                elif encoding_method == 'one_hot':
+                    _num_attr_type = raw_num_adj_type
+                else:
+                    raise NotImplementedError
+                _q_adj = attribute_converter(in_attr=adj_samples, attr_flags=node_flags.cpu(),
+                                             in_encoding=encoding_method, out_encoding='int',
+                                             num_attr_type=_num_attr_type,
+                                             flag_nodes=True, flag_adjs=False,
+                                             flag_in_ddpm_range=True, flag_out_ddpm_range=False)
+            elif encoding_method == 'bits':
+                if flag_binary_edge:
+                    adj_samples = adj_samples.unsqueeze(1)
+                _q_binary_adj = adj_samples.gt(0.0).cpu().float()
+                _q_binary_adj = mask_adjs(_q_binary_adj, node_flags.cpu())
+                _q_binary_adj = _q_binary_adj.permute(0, 2, 3, 1)
+                _q_adj = bin2dec(_q_binary_adj, num_bits=np.ceil(np.log2(raw_num_adj_type)).astype(int))
+                _q_adj = mask_adjs(_q_adj, node_flags.cpu()).clamp(min=0, max=raw_num_adj_type - 1)
+            else:
+                raise NotImplementedError
+            b, n = node_flags.shape[:2]
+            if not flag_node_only:
+                _q_adj[:, torch.eye(n, device=_q_adj.device).bool()] = 0.0
+            return _q_adj.contiguous()
+
+        node_flags = t(flags)
+        # the sampler hands back squeezed singleton channels (edm.py:437-443 via flag_*_multi_channel): 'ddpm' adjacency is [B, N, N]
+        final_samples_adjs = t(adj.copy())
+        if final_samples_adjs.shape[1] == 1:
+            final_samples_adjs = final_samples_adjs[:, 0]
+        final_samples_nodes = t(node.copy())
+        # :194-209 (flag_bbox, not node-only)
+        final_samples_nodes, final_samples_nodes_bbox = final_samples_nodes[..., :-4], final_samples_nodes[..., -4:]
+        final_samples_nodes_bbox = final_samples_nodes_bbox * 0.5 + 0.5
+        final_samples_nodes_bbox = mask_nodes(final_samples_nodes_bbox.cpu(), node_flags.cpu())
+        q_node = _decode_node(final_samples_nodes.cpu(), node_flags.cpu(), node_encoding)      # :288
+        q_adj = _decode_adj(final_samples_adjs.cpu(), node_flags.cpu(), edge_encoding)        # :290
+        qa, qn = q_adj.numpy().astype(np.float64), q_node.numpy().astype(np.float64)
+        assert np.array_equal(qa, np.round(qa)) and np.array_equal(qn, np.round(qn)) and qa.min() >= 0 and qn.min() >= 0
+        res[f"{name}_q_adj"], res[f"{name}_q_node"] = qa.astype(np.int16), qn.astype(np.int16)
+        res[f"{name}_bbox"] = final_samples_nodes_bbox.numpy().astype(np.float32)
+        print(f"decode {name} ({edge_encoding}/{node_encoding}): q_adj classes used {len(np.unique(qa))} of {raw_num_adj_type} (max {qa.max():.0f}), "
+              f"q_node classes used {len(np.unique(qn))} of {raw_num_node_type} (max {qn.max():.0f})")
+    np.savez_compressed(os.path.join(out, "decode_enc.npz"), **res)
 
 
 def gen_train_forward(DiffuseSG, NodeAdjPrecond, out):
@@ -741,6 +887,8 @@ def main():
     check_channel_table()
     if args.only in ("", "decode"):
         gen_decode(args.out)
+    if args.only in ("", "decode_enc"):
+        gen_decode_enc(args.out)
     if args.only in ("", "train"):
         gen_train_forward(DiffuseSG, NodeAdjPrecond, args.out)
     if args.only in ("", "train", "train_bwd"):
@@ -759,6 +907,8 @@ def main():
         gen_sampler(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, args.out)
     if args.only in ("", "big"):
         gen_big_trajectories(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, args.out)
+    if args.only in ("", "long"):
+        gen_long_trajectories(DiffuseSG, NodeAdjPrecond, NodeAdjEDMSampler, args.out)
 
 
 if __name__ == "__main__":
