@@ -90,6 +90,9 @@ def cpu_baseline(cfg, sd, T, valid, budget_s):
     orc = Oracle(cfg, sd)
     cores = os.cpu_count() if not hasattr(os, "sched_getaffinity") else len(os.sched_getaffinity(0))
     B = max(2, min(64, cores))
+    # the ranks of a multi-GPU run are started with OMP_NUM_THREADS=1 (launch_ranks); this leg runs on rank 0 while the others wait at
+    # the final barrier, and wants the host's cores
+    threads = Oracle.set_threads(min(cores, B))
     flags, ia, inn, _, _, cv = synth.sampler_case(cfg, 4, B, valid, 77, "bench/cpu")
     coins_all = (weights.coins(77, "bench/cpu/all", 2 * T - 1) < 0.5).astype(np.uint8)
     nfe_total = (2 * T - 1) + int(coins_all.sum())
@@ -108,7 +111,7 @@ def cpu_baseline(cfg, sd, T, valid, budget_s):
         orc.sample(flags, ia, inn, None, None, coins_all, num_steps=T, max_steps=steps)
         elapsed, nfe = time.perf_counter() - t0, orc.nfe - n0
     per_fwd = elapsed / nfe
-    return {"value": B / (per_fwd * nfe_total), "unit": "scene-graphs/s", "cores": int(min(cores, B)), "kind": "port",
+    return {"value": B / (per_fwd * nfe_total), "unit": "scene-graphs/s", "cores": int(min(threads, B)), "kind": "port",
             "sample": f"oracle/dsg_ref.c (OpenMP, one graph per thread), same config, B={B}, first {steps} of T={T} Heun steps = "
                       f"{nfe} network forwards of {B} graphs in {elapsed:.1f} s, scaled to {nfe_total} forwards per graph"}
 
@@ -173,7 +176,7 @@ def worker(args):
         def one_step(k, sampler):
             g = torch.Generator().manual_seed(seed + 1000 * (k + 7))
             oa, on = torch.randn(B, cfg.c_adj, n, n, generator=g), torch.randn(B, n, cfg.c_node, generator=g)
-            return dsg_dist.gather_results(dsg_dist.pack_results(oa, on)), {"net_forwards": 0}
+            return dsg_dist.gather_results(dsg_dist.pack_results(oa, on)), {"net_forwards": 100 + rank}   # (stand-in count, differs by rank)
     else:
         from diffusesg_amd.model import build_network
         from diffusesg_amd.sampler import NodeAdjEDMSamplerHip
@@ -232,6 +235,17 @@ def worker(args):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert out.shape[0] == world_seen * B and bool(torch.isfinite(out).all())
+    # what differs by rank in a multi-GPU run: every rank draws its own coin stream (seed + rank), so its number of network forwards
+    # differs; `value` is graphs over the MAX-over-ranks time, i.e. the slowest rank's -- record the spread
+    nfe_min = nfe_max = nfe
+    if use_pg:
+        tn = torch.tensor([float(nfe), -float(nfe)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+        nfe_max, nfe_min = int(tn[0].item()), int(-tn[1].item())
+    per_rank = {"net_forwards_per_step_min": nfe_min / args.steps, "net_forwards_per_step_max": nfe_max / args.steps,
+                "net_forwards_per_step_rank0": nfe / args.steps,
+                "gather_payload_bytes_per_rank": int(out.numel() // world_seen * out.element_size()),
+                "gather_payload_bytes_total": int(out.numel() * out.element_size())}
     if world > 1:
         # rank order of the gather: every rank drew from its own seed, so the blocks must differ and block r must be rank r's
         mine = out[rank * B:(rank + 1) * B]
@@ -244,7 +258,7 @@ def worker(args):
             line = {"metric": "launcher self-test (no GPU work)", "value": world * B * args.steps / max(elapsed, 1e-9),
                     "unit": "stand-in steps/s", "n_gpus": world, "world_size": world_seen, "steps": args.steps,
                     "warmup": args.warmup, "selftest": True, "backend": "gloo" if world > 1 else None,
-                    "gathered_rows": int(out.shape[0])}
+                    "gathered_rows": int(out.shape[0]), "per_rank": per_rank, "cpu_baseline": None}
     else:
         # The tail the reference pays after sampling (sampler_node_adj.py:194-345): decode the 'bits' samples, gather the
         # decoded graphs and bring them to the host.  Reported beside `value`, never inside it.
@@ -259,6 +273,7 @@ def worker(args):
         fence()
         tail = time.perf_counter() - t1
         assert dec_host.shape[0] == world_seen * B
+        per_rank["decoded_gather_payload_bytes_per_rank"] = int(dec.numel() // world_seen * dec.element_size())
 
     if rank == 0 and not selftest:
         graphs = world * B * args.steps
@@ -325,8 +340,10 @@ def worker(args):
         # against the peak of the pipe the mode's GEMMs run on (bf16 mode: most of the path's FLOPs are bf16-MFMA products; the
         # fp32 PatchEmbed / read-out / heads are priced against that peak too, which only understates the fraction)
         roofline["whole_path_frac"] = roofline["whole_path_tflops"] / peak
+        # cpu_baseline on rank 0 at every world size: the timed region is over, the other ranks are idle at the final barrier (the
+        # leg is bounded by --cpu-budget-s, well inside the process group's timeout)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             progress(f"cpu_baseline: timing the oracle on the host cores for up to {args.cpu_budget_s:.0f} s")
             cpu = cpu_baseline(cfg, sd, T, valid, args.cpu_budget_s)
         # BASELINE.json's metric string for the configuration it is quoted on (VG shape: 30 valid nodes, T=1000); any other
@@ -351,7 +368,7 @@ def worker(args):
                        "net_forwards_per_step": nfe / args.steps, "gflop_per_forward_per_graph": f_fwd / 1e9,
                        "hip_graph": not args.no_graph, "precision_mode": mode,
                        "parallelism": f"batch-sharded x{world}, one all-gather", "process_group": "nccl (RCCL)" if use_pg else None},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "per_rank": per_rank,
             "tail": {"what": "on-GPU decode of the bits samples + packed int16 all-gather + D2H of the decoded graphs (once per step)",
                      "ms": 1e3 * tail, "value_with_tail": graphs / (elapsed + args.steps * tail)},
         }

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -539,6 +540,9 @@ const char *dsg_version(void) { return "dsg-gfx950 0.4 (fp32 MFMA; ABI 4)"; }
 int32_t dsg_abi_version(void) { return DSG_ABI_VERSION; }
 // dsg_last_error(NULL): why the last dsg_create on this thread failed (there is no handle to ask then)
 static thread_local std::string g_create_err;
+// live handles of the process: when the last one is destroyed the per-stream scratch of the handle-less training kernels is released too
+// (train_kernels.hip keeps it per hipStream_t and it only grows; a destroyed stream's address may be reused by a later stream)
+static std::atomic<int> g_live_handles{0};
 
 int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     if (!cfg || !out) { g_create_err = "dsg_create: null argument"; return DSG_ERR_INVALID; }
@@ -578,6 +582,7 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     h->opt_bf16_pipe = env_on("DSG_BF16_PIPE", true);
     h->opt_gemm_split = env_on("DSG_GEMM_SPLIT", false);
     *out = h;
+    g_live_handles++;
     return DSG_OK;
 }
 
@@ -602,6 +607,7 @@ void dsg_destroy(dsg_handle h) {
         for (void *p : kv.second->allocs) (void)hipFree(p);
     }
     delete h;
+    if (--g_live_handles == 0) { (void)hipDeviceSynchronize(); t_scratch_release(); }
 }
 
 const char *dsg_last_error(dsg_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -1205,10 +1211,10 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
         P_BX(g, "proj");
         if (!full) P_KERN(PK_ROW, 0.0, launch_ln_bx(w->x, nullptr, 0, 0, w->xn, B, T, C, true, s));
     }
-    // fc1 -> GELU -> fc2 -> + residual (-> the next block's modulate / LayerNorm-1) in one kernel, no hidden tensor: at C = 96 / 192,
-    // where the pair of GEMMs is bound by the hidden tensor's HBM round trip (measured at COCO B = 512, tools/bx_bench.py: 324 us
-    // against 302 + 325 at C = 96, 270 against 193 + 196 at C = 192).  At C = 384 the fused kernel needs 230 + 192 registers, runs one
-    // wave per SIMD and is slower than the two GEMMs (312 us against 115 + 156): option value 2 forces it there too (tests).
+    // fc1 -> GELU -> fc2 -> + residual (-> the next block's modulate / LayerNorm-1) in one kernel, no hidden tensor (measured at COCO
+    // B = 512, tools/bx_bench.py: 324 us against 302 + 325 for the GEMM pair at C = 96, 270 against 193 + 196 at C = 192, and at C = 384
+    // the eight-wave kernel mlp384_bx 199 against 111 + 152; the four-wave kernel at C = 384 -- option value 2, tests only -- needs
+    // 230 + 192 registers, runs one wave per SIMD and loses to the pair: 312 us).  C = 768 (VG's deepest level) keeps the GEMM pair.
     if (mlp_fused) {
         BxMlp m;
         m.wide8 = h->opt_bf16_mlp == 2 ? 0 : 1;

@@ -11,7 +11,9 @@ Same constructor kwargs, call signatures and return conventions as the reference
 `train_step_grads` (network in training form, loss, backward to every parameter: `dsg_train_step_grads`), `AdamHip` (clip + Adam:
 `dsg_adam_step`), `ExponentialLRHip` (the scheduler `get_optimizer` returns beside it), `EMAHip` (`dsg_ema_update`; parity unpinned),
 `train_one_iteration`; gradients all-reduce through
-`diffusesg_amd.dist.all_reduce_mean`.  The kernels are plain fp32 (csrc/train_kernels.hip), not the sampling path's MFMA kernels.
+`diffusesg_amd.dist.all_reduce_mean`.  The products of the training form run on the matrix pipe since round 3 (csrc/train_kernels.hip: y = x W^T and dx = dy W on the
+sampling path's gemm4_f32_kernel, weight gradients on gemm_tn_f32_kernel, attention forward / backward on t_attn_mfma_kernel -- all
+v_mfma_f32_32x32x2_f32); LayerNorm / modulate / optimiser are HBM-bound row and multi-tensor kernels.
 """
 from __future__ import annotations
 

@@ -295,8 +295,8 @@ int dsg_rainbow_loss_backward(int32_t B, int32_t N, int32_t c_adj, int32_t c_nod
 
 /* One SwinTransformerBlock in training form: forward x_out = block(x_in, emb) (R/model/diffusesg/diffusesg.py:232-277 with
  * WindowAttention :108-139 and Mlp :19-25) and, when grad_out != NULL, its backward as torch.autograd derives it -- the first
- * building block of the network backward.  Correctness-first kernels (csrc/train_kernels.hip; only the large GEMMs run
- * on the sampling path's MFMA kernel), pinned to the reference's autograd by tests/golden/block_backward.npz.
+ * building block of the network backward.  Kernels: csrc/train_kernels.hip -- products, weight gradients and the
+ * attention forward / backward on fp32 MFMA, row passes HBM-bound; pinned to the reference's autograd by tests/golden/block_backward.npz.
  *   block: state-dict prefix of the block, e.g. "down_layers.0.blocks.1".  x_in, x_out, grad_out, grad_in: [B, T, C] token-major
  *   (the reference's [B, L, C]); emb, grad_emb: [B, 512] (the mapped noise embedding, dsg_noise_embed).  names[i] (relative to the
  *   prefix: "affine.weight", "affine.bias", "norm1.weight", "norm1.bias", "attn.relative_position_bias_table", "attn.qkv.weight",
@@ -308,8 +308,8 @@ int dsg_block_train(dsg_handle h, const char *block, int32_t B, const float *x_i
 /* The whole network in training form: F = DiffuseSG.forward(in_adj, in_node, flags, c_noise, sc_adj, sc_node)
  * (R/model/diffusesg/diffusesg.py:765-830) and, when grad_F_adj != NULL, the gradient of every parameter for the upstream gradients
  * dL/dF (e.g. from dsg_rainbow_loss_backward) -- what loss.backward() of a training step leaves in the parameters' .grad
- * (R/runner/trainer/trainer_node_adj.py:163-170), pinned by tests/golden/train_backward.npz.  Correctness-first kernels
- * (csrc/train_kernels.hip), well below the sampling path's speed.  dsg_finalize_weights must have run once; weights
+ * (R/runner/trainer/trainer_node_adj.py:163-170), pinned by tests/golden/train_backward.npz.  MFMA products, weight gradients
+ * and attention since round 3 (csrc/train_kernels.hip; measured rates: DESIGN.md §4).  dsg_finalize_weights must have run once; weights
  * set afterwards (an optimiser step) are used as they are -- the training form reads the raw tensors only.
  *   in_adj [B,C_adj,N,N], in_node [B,N,C_node]: the preconditioned inputs c_in(sigma) * noisy (precond.py:100); c_noise [B];
  *   sc_*: the self-conditioning inputs (constants: the reference detaches them) or NULL; out_F_*: the raw network outputs;

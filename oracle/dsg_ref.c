@@ -22,6 +22,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define NOISE_EMB 512
 #define MAX_LAYERS 8
@@ -749,6 +752,18 @@ int dsgref_decode_bits(dsgref *h, int B, const float *adj, const float *node, co
         }
     }
     return 0;
+}
+
+/* Number of OpenMP threads the oracle's loops use from now on (bench.py's cpu_baseline on a multi-rank run: the launcher starts the
+ * ranks with OMP_NUM_THREADS=1, the baseline leg wants the host's cores).  Returns the number in effect. */
+int dsgref_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 
 /* The other two attribute encodings of the post-decode (`--node_encoding` / `--edge_encoding` = 'one_hot' | 'ddpm'):

@@ -54,6 +54,8 @@ def lib():
         L.dsgref_rainbow_loss_backward.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_float] * 3 + [C.c_int] + [C.c_void_p] * 5
         L.dsgref_noise_embed.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3
         L.dsgref_decode_bits.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 3
+        L.dsgref_set_threads.argtypes = [C.c_int]
+        L.dsgref_set_threads.restype = C.c_int
         L.dsgref_decode.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 5 + [C.c_void_p] * 3
         _lib = L
     return _lib
@@ -171,6 +173,11 @@ class Oracle:
         lib().dsgref_decode_bits(self._h, B, _p(adj), _p(node), _p(fl), int(n_adj_type), int(n_node_type),
                                  c.c_node - 4 if bbox else c.c_node, _p(qa), _p(qn), _p(bb))
         return qa, qn, bb
+
+    @staticmethod
+    def set_threads(n: int) -> int:
+        """OpenMP threads of the oracle's loops from now on (returns the number in effect)"""
+        return int(lib().dsgref_set_threads(int(n)))
 
     def decode(self, adj, node, flags, edge_encoding, node_encoding, n_adj_type, n_node_type, bbox=True):
         """samples in any of the reference's encodings ('bits' | 'one_hot' | 'ddpm') -> (q_adj, q_node, bbox | None);

@@ -304,6 +304,13 @@ def test_bench_self_launches_two_ranks_gloo():
     ln = lines[0]
     assert ln["selftest"] and ln["n_gpus"] == 2 and ln["world_size"] == 2 and ln["backend"] == "gloo"
     assert ln["gathered_rows"] == 6 and ln["steps"] == 2 and ln["warmup"] == 1
+    # an N-GPU line describes itself: the per-rank spread of network forwards (coin streams differ by rank; `value` is over the
+    # max-over-ranks time) and the gathered payload; the stand-in step reports 100 + rank forwards per step
+    pr = ln["per_rank"]
+    assert pr["net_forwards_per_step_min"] == 100 and pr["net_forwards_per_step_max"] == 101 and pr["net_forwards_per_step_rank0"] == 100
+    tiny = 6 * 8 * 8 + 8 * 12   # floats of one tiny-config graph (C_adj N^2 + N C_node)
+    assert pr["gather_payload_bytes_per_rank"] == 3 * tiny * 4 and pr["gather_payload_bytes_total"] == 6 * tiny * 4
+    assert "cpu_baseline" in ln
 
 
 def test_bench_launcher_propagates_failure():
