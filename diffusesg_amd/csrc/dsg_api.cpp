@@ -143,6 +143,7 @@ struct dsg_handle_s {
     int opt_bf16_mlp = 1;                                         // in that pipeline: the fused fc1-GELU-fc2 kernels (0: two GEMMs with a bf16 hidden tensor; 1: C <= 192 on 4 waves, C = 384 on 8; 2: C = 384 on the 4-wave kernel too; 3: GEMM pair at C = 384)
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
+    std::map<const float *, void *> w_img;                        // per C = 384 block (key: its fc1_wf): W1 | W2 | Wp pre-arranged for mlp384d_bx_kernel's LDS-DMA ring
     bool opt_gemm_split = false;                                  // split-bf16 GEMMs (3 planes, 6 products): fp32-accurate, opt-in
     std::map<const float *, void *> w_split;                      // [3][N][K] bf16 planes
     int opt_fused_mlp_maxc = 96;   // at C = 192 the plain GEMM pair is faster than the one-wave-per-SIMD fused kernel
@@ -505,8 +506,25 @@ int ensure_bf16_weights(dsg_handle h) {
         launch_f32_to_bf16(pw.first, q, pw.second, nullptr);
         h->w_bf16[pw.first] = q;
     }
+    // the C = 384 blocks' fc1 / fc2 / proj weights once more, in the piece order the LDS-DMA MLP kernel streams and reads them
+    if (h->cfg.mlp_ratio == 4)
+        for (int l = 0; l < h->L; l++)
+            for (auto *vec : {&h->down[l], &h->up[l]})
+                for (auto &b : *vec) {
+                    if (b.C != 384 || !b.fc1_wf || h->w_img.count(b.fc1_wf)) continue;
+                    const float *w2 = WT(h, b.prefix + ".mlp.fc2.weight"), *wp = WT(h, b.prefix + ".attn.proj.weight");
+                    if (!h->w_bf16.count(b.fc1_wf) || !h->w_bf16.count(w2) || !h->w_bf16.count(wp)) continue;
+                    void *q;
+                    HIP_TRY(h, hipMalloc(&q, mlp384_image_bytes()));
+                    launch_mlp384_images(h->w_bf16[b.fc1_wf], h->w_bf16[w2], h->w_bf16[wp], q, nullptr);
+                    h->w_img[b.fc1_wf] = q;
+                }
     HIP_TRY(h, hipDeviceSynchronize());
     return 0;
+}
+const void *img_of(dsg_handle h, const float *fc1_wf) {
+    auto it = h->w_img.find(fc1_wf);
+    return it == h->w_img.end() ? nullptr : it->second;
 }
 
 const void *split_of(dsg_handle h, const float *W) {
@@ -590,6 +608,7 @@ void dsg_destroy(dsg_handle h) {
     if (!h) return;
     for (auto &kv : h->w) (void)hipFree(kv.second.p);
     for (auto &kv : h->w_bf16) (void)hipFree(kv.second);
+    for (auto &kv : h->w_img) (void)hipFree(kv.second);
     for (auto &kv : h->w_split) (void)hipFree(kv.second);
     for (void *p : h->derived_allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -816,6 +835,8 @@ int dsg_finalize_weights(dsg_handle h) {
     // bf16 copies (opt-in mode): drop stale ones, list every GEMM weight, rebuild if the mode is on
     for (auto &kv : h->w_bf16) (void)hipFree(kv.second);
     h->w_bf16.clear();
+    for (auto &kv : h->w_img) (void)hipFree(kv.second);
+    h->w_img.clear();
     for (auto &kv : h->w_split) (void)hipFree(kv.second);
     h->w_split.clear();
     h->gemm_weights.clear();
@@ -1200,7 +1221,7 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
     }
     // the fused MLP kernel can take the proj linear, the residual and LayerNorm-2 in front (x + proj(att) never goes to HBM)
     const bool mlp_fused = h->opt_bf16_mlp && h->cfg.mlp_ratio == 4 && (C == 96 || C == 192 || (C == 384 && h->opt_bf16_mlp != 3));
-    const bool proj_in_mlp = mlp_fused && h->opt_bf16_proj_mlp && h->taps.empty() && (C == 96 || C == 192 || (C == 384 && h->opt_bf16_mlp == 1));
+    const bool proj_in_mlp = mlp_fused && h->opt_bf16_proj_mlp && h->taps.empty() && (C == 96 || C == 192 || (C == 384 && (h->opt_bf16_mlp == 1 || h->opt_bf16_mlp == 4)));
     const bool full = bx_full_row(C);
     if (!proj_in_mlp) {
         g = BxGemm();
@@ -1217,7 +1238,9 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
     // 230 + 192 registers, runs one wave per SIMD and loses to the pair: 312 us).  C = 768 (VG's deepest level) keeps the GEMM pair.
     if (mlp_fused) {
         BxMlp m;
-        m.wide8 = h->opt_bf16_mlp == 2 ? 0 : 1;
+        // C = 384: 1 -> the LDS-DMA kernel on pre-arranged weight images (round 4), 4 -> round 3's eight-wave kernel, 2 -> the four-wave one
+        m.wide8 = h->opt_bf16_mlp == 2 ? 0 : (h->opt_bf16_mlp == 4 ? 2 : 1);
+        m.img = C == 384 ? img_of(h, b.fc1_wf) : nullptr;
         if (proj_in_mlp) { m.att = w->att; m.Wp = bf16_of(h, WT(h, p + ".attn.proj.weight")); m.bp = WT(h, p + ".attn.proj.bias"); }
         m.xn = w->xn; m.x = w->x; m.W1 = bf16_of(h, b.fc1_wf); m.b1 = b.fc1_bf;
         m.W2 = bf16_of(h, WT(h, p + ".mlp.fc2.weight")); m.b2 = WT(h, p + ".mlp.fc2.bias"); m.M = M; m.C = C;
@@ -1634,7 +1657,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "loop_graph") h->opt_loop_graph = value != 0;
     else if (n == "bf16_act") h->opt_bf16_act = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "bf16_pipe") h->opt_bf16_pipe = value != 0;
-    else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 3 ? 3 : value);
+    else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 4 ? 4 : value);
     else if (n == "bf16_qkv_attn") h->opt_bf16_qkv_attn = value != 0;
     else if (n == "bf16_proj_mlp") h->opt_bf16_proj_mlp = value != 0;
     else if (n == "bf16_readout") h->opt_bf16_readout = value != 0;
@@ -2046,12 +2069,13 @@ int dsg_debug_gemm_bx(int32_t M, int32_t N, int32_t K, const float *A, const flo
 
 int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *mod, int32_t out_mode, float *out_xn, int32_t time_iters, float *out_ms, void *stream) {
-    const int narrow384 = (out_mode >> 4) & 1;   // + 16: C = 384 on the one-wave-per-SIMD kernel instead of the eight-wave one
+    const int narrow384 = (out_mode >> 4) & 1;   // + 16: C = 384 on the one-wave-per-SIMD kernel instead of the eight-wave ones
+    const int old384 = (out_mode >> 5) & 1;      // + 32: C = 384 on round 3's eight-wave kernel (register-staged weights) instead of the LDS-DMA one
     out_mode &= 15;
     if (M < 1 || !xn || !x || !W1 || !b1 || !W2 || !b2 || (out_mode && !out_xn)) return DSG_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    void *xb = nullptr, *w1b = nullptr, *w2b = nullptr, *ob = nullptr;
-    auto cleanup = [&]() { (void)hipFree(xb); (void)hipFree(w1b); (void)hipFree(w2b); (void)hipFree(ob); };
+    void *xb = nullptr, *w1b = nullptr, *w2b = nullptr, *ob = nullptr, *imgb = nullptr;
+    auto cleanup = [&]() { (void)hipFree(xb); (void)hipFree(w1b); (void)hipFree(w2b); (void)hipFree(ob); (void)hipFree(imgb); };
     if (hipMalloc(&xb, (size_t)M * C * 2) != hipSuccess || hipMalloc(&w1b, (size_t)4 * C * C * 2) != hipSuccess ||
         hipMalloc(&w2b, (size_t)4 * C * C * 2) != hipSuccess || hipMalloc(&ob, (size_t)M * C * 2) != hipSuccess) { cleanup(); return DSG_ERR_HIP; }
     launch_f32_to_bf16(xn, xb, (size_t)M * C, s);
@@ -2060,7 +2084,12 @@ int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const floa
     BxMlp g;
     g.xn = xb; g.x = x; g.W1 = w1b; g.b1 = b1; g.W2 = w2b; g.b2 = b2; g.M = M; g.C = C;
     if (out_mode) { g.xn_out = ob; g.out_mode = out_mode; }
-    g.wide8 = narrow384 ? 0 : 1;
+    g.wide8 = narrow384 ? 0 : (old384 ? 2 : 1);
+    if (C == 384 && g.wide8 == 1) {
+        if (hipMalloc(&imgb, mlp384_image_bytes()) != hipSuccess) { cleanup(); return DSG_ERR_HIP; }
+        launch_mlp384_images(w1b, w2b, nullptr, imgb, s);
+        g.img = imgb;
+    }
     if (mod) { g.mod_aff = mod; g.mod_ld = 0; g.mod_off = 0; g.mod_T = 1; }
     const bool ok = launch_mlp_bx(g, s);
     if (ok && out_mode) launch_bf16_to_f32(ob, out_xn, (size_t)M * C, s);
@@ -2074,10 +2103,12 @@ int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const floa
 int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const float *Wp, const float *bp, const float *W1, const float *b1,
                          const float *W2, const float *b2, const float *mod, int32_t out_mode, float *out_xn, int32_t time_iters, float *out_ms,
                          void *stream) {
+    const int old384 = (out_mode >> 5) & 1;      // + 32: C = 384 on round 3's eight-wave kernel instead of the LDS-DMA one
+    out_mode &= 15;
     if (M < 1 || !att || !x || !Wp || !bp || !W1 || !b1 || !W2 || !b2 || (out_mode && !out_xn)) return DSG_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
-    void *ab = nullptr, *wpb = nullptr, *w1b = nullptr, *w2b = nullptr, *ob = nullptr;
-    auto cleanup = [&]() { (void)hipFree(ab); (void)hipFree(wpb); (void)hipFree(w1b); (void)hipFree(w2b); (void)hipFree(ob); };
+    void *ab = nullptr, *wpb = nullptr, *w1b = nullptr, *w2b = nullptr, *ob = nullptr, *imgb = nullptr;
+    auto cleanup = [&]() { (void)hipFree(ab); (void)hipFree(wpb); (void)hipFree(w1b); (void)hipFree(w2b); (void)hipFree(ob); (void)hipFree(imgb); };
     if (hipMalloc(&ab, (size_t)M * C * 2) != hipSuccess || hipMalloc(&wpb, (size_t)C * C * 2) != hipSuccess || hipMalloc(&w1b, (size_t)4 * C * C * 2) != hipSuccess ||
         hipMalloc(&w2b, (size_t)4 * C * C * 2) != hipSuccess || hipMalloc(&ob, (size_t)M * C * 2) != hipSuccess) { cleanup(); return DSG_ERR_HIP; }
     launch_f32_to_bf16(att, ab, (size_t)M * C, s);
@@ -2087,6 +2118,12 @@ int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const
     BxMlp g;
     g.att = ab; g.Wp = wpb; g.bp = bp; g.x = x; g.W1 = w1b; g.b1 = b1; g.W2 = w2b; g.b2 = b2; g.M = M; g.C = C;
     if (out_mode) { g.xn_out = ob; g.out_mode = out_mode; }
+    g.wide8 = old384 ? 2 : 1;
+    if (C == 384 && g.wide8 == 1) {
+        if (hipMalloc(&imgb, mlp384_image_bytes()) != hipSuccess) { cleanup(); return DSG_ERR_HIP; }
+        launch_mlp384_images(w1b, w2b, wpb, imgb, s);
+        g.img = imgb;
+    }
     if (mod) { g.mod_aff = mod; g.mod_ld = 0; g.mod_off = 0; g.mod_T = 1; }
     const bool ok = launch_mlp_bx(g, s);
     if (ok && out_mode) launch_bf16_to_f32(ob, out_xn, (size_t)M * C, s);

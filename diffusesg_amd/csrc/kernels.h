@@ -98,11 +98,16 @@ struct BxMlp {
     void *xn_out = nullptr; int out_mode = 0;
     const float *mod_aff = nullptr; int mod_ld = 0, mod_off = 0, mod_T = 1;
     int M = 0, C = 0;
-    int wide8 = 1;   // C = 384: the eight-wave kernel (0: mlp_bx_kernel<384>, one wave per SIMD)
+    int wide8 = 1;   // C = 384: 1 the eight-wave LDS-DMA kernel (needs img), 2 round 3's eight-wave kernel, 0 mlp_bx_kernel<384> (one wave per SIMD)
+    const void *img = nullptr;   // C = 384: W1 | W2 | Wp pre-arranged for mlp384d_bx_kernel (launch_mlp384_images; mlp384_image_bytes())
     // the attention half's tail in front (att != null; xn is then unused): x <- x + att Wp^T + bp first, its LayerNorm feeds fc1
     const void *att = nullptr, *Wp = nullptr; const float *bp = nullptr;
 };
 bool launch_mlp_bx(const BxMlp &g, hipStream_t s);
+// the C = 384 weights in the order mlp384d_bx_kernel's LDS-DMA ring and fragment reads want them: W1b [1536, 384], W2b [384, 1536],
+// Wpb [384, 384] (may be null: no proj stage) row-major bf16 -> img (mlp384_image_bytes() bytes)
+size_t mlp384_image_bytes();
+void launch_mlp384_images(const void *W1b, const void *W2b, const void *Wpb, void *img, hipStream_t s);
 // x fp32 [B*T, C] -> optional in-place modulate+SiLU (aff != null) -> xn bf16: LayerNorm without affine (ln) or the plain copy
 void launch_ln_bx(float *x, const float *aff, int aff_ld, int aff_off, void *xn, int B, int T, int C, bool ln, hipStream_t s);
 // window attention on bf16 qkv [B*T, 3C] -> bf16 out [B*T, C]; biasT as launch_window_attn; false: window size not covered

@@ -978,6 +978,317 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Round 4: the fused (proj +) MLP at C = 384 rebuilt around how the weights reach the CU.  What the eight-wave kernel above left on the
+// table (profiles/r3/bx_experiments.txt: 138 of its 208 us remain with every MFMA deleted): the weights of a chunk pair -- 96 KB per 128
+// tokens, 2.65 MB per block -- went global -> VGPR -> LDS in the middle of the compute phases, behind three all-wave barriers per pair
+// that also held the eight waves in the same phase, so fc1 / GELU / fc2 ran one after the other on every SIMD.  Here:
+//   * the weights are PRE-ARRANGED in HBM in the exact order the LDS reads want them (launch_mlp384_images: per stage of 48 KB, 16-byte
+//     pieces in [k-step][k-half][row] order for fc1 / proj and [row tile][chunk][k-step][k-half][row] for fc2, K and hidden units already
+//     in the accumulator order of the operand they meet), so a stage is a LINEAR copy;
+//   * that copy is LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPR in between, no ds_write), six instructions
+//     per wave and stage, into a ring of THREE 48-KB slots that W1 and W2 stages share alternately: every stage is requested two to three
+//     slots of the schedule before its first reader and retired by a counted s_waitcnt vmcnt(6) in front of a raw s_barrier;
+//   * every LDS read of a weight fragment is base + lane * 16 + immediate: conflict-free ds_read_b128, one address register per matrix;
+//   * fc1 is split along the HIDDEN units inside a wave pair (wave kh forms chunk 2 p + kh of pair p over the whole K = 384 from the
+//     full normalised row, 96 registers), so no fp32 partial sum crosses the pair; only the bf16 hidden tiles do (as before), and fc2
+//     is split along N as before;
+//   * the two halves of the block (waves 0-3 / 4-7: the two waves of every SIMD) run the SAME program ONE barrier interval apart
+//     (MI355X_MICROARCH.md, "Two waves per SIMD" item 9): while one half is in its GELU interval the other is in a matrix interval.
+// LDS: 3 x 48 KB ring + 16 KB exchange = 160 KB, one block per CU.  PROJ / MOD / out_mode: as mlp384_bx_kernel.
+// -------------------------------------------------------------------------------------------------
+constexpr int M384_STAGE = 49152;                                   // bytes of a ring slot = 3072 pieces of 16 B
+constexpr size_t M384_W1IMG = 0, M384_W2IMG = (size_t)1536 * 384 * 2, M384_WPIMG = (size_t)2 * 1536 * 384 * 2;   // byte offsets in the image
+size_t mlp384_image_bytes() { return (size_t)(2 * 1536 * 384 + 384 * 384) * 2; }
+
+// one thread per 16-byte piece of the image (see above); W1 [1536, 384], W2 [384, 1536], Wp [384, 384] row-major bf16 (Wp may be null)
+__global__ __launch_bounds__(256) void mlp384_img_kernel(const unsigned short *__restrict__ W1, const unsigned short *__restrict__ W2,
+                                                         const unsigned short *__restrict__ Wp, unsigned short *__restrict__ img) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int n1 = 24 * 3072, n2 = 24 * 3072, np = 6 * 3072;
+    if (idx >= n1 + n2 + (Wp ? np : 0)) return;
+    unsigned short v[8];
+    if (idx < n1) {
+        const int p = idx / 3072, P = idx % 3072, r = P % 64, sg = P / 64, s = sg >> 1, g = sg & 1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = W1[(size_t)(64 * p + r) * 384 + 16 * s + 4 * g + (j & 3) + 8 * (j >> 2)];
+    } else if (idx < n1 + n2) {
+        const int i2 = idx - n1, p = i2 / 3072, P = i2 % 3072, row = P % 32, q = P / 32;
+        const int g = q & 1, s2 = (q >> 1) & 1, c = (q >> 2) & 1, ct = (q >> 3) % 6, kh = (q >> 3) / 6;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = W2[(size_t)(192 * kh + 32 * ct + row) * 1536 + 64 * p + 32 * c + 16 * s2 + 4 * g + (j & 3) + 8 * (j >> 2)];
+    } else {
+        const int i3 = idx - n1 - n2, ct = i3 / 3072, P = i3 % 3072, r = P % 64, sg = P / 64, s = sg >> 1, g = sg & 1;
+        const int row = r < 32 ? 32 * ct + r : 192 + 32 * ct + (r - 32);
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = Wp[(size_t)row * 384 + 16 * s + 8 * g + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) img[(size_t)idx * 8 + j] = v[j];
+}
+void launch_mlp384_images(const void *W1b, const void *W2b, const void *Wpb, void *img, hipStream_t s) {
+    const int n = 24 * 3072 * 2 + (Wpb ? 6 * 3072 : 0);
+    DSG_LAUNCH(mlp384_img_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned short *)W1b, (const unsigned short *)W2b,
+               (const unsigned short *)Wpb, (unsigned short *)img);
+}
+
+typedef __attribute__((address_space(3))) void *lds_vptr;
+#define M384_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))   // vmcnt(N) only (lgkmcnt / expcnt: no wait)
+#define M384_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)                                      // lgkmcnt(0) only
+
+template <int MOD, bool PROJ = false>
+__global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
+    constexpr int C = 384, NP = 24, CT = 6, TLD = 104;
+    __shared__ __attribute__((aligned(16))) char lds[3 * M384_STAGE + 16384];
+    char *xchb = lds + 3 * M384_STAGE;
+    u32x4 *xch2 = reinterpret_cast<u32x4 *>(xchb);                  // [2 k-steps][8 waves][64 lanes]: the pair's bf16 hidden tiles
+    const int tid = threadIdx.x, lane = tid & 63, lrow = lane & 31, lhalf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ts = wave >> 1, kh = wave & 1, team = wave >> 2;
+    const int m0 = blockIdx.x * 128;
+    const int rows = min(128, g.M - m0);
+    const unsigned mrow = (unsigned)(32 * ts + lrow);
+    const char *img = static_cast<const char *>(g.img);
+    // this wave's six 1-KiB pieces of a 48-KB stage: image bytes [src, src + 49152) -> ring slot r, linear
+    const unsigned dma_voff = (unsigned)lane * 16u;
+    auto dma_stage = [&](const char *src, int r) {      // src, r: wave-uniform -> scalar base + one 32-bit lane offset
+        const char *sbase = src + wave * 6144;
+        char *dbase = lds + r * M384_STAGE + wave * 6144;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            __builtin_amdgcn_global_load_lds(sbase + i * 1024 + dma_voff, (lds_vptr)(dbase + i * 1024), 16, 0, 0);
+    };
+    // the normalised row of the lane's token as fc1's B operand, k-step s = channels 16 s + 4 half + {0..3, 8..11}: xo = the k-steps
+    // 12 kh .. + 11 (the channels this wave's proj / fc2 half owns), xp = the partner's 12 (fc1 walks own, then partner's: the order
+    // of a sum's terms is free, and the register arrays keep compile-time indices)
+    bf16x8 xfo[12], xfp[12];
+    f32x16 oacc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
+    if (PROJ) {
+        const char *wp = img + M384_WPIMG;
+        const rsrc_t rsAt = make_rsrc(static_cast<const __bf16 *>(g.att) + (size_t)m0 * C, (unsigned)rows * C * 2u);
+        bf16x8 af[24];   // the whole attention row of the lane's token: channels 16 s + 8 half .. + 7 of k-step s
+#pragma unroll
+        for (int s = 0; s < 24; s++) af[s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsAt, (mrow * C + 16u * s + 8u * lhalf) * 2u, 0u));
+        dma_stage(wp, 0); dma_stage(wp + M384_STAGE, 1); dma_stage(wp + 2 * M384_STAGE, 2);
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            if (ct < CT - 1) M384_WAIT_VM(12); else M384_WAIT_VM(6);   // stage ct has landed (at most the two younger requests are still out)
+            __builtin_amdgcn_s_barrier();
+            const char *a = lds + (ct % 3) * M384_STAGE + lhalf * 1024 + (32 * kh + lrow) * 16;
+#pragma unroll
+            for (int s = 0; s < 24; s++)
+                oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(a + s * 2048), af[s], oacc[ct], 0, 0, 0);
+            M384_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();          // every wave has read slot ct % 3
+            if (ct + 3 < CT) dma_stage(wp + (ct + 3) * M384_STAGE, ct % 3);
+            else if (ct == 3) dma_stage(img + M384_W1IMG, 0);          // W1 stage of pair 0 -> slot 0 (its ring position)
+        }
+        // x1 = x + proj + bp on this wave's 192 channels; LayerNorm-2 statistics across the pair
+        const rsrc_t rsXi = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+            f32x4 rr[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) rr[q] = buf_load4(rsXi, (mrow * C + (unsigned)(192 * kh + 32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.bp + 192 * kh + 32 * ct + 8 * q + 4 * lhalf);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float v = oacc[ct][4 * q + e] + b4[e] + rr[q][e];
+                    oacc[ct][4 * q + e] = v; sm += v; sq = fmaf(v, v, sq);
+                }
+            }
+        }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        f32x2 *part0 = reinterpret_cast<f32x2 *>(xchb);   // [128 rows][2]
+        if (lhalf == 0) part0[mrow * 2 + kh] = (f32x2){sm, sq};
+        __syncthreads();                       // statistics visible (this also drains the W1 stage request: it is needed next anyway)
+        const f32x2 q0 = part0[mrow * 2], q1 = part0[mrow * 2 + 1];
+        const float tsm = q0[0] + q1[0], tsq = q0[1] + q1[1];
+        const float mean = tsm * (1.0f / C), rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, tsq * (1.0f / C)), 0.f) + LN_EPS), nmr = -mean * rstd;
+        // the normalised values of the own 192 channels are k-steps 12 kh .. + 11 of fc1's B operand as the registers stand; the partner's
+        // half crosses through ring slots 1 and 2 (free until the first W2 / second W1 stage is requested below)
+        u32x4 *xx = reinterpret_cast<u32x4 *>(lds + M384_STAGE);   // [8 waves][12][64 lanes]
+#pragma unroll
+        for (int s = 0; s < 12; s++) {
+            u32x4 pk;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                pk[j] = pack_bf16(fmaf(oacc[s >> 1][8 * (s & 1) + 2 * j], rstd, nmr), fmaf(oacc[s >> 1][8 * (s & 1) + 2 * j + 1], rstd, nmr));
+            xx[(wave * 12 + s) * 64 + lane] = pk;
+            xfo[s] = __builtin_bit_cast(bf16x8, pk);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 12; s++) {
+            xfp[s] = __builtin_bit_cast(bf16x8, xx[((wave ^ 1) * 12 + s) * 64 + lane]);
+        }
+        __syncthreads();                       // slots 1 and 2 are free again
+    } else {
+        dma_stage(img + M384_W1IMG, 0);
+        // the normalised rows from HBM, in the K order of the W1 image: k-step s = channels 16 s + 4 half + {0..3} and + 8 + {0..3}
+        const rsrc_t rsXn = make_rsrc(static_cast<const __bf16 *>(g.xn) + (size_t)m0 * C, (unsigned)rows * C * 2u);
+#pragma unroll
+        for (int s = 0; s < 24; s++) {
+            const unsigned ch = (unsigned)(s < 12 ? 192 * kh : 192 * (1 - kh)) + 16u * (s % 12) + 4u * lhalf;
+            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rsXn, (mrow * C + ch) * 2u, 0u, 0);
+            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rsXn, (mrow * C + ch + 8u) * 2u, 0u, 0);
+            const bf16x8 v = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+            if (s < 12) xfo[s] = v; else xfp[s - 12] = v;
+        }
+    }
+    dma_stage(img + M384_W2IMG, 1);                     // ring item 1: W2 of pair 0
+    dma_stage(img + M384_W1IMG + M384_STAGE, 2);        // ring item 2: W1 of pair 1
+    // ---- the chunk-pair loop.  Ring item n lives in slot n % 3: item 2 p = W1 stage of pair p, item 2 p + 1 = its W2 stage.
+    // Global schedule in barrier intervals t: first half (waves 0-3) runs fc1(p) | GELU(p) | fc2(p) in t = 3 p, 3 p + 1, 3 p + 2; the second
+    // half runs the same program one interval later.  Requests (by all eight waves, six pieces each): W1 of pair t/3 + 1 at the start of
+    // every interval t = 1 (mod 3), W2 of pair t/3 + 1 at t = 2 (mod 3) -- the slot's previous reader finished in the interval before --
+    // and vmcnt(6) in front of every barrier retires everything but the newest request.
+    const int w1own = lhalf * 1024 + (32 * kh + lrow) * 16 + 12 * kh * 2048;        // k-steps 12 kh + s': + 2048 s'
+    const int w1oth = lhalf * 1024 + (32 * kh + lrow) * 16 + 12 * (1 - kh) * 2048;  // the partner's channels
+    const int w2own = lane * 16 + 26 * kh * 1024;                            // piece block (kh, ct, c = kh, s2): + (4 ct + s2) KiB
+    const int w2oth = lane * 16 + (24 * kh + 2 * (1 - kh)) * 1024;           // c = 1 - kh
+    // b1 is the fc1 accumulator's initial value: lane (token, half) holds hidden units 8 q + 4 half + {0..3} of its chunk in h[4 q ..];
+    // the four loads of pair p + 1 are issued in interval C of pair p (h is dead there) and have a whole interval to land
+    const float *b1w = g.b1 + 32 * kh + 4 * lhalf;
+    f32x16 h;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(b1w + 8 * q);
+        h[4 * q] = b4[0]; h[4 * q + 1] = b4[1]; h[4 * q + 2] = b4[2]; h[4 * q + 3] = b4[3];
+    }
+    if (team == 1) { M384_WAIT_VM(6); __builtin_amdgcn_s_barrier(); }        // the second half starts one interval late
+    int slot1 = 0, slot2 = 1;                                                // ring slots of this pair's W1 / W2 stage
+    for (int p = 0; p < NP; p++) {
+        // ---- interval A: fc1 of the own chunk over the whole K (h starts at b1)
+        {
+            const char *a = lds + slot1 * M384_STAGE + w1own, *ax = lds + slot1 * M384_STAGE + w1oth;
+#pragma unroll
+            for (int s = 0; s < 12; s++)
+                h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(a + s * 2048), xfo[s], h, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 12; s++)
+                h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(ax + s * 2048), xfp[s], h, 0, 0, 0);
+        }
+        // (the second half's request of this interval goes LAST: nothing the compiler waits for -- the b1 loads -- has it behind itself)
+        if (team == 1 && p >= 1 && p + 1 < NP) dma_stage(img + M384_W1IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 2) % 3);
+        M384_WAIT_VM(6); M384_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        // ---- interval B: + b1, GELU, bf16; the hidden tile goes to the partner
+        if (team == 0 && p >= 1 && p + 1 < NP) dma_stage(img + M384_W1IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 2) % 3);
+        if (team == 1 && p + 1 < NP) dma_stage(img + M384_W2IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 3) % 3);
+        u32x4 hf[2];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            hf[q >> 1][2 * (q & 1)] = pack_bf16(gelu_f(h[4 * q]), gelu_f(h[4 * q + 1]));
+            hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(gelu_f(h[4 * q + 2]), gelu_f(h[4 * q + 3]));
+        }
+        xch2[(0 * 8 + wave) * 64 + lane] = hf[0];
+        xch2[(1 * 8 + wave) * 64 + lane] = hf[1];
+        M384_WAIT_VM(6); M384_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        // ---- interval C: fc2 on the own 192 output channels over both chunks of the pair
+        if (team == 0 && p + 1 < NP) dma_stage(img + M384_W2IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 3) % 3);
+        u32x4 hp[2];
+        hp[0] = xch2[(0 * 8 + (wave ^ 1)) * 64 + lane];
+        hp[1] = xch2[(1 * 8 + (wave ^ 1)) * 64 + lane];
+        if (p + 1 < NP) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(b1w + 64 * (p + 1) + 8 * q);
+                h[4 * q] = b4[0]; h[4 * q + 1] = b4[1]; h[4 * q + 2] = b4[2]; h[4 * q + 3] = b4[3];
+            }
+        }
+        {
+            const char *ao = lds + slot2 * M384_STAGE + w2own, *ax = lds + slot2 * M384_STAGE + w2oth;
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++) {
+                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(ao + (4 * ct + s2) * 1024),
+                                                                       __builtin_bit_cast(bf16x8, hf[s2]), oacc[ct], 0, 0, 0);
+                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(ax + (4 * ct + s2) * 1024),
+                                                                       __builtin_bit_cast(bf16x8, hp[s2]), oacc[ct], 0, 0, 0);
+                }
+        }
+        M384_WAIT_VM(6); M384_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        slot1 = slot1 == 0 ? 2 : slot1 - 1;     // (2 p) % 3: 0, 2, 1, 0, ...
+        slot2 = slot2 == 0 ? 2 : slot2 - 1;     // (2 p + 1) % 3: 1, 0, 2, 1, ...
+    }
+    if (team == 0) { M384_WAIT_VM(0); __builtin_amdgcn_s_barrier(); }        // the first half waits out the second half's last interval
+    __syncthreads();                           // the ring is free: output transposition, row statistics
+    // ---- epilogue (as mlp384_bx_kernel): lane (token, half) holds channels 192 kh + 32 ct + 8 q + 4 half + {0..3} in oacc[ct][4 q ..]
+    const rsrc_t rsX = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
+    __bf16 *xo = static_cast<__bf16 *>(g.xn_out);
+    const rsrc_t rsO = make_rsrc(xo ? xo + (size_t)m0 * C : nullptr, xo ? (unsigned)rows * C * 2u : 0u);
+    const float *aff_row = nullptr;
+    if (MOD != 0) aff_row = g.mod_aff + (size_t)(MOD == 2 ? min(m0 + (int)mrow, g.M - 1) / g.mod_T : 0) * g.mod_ld + g.mod_off;
+    __bf16 *T = reinterpret_cast<__bf16 *>(lds) + wave * 32 * TLD;
+    f32x2 *part = reinterpret_cast<f32x2 *>(xchb);   // [128 rows][2]
+    auto tflush = [&](int half96) {               // the wave's 32 x 96 tile -> row-contiguous 16-byte stores (as gemm_bx_kernel)
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = lane + 64 * k, r = i / 12, pc = i - 12 * r;
+            const u32x4 d = *reinterpret_cast<const u32x4 *>(T + r * TLD + 8 * pc);
+            buf_store_u4(d, rsO, ((unsigned)(32 * ts + r) * C + (unsigned)(192 * kh + 96 * half96 + 8 * pc)) * 2u, 0u);
+        }
+    };
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        f32x4 rr[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            rr[q] = PROJ ? (f32x4){0.f, 0.f, 0.f, 0.f} : buf_load4(rsX, (mrow * C + (unsigned)(192 * kh + 32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);   // (PROJ: x1 is in oacc)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int c = 192 * kh + 32 * ct + 8 * q + 4 * lhalf;
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.b2 + c);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = oacc[ct][4 * q + e] + b4[e] + rr[q][e];
+            if (MOD != 0) {
+                const f32x4 scl = *reinterpret_cast<const f32x4 *>(aff_row + c), sft = *reinterpret_cast<const f32x4 *>(aff_row + C + c);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = silu_exact(fmaf(v[e], scl[e] + 1.0f, sft[e]));
+            }
+            buf_store4(v, rsX, (mrow * C + (unsigned)c) * 4u, 0u);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { ssum += v[e]; ssq = fmaf(v[e], v[e], ssq); oacc[ct][4 * q + e] = v[e]; }
+            if (g.out_mode == 2) *reinterpret_cast<u32x2 *>(T + lrow * TLD + 32 * (ct % 3) + 8 * q + 4 * lhalf) = pack_bf16x4(v);
+        }
+        if (g.out_mode == 2 && ct % 3 == 2) tflush(ct / 3);
+    }
+    if (g.out_mode == 1) {
+        ssum += __shfl_xor(ssum, 32, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        if (lhalf == 0) part[mrow * 2 + kh] = (f32x2){ssum, ssq};
+        __syncthreads();
+        const f32x2 p0 = part[mrow * 2], p1 = part[mrow * 2 + 1];
+        const float sm = p0[0] + p1[0], sq = p0[1] + p1[1];
+        const float mean = sm * (1.0f / C), rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * (1.0f / C)), 0.f) + LN_EPS), nmr = -mean * rstd;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = fmaf(oacc[ct][4 * q + e], rstd, nmr);
+                *reinterpret_cast<u32x2 *>(T + lrow * TLD + 32 * (ct % 3) + 8 * q + 4 * lhalf) = pack_bf16x4(v);
+            }
+            if (ct % 3 == 2) tflush(ct / 3);
+        }
+    }
+}
+
 bool launch_mlp_bx(const BxMlp &g, hipStream_t s) {
     if ((!g.xn && !g.att) || !g.x || !g.W1 || !g.b1 || !g.W2 || !g.b2 || g.M < 1 || (g.out_mode && !g.xn_out)) return false;
     const dim3 grid((g.M + 127) / 128), block(256);
@@ -1000,7 +1311,18 @@ bool launch_mlp_bx(const BxMlp &g, hipStream_t s) {
         case 96: MLP_LAUNCH(96); break;
         case 192: MLP_LAUNCH(192); break;
         case 384:
-            if (g.wide8) {   // eight waves per 128 tokens (mlp384_bx_kernel)
+            if (g.wide8 == 1 && g.img) {   // eight waves, pre-arranged weight images streamed by LDS-DMA (mlp384d_bx_kernel)
+                const dim3 block8(512);
+                if (proj) {
+                    if (mod == 0) DSG_LAUNCH((mlp384d_bx_kernel<0, true>), grid, block8, 0, s, g);
+                    else if (mod == 1) DSG_LAUNCH((mlp384d_bx_kernel<1, true>), grid, block8, 0, s, g);
+                    else DSG_LAUNCH((mlp384d_bx_kernel<2, true>), grid, block8, 0, s, g);
+                } else {
+                    if (mod == 0) DSG_LAUNCH((mlp384d_bx_kernel<0>), grid, block8, 0, s, g);
+                    else if (mod == 1) DSG_LAUNCH((mlp384d_bx_kernel<1>), grid, block8, 0, s, g);
+                    else DSG_LAUNCH((mlp384d_bx_kernel<2>), grid, block8, 0, s, g);
+                }
+            } else if (g.wide8) {   // round 3's eight-wave kernel (register-staged weights): wide8 = 2, or no image
                 const dim3 block8(512);
                 if (proj) {
                     if (mod == 0) DSG_LAUNCH((mlp384_bx_kernel<0, true>), grid, block8, 0, s, g);

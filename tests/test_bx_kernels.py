@@ -173,7 +173,8 @@ def test_qkv_attn_bx_vs_torch(B, res, ws, shift, heads):
 
 
 @pytest.mark.parametrize("M,C,mod,out_mode", [(51200, 384, 1, 1), (20037, 192, 1, 1), (65541, 96, 0, 2), (300, 96, 1, 1), (4096, 384, 0, 0),
-                                               (1000, 192, 0, 2), (20037, 384, 0, 2), (51200, 384, 1, 1 + 16), (4100, 384, 0, 2 + 16)])
+                                               (1000, 192, 0, 2), (20037, 384, 0, 2), (51200, 384, 1, 1 + 16), (4100, 384, 0, 2 + 16),
+                                               (51200, 384, 1, 1 + 32), (20037, 384, 0, 2 + 32), (130, 384, 1, 1)])
 def test_mlp_bx_whole_matrix(M, C, mod, out_mode):
     """the fused fc1 -> GELU -> fc2 -> + residual -> [modulate] -> [LayerNorm | copy] kernel at its three widths against fp64 on the
     bf16-rounded operands, with the hidden activations rounded to bf16 between the two products as the kernel does"""
@@ -189,7 +190,8 @@ def test_mlp_bx_whole_matrix(M, C, mod, out_mode):
     aff = (torch.randn(2 * C, device="cuda", generator=gen) * 0.5) if mod else None
     x_io = x.clone()
     out_xn = torch.full((M, C), float("nan"), device="cuda")
-    # C = 384: the eight-wave kernel (pairs of waves share 32 tokens); out_mode + 16 selects the one-wave-per-SIMD kernel instead
+    # C = 384: the eight-wave LDS-DMA kernel on pre-arranged weight images (round 4); out_mode + 32 selects round 3's eight-wave kernel
+    # (register-staged weights), + 16 the one-wave-per-SIMD kernel
     rc = lib.dsg_debug_mlp_bx(M, C, _p(xn), _p(x_io), _p(W1), _p(b1), _p(W2), _p(b2), _p(aff), out_mode, _p(out_xn) if out_mode else None, 0, None, None)
     assert rc == 0
     out_mode &= 15
@@ -210,7 +212,8 @@ def test_mlp_bx_whole_matrix(M, C, mod, out_mode):
 
 
 @pytest.mark.parametrize("M,C,mod,out_mode", [(20037, 192, 1, 1), (65541, 96, 0, 2), (300, 96, 1, 1), (4096, 192, 0, 0), (51200, 96, 1, 1),
-                                               (51200, 384, 1, 1), (20037, 384, 0, 2), (300, 384, 0, 0)])
+                                               (51200, 384, 1, 1), (20037, 384, 0, 2), (300, 384, 0, 0),
+                                               (51200, 384, 1, 1 + 32), (20037, 384, 0, 2 + 32), (129, 384, 1, 1)])
 def test_projmlp_bx_whole_matrix(M, C, mod, out_mode):
     """proj + residual + LayerNorm-2 + fc1 + GELU + fc2 + residual [+ modulate] [+ LayerNorm | copy] in one kernel against fp64 on the
     bf16-rounded operands: x1 = x + att Wp^T + bp stays in the accumulators (fp32), its LayerNorm is rounded to bf16 as fc1's operand,
@@ -229,9 +232,11 @@ def test_projmlp_bx_whole_matrix(M, C, mod, out_mode):
     aff = (torch.randn(2 * C, device="cuda", generator=gen) * 0.5) if mod else None
     x_io = x.clone()
     out_xn = torch.full((M, C), float("nan"), device="cuda")
+    # (C = 384: out_mode + 32 selects round 3's eight-wave kernel instead of the LDS-DMA one)
     rc = lib.dsg_debug_projmlp_bx(M, C, _p(att), _p(x_io), _p(Wp), _p(bp), _p(W1), _p(b1), _p(W2), _p(b2), _p(aff), out_mode,
                                   _p(out_xn) if out_mode else None, 0, None, None)
     assert rc == 0
+    out_mode &= 15
     x1 = x.double() + _bf(att).double() @ _bf(Wp).double().t() + bp.double()
     xn = _bf(torch.nn.functional.layer_norm(x1, (C,), eps=1e-5).float()).double()
     hid = torch.nn.functional.gelu(xn @ _bf(W1).double().t() + b1.double())

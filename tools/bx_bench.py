@@ -120,6 +120,14 @@ if __name__ == "__main__":
     print(f"B={B}")
     M2, M1, M0 = B * 100, B * 400, B * 1600
     only = os.environ.get("BX_ONLY", "")
+    if only == "mlp":   # the fused MLP kernels alone
+        mlp("L2 fused MLP (mod, LN), 8 waves LDS-DMA", M2, 384)
+        mlp("L2 fused MLP (mod, LN), 8 waves round 3", M2, 384, out_mode=1 + 32)
+        projmlp("L2 proj + MLP (mod, LN), LDS-DMA", M2, 384)
+        projmlp("L2 proj + MLP (mod, LN), round 3", M2, 384, out_mode=1 + 32)
+        projmlp("L1 proj + MLP fused (mod, LN)", M1, 192)
+        projmlp("L0 proj + MLP fused (copy)", M0, 96, mod=0, out_mode=2)
+        sys.exit(0)
     gemm("L2 qkv", M2, 1152, 384)
     gemm("L2 proj (res, LN)", M2, 384, 384, res=1, ln=1)
     gemm("L2 fc1 (gelu)", M2, 1536, 384, act=1)
