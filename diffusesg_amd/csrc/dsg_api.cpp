@@ -2128,6 +2128,34 @@ int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const
     const bool ok = launch_mlp_bx(g, s);
     if (ok && out_mode) launch_bf16_to_f32(ob, out_xn, (size_t)M * C, s);
     if (ok && time_iters > 0 && out_ms) *out_ms = time_launches(s, time_iters, [&]() { (void)launch_mlp_bx(g, s); });   // (x keeps accumulating: timing only)
+    if (ok && C == 384 && g.wide8 == 1 && getenv("DSG_M384_CLK")) {   // dev measurement: phase clocks of one more launch (tools/bx_bench.py)
+        const int nb = (M + 127) / 128;
+        unsigned long long *dbg = nullptr;
+        if (hipMalloc((void **)&dbg, sizeof(unsigned long long) * nb * 128) == hipSuccess) {
+            (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * nb * 128, s);
+            g.dbg = dbg;
+            (void)launch_mlp_bx(g, s);
+            std::vector<unsigned long long> hb((size_t)nb * 128);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(hb.data(), dbg, sizeof(unsigned long long) * hb.size(), hipMemcpyDeviceToHost);
+            double ph[4] = {0, 0, 0, 0}, tot = 0, iv[2][6] = {{0}};
+            for (int b = 0; b < nb; b++)
+                for (int w = 0; w < 8; w++) {
+                    const unsigned long long *t = hb.data() + ((size_t)b * 8 + w) * 16;
+                    for (int k = 0; k < 4; k++) ph[k] += (double)(t[k + 1] - t[k]);
+                    tot += (double)(t[4] - t[0]);
+                    for (int k = 0; k < 6; k++) iv[w >> 2][k] += (double)(t[6 + k] - t[5 + k]);
+                }
+            const double n = (double)nb * 8;
+            fprintf(stderr, "   mlp384d phases (kclk per wave, mean of %d blocks): proj %.1f | LN + exchange %.1f | chunk-pair loop %.1f | epilogue %.1f | block %.1f\n",
+                    nb, ph[0] / n / 1e3, ph[1] / n / 1e3, ph[2] / n / 1e3, ph[3] / n / 1e3, tot / n / 1e3);
+            for (int tm = 0; tm < 2; tm++)
+                fprintf(stderr, "      pair 8, %s half (clk): fc1 %.0f | wait + barrier %.0f | GELU + exchange %.0f | wait + barrier %.0f | fc2 %.0f | wait + barrier %.0f\n",
+                        tm ? "second" : "first", iv[tm][0] / (n / 2), iv[tm][1] / (n / 2), iv[tm][2] / (n / 2), iv[tm][3] / (n / 2), iv[tm][4] / (n / 2), iv[tm][5] / (n / 2));
+            (void)hipFree(dbg);
+            g.dbg = nullptr;
+        }
+    }
     const hipError_t e = hipStreamSynchronize(s);
     cleanup();
     if (!ok) return DSG_ERR_INVALID;

@@ -99,6 +99,8 @@ struct BxMlp {
     const float *mod_aff = nullptr; int mod_ld = 0, mod_off = 0, mod_T = 1;
     int M = 0, C = 0;
     int wide8 = 1;   // C = 384: 1 the eight-wave LDS-DMA kernel (needs img), 2 round 3's eight-wave kernel, 0 mlp_bx_kernel<384> (one wave per SIMD)
+    unsigned long long *dbg = nullptr;   // measurement runs of the debug entry: [grid][8 waves][8] s_memtime stamps (mlp384d_bx_kernel)
+    int skew = 0;                // mlp384d_bx_kernel: stagger step of the first-round blocks in shader clocks (0: all start together)
     const void *img = nullptr;   // C = 384: W1 | W2 | Wp pre-arranged for mlp384d_bx_kernel (launch_mlp384_images; mlp384_image_bytes())
     // the attention half's tail in front (att != null; xn is then unused): x <- x + att Wp^T + bp first, its LayerNorm feeds fc1
     const void *att = nullptr, *Wp = nullptr; const float *bp = nullptr;

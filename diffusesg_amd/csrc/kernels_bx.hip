@@ -1035,7 +1035,13 @@ void launch_mlp384_images(const void *W1b, const void *W2b, const void *Wpb, voi
 typedef __attribute__((address_space(3))) void *lds_vptr;
 #define M384_WAIT_VM(N) __builtin_amdgcn_s_waitcnt(0x0F70 | ((N) & 15) | (((N) >> 4) << 14))   // vmcnt(N) only (lgkmcnt / expcnt: no wait)
 #define M384_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)                                      // lgkmcnt(0) only
+// raw s_barrier (no vmcnt(0) in front of it: the LDS-DMA requests stay in flight across it) between two compiler-level memory barriers
+// (the intrinsic alone does not keep the compiler from moving LDS accesses across it)
+#define M384_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
+#ifndef DSG_M384_EXP
+#define DSG_M384_EXP 0   // timing experiments of tools/m384_exp.sh (wrong results): 1 no LDS-DMA inside the chunk-pair loop, 2 no MFMAs there, 3 no GELU, 5 MFMAs without their LDS fragment reads
+#endif
 template <int MOD, bool PROJ = false>
 __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
     constexpr int C = 384, NP = 24, CT = 6, TLD = 104;
@@ -1049,6 +1055,18 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
     const int rows = min(128, g.M - m0);
     const unsigned mrow = (unsigned)(32 * ts + lrow);
     const char *img = static_cast<const char *>(g.img);
+    // measurement builds of the debug entry only (g.dbg != null): per-wave s_memtime stamps at the phase boundaries
+    unsigned long long *dbg = g.dbg ? g.dbg + ((size_t)blockIdx.x * 8 + wave) * 16 : nullptr;
+#define M384_STAMP(i) do { if (dbg && lane == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    // First-round blocks start STAGGERED (g.skew clocks x an eighth-phase of the CU index inside its XCD): with one block per CU and every
+    // block starting at once, all CUs are in their HBM phases (attention / residual rows in, residual / LayerNorm rows out) at the same
+    // time -- HBM saturated, ~7 B/clk per CU -- and in their compute phases at the same time, HBM idle.  Spread out, a CU's HBM phase
+    // meets the others' compute phases.  The one-tile CUs of the last round absorb the delay.
+    if (g.skew > 0 && blockIdx.x < 256) {
+        const unsigned long long until = __builtin_amdgcn_s_memtime() + (unsigned long long)(((blockIdx.x >> 3) & 7) * g.skew);
+        while (__builtin_amdgcn_s_memtime() < until) __builtin_amdgcn_s_sleep(32);
+    }
+    M384_STAMP(0);
     // this wave's six 1-KiB pieces of a 48-KB stage: image bytes [src, src + 49152) -> ring slot r, linear
     const unsigned dma_voff = (unsigned)lane * 16u;
     auto dma_stage = [&](const char *src, int r) {      // src, r: wave-uniform -> scalar base + one 32-bit lane offset
@@ -1063,11 +1081,19 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
     // of a sum's terms is free, and the register arrays keep compile-time indices)
     bf16x8 xfo[12], xfp[12];
     f32x16 oacc[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ct++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
     if (PROJ) {
+        // x1 = x + att Wp^T + bp: the residual rows and the bias are the proj accumulators' INITIAL value -- their loads are in flight
+        // together with the attention rows and the first weight stages instead of forming a second exposed HBM round trip after the proj
+        const rsrc_t rsXi = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 rr = buf_load4(rsXi, (mrow * C + (unsigned)(192 * kh + 32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.bp + 192 * kh + 32 * ct + 8 * q + 4 * lhalf);
+#pragma unroll
+                for (int e = 0; e < 4; e++) oacc[ct][4 * q + e] = rr[e] + b4[e];
+            }
         const char *wp = img + M384_WPIMG;
         const rsrc_t rsAt = make_rsrc(static_cast<const __bf16 *>(g.att) + (size_t)m0 * C, (unsigned)rows * C * 2u);
         bf16x8 af[24];   // the whole attention row of the lane's token: channels 16 s + 8 half .. + 7 of k-step s
@@ -1077,34 +1103,23 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
             if (ct < CT - 1) M384_WAIT_VM(12); else M384_WAIT_VM(6);   // stage ct has landed (at most the two younger requests are still out)
-            __builtin_amdgcn_s_barrier();
+            M384_BARRIER();
             const char *a = lds + (ct % 3) * M384_STAGE + lhalf * 1024 + (32 * kh + lrow) * 16;
 #pragma unroll
             for (int s = 0; s < 24; s++)
                 oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(a + s * 2048), af[s], oacc[ct], 0, 0, 0);
             M384_WAIT_LGKM0();
-            __builtin_amdgcn_s_barrier();          // every wave has read slot ct % 3
+            M384_BARRIER();          // every wave has read slot ct % 3
             if (ct + 3 < CT) dma_stage(wp + (ct + 3) * M384_STAGE, ct % 3);
             else if (ct == 3) dma_stage(img + M384_W1IMG, 0);          // W1 stage of pair 0 -> slot 0 (its ring position)
         }
-        // x1 = x + proj + bp on this wave's 192 channels; LayerNorm-2 statistics across the pair
-        const rsrc_t rsXi = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
+        M384_STAMP(1);
+        // LayerNorm-2 statistics of x1 (this wave's 192 channels) across the pair
         float sm = 0.f, sq = 0.f;
 #pragma unroll
-        for (int ct = 0; ct < CT; ct++) {
-            f32x4 rr[4];
+        for (int ct = 0; ct < CT; ct++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) rr[q] = buf_load4(rsXi, (mrow * C + (unsigned)(192 * kh + 32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.bp + 192 * kh + 32 * ct + 8 * q + 4 * lhalf);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const float v = oacc[ct][4 * q + e] + b4[e] + rr[q][e];
-                    oacc[ct][4 * q + e] = v; sm += v; sq = fmaf(v, v, sq);
-                }
-            }
-        }
+            for (int r = 0; r < 16; r++) { const float v = oacc[ct][r]; sm += v; sq = fmaf(v, v, sq); }
         sm += __shfl_xor(sm, 32, 64);
         sq += __shfl_xor(sq, 32, 64);
         f32x2 *part0 = reinterpret_cast<f32x2 *>(xchb);   // [128 rows][2]
@@ -1132,6 +1147,10 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
         }
         __syncthreads();                       // slots 1 and 2 are free again
     } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
         dma_stage(img + M384_W1IMG, 0);
         // the normalised rows from HBM, in the K order of the W1 image: k-step s = channels 16 s + 4 half + {0..3} and + 8 + {0..3}
         const rsrc_t rsXn = make_rsrc(static_cast<const __bf16 *>(g.xn) + (size_t)m0 * C, (unsigned)rows * C * 2u);
@@ -1164,38 +1183,66 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
         const f32x4 b4 = *reinterpret_cast<const f32x4 *>(b1w + 8 * q);
         h[4 * q] = b4[0]; h[4 * q + 1] = b4[1]; h[4 * q + 2] = b4[2]; h[4 * q + 3] = b4[3];
     }
-    if (team == 1) { M384_WAIT_VM(6); __builtin_amdgcn_s_barrier(); }        // the second half starts one interval late
+    M384_WAIT_VM(12);                                                        // the W1 stage of pair 0 has landed (two younger requests are out)
+    M384_BARRIER();
+    M384_STAMP(2);
+    if (team == 1) { M384_WAIT_VM(6); M384_BARRIER(); }                      // the second half starts one interval late
     int slot1 = 0, slot2 = 1;                                                // ring slots of this pair's W1 / W2 stage
     for (int p = 0; p < NP; p++) {
         // ---- interval A: fc1 of the own chunk over the whole K (h starts at b1)
+        if (p == 8) M384_STAMP(5);
         {
             const char *a = lds + slot1 * M384_STAGE + w1own, *ax = lds + slot1 * M384_STAGE + w1oth;
+            // weight fragments four k-steps ahead of their MFMA (a wave issues in order: a read issued right in front of its MFMA
+            // exposes the whole LDS latency); sched_group_barrier pins read / MFMA alternation
+            auto LD = [&](int s) { return DSG_M384_EXP == 5 ? xfp[s % 12] : *reinterpret_cast<const bf16x8 *>((s < 12 ? a : ax) + (s % 12) * 2048); };
+            bf16x8 fr[4];
 #pragma unroll
-            for (int s = 0; s < 12; s++)
-                h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(a + s * 2048), xfo[s], h, 0, 0, 0);
+            for (int s = 0; s < 4; s++) fr[s] = LD(s);
 #pragma unroll
-            for (int s = 0; s < 12; s++)
-                h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(ax + s * 2048), xfp[s], h, 0, 0, 0);
+            for (int s = 0; s < 24; s++) {
+                if (DSG_M384_EXP == 2) { h[s & 15] += (float)(s < 12 ? xfo[s] : xfp[s - 12])[0] + (float)fr[s & 3][1]; }
+                else h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s & 3], s < 12 ? xfo[s] : xfp[s - 12], h, 0, 0, 0);
+                if (s + 4 < 24) fr[s & 3] = LD(s + 4);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int s = 0; s < 20; s++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
+        if (p == 8) M384_STAMP(6);
         // (the second half's request of this interval goes LAST: nothing the compiler waits for -- the b1 loads -- has it behind itself)
-        if (team == 1 && p >= 1 && p + 1 < NP) dma_stage(img + M384_W1IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 2) % 3);
-        M384_WAIT_VM(6); M384_WAIT_LGKM0();
-        __builtin_amdgcn_s_barrier();
+        if (DSG_M384_EXP != 1 && team == 1 && p >= 1 && p + 1 < NP) dma_stage(img + M384_W1IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 2) % 3);
+        if (p + 2 < NP) M384_WAIT_VM(6); else M384_WAIT_VM(0);   // (the last stages have no younger request behind them)
+        M384_WAIT_LGKM0();
+        M384_BARRIER();
+        if (p == 8) M384_STAMP(7);
         // ---- interval B: + b1, GELU, bf16; the hidden tile goes to the partner
-        if (team == 0 && p >= 1 && p + 1 < NP) dma_stage(img + M384_W1IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 2) % 3);
-        if (team == 1 && p + 1 < NP) dma_stage(img + M384_W2IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 3) % 3);
+        if (DSG_M384_EXP != 1 && team == 0 && p >= 1 && p + 1 < NP) dma_stage(img + M384_W1IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 2) % 3);
+        if (DSG_M384_EXP != 1 && team == 1 && p + 1 < NP) dma_stage(img + M384_W2IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 3) % 3);
         u32x4 hf[2];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            hf[q >> 1][2 * (q & 1)] = pack_bf16(gelu_f(h[4 * q]), gelu_f(h[4 * q + 1]));
-            hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(gelu_f(h[4 * q + 2]), gelu_f(h[4 * q + 3]));
+            if (DSG_M384_EXP == 3) {   // no GELU
+                hf[q >> 1][2 * (q & 1)] = pack_bf16(h[4 * q], h[4 * q + 1]);
+                hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(h[4 * q + 2], h[4 * q + 3]);
+                continue;
+            }
+            hf[q >> 1][2 * (q & 1)] = pack_bf16(gelu_bx4(h[4 * q]), gelu_bx4(h[4 * q + 1]));
+            hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(gelu_bx4(h[4 * q + 2]), gelu_bx4(h[4 * q + 3]));
         }
         xch2[(0 * 8 + wave) * 64 + lane] = hf[0];
         xch2[(1 * 8 + wave) * 64 + lane] = hf[1];
-        M384_WAIT_VM(6); M384_WAIT_LGKM0();
-        __builtin_amdgcn_s_barrier();
+        if (p == 8) M384_STAMP(8);
+        if (p + 2 < NP) M384_WAIT_VM(6); else M384_WAIT_VM(0);   // (the last stages have no younger request behind them)
+        M384_WAIT_LGKM0();
+        M384_BARRIER();
+        if (p == 8) M384_STAMP(9);
         // ---- interval C: fc2 on the own 192 output channels over both chunks of the pair
-        if (team == 0 && p + 1 < NP) dma_stage(img + M384_W2IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 3) % 3);
+        if (DSG_M384_EXP != 1 && team == 0 && p + 1 < NP) dma_stage(img + M384_W2IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 3) % 3);
         u32x4 hp[2];
         hp[0] = xch2[(0 * 8 + (wave ^ 1)) * 64 + lane];
         hp[1] = xch2[(1 * 8 + (wave ^ 1)) * 64 + lane];
@@ -1208,23 +1255,37 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
         }
         {
             const char *ao = lds + slot2 * M384_STAGE + w2own, *ax = lds + slot2 * M384_STAGE + w2oth;
+            // MFMA i = 4 ct + 2 s2 + c' (c' = 0: own chunk, 1: the partner's), fragments four ahead as in fc1
+            auto LD = [&](int i) { return DSG_M384_EXP == 5 ? __builtin_bit_cast(bf16x8, hp[i & 1]) : *reinterpret_cast<const bf16x8 *>(((i & 1) ? ax : ao) + (4 * (i >> 2) + ((i >> 1) & 1)) * 1024); };
+            bf16x8 fr[4];
 #pragma unroll
-            for (int ct = 0; ct < CT; ct++)
+            for (int i = 0; i < 4; i++) fr[i] = LD(i);
 #pragma unroll
-                for (int s2 = 0; s2 < 2; s2++) {
-                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(ao + (4 * ct + s2) * 1024),
-                                                                       __builtin_bit_cast(bf16x8, hf[s2]), oacc[ct], 0, 0, 0);
-                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(ax + (4 * ct + s2) * 1024),
-                                                                       __builtin_bit_cast(bf16x8, hp[s2]), oacc[ct], 0, 0, 0);
-                }
+            for (int i = 0; i < 24; i++) {
+                const int ct = i >> 2, s2 = (i >> 1) & 1;
+                if (DSG_M384_EXP == 2) oacc[ct][i & 3] += __builtin_bit_cast(float, hf[s2][0] ^ hp[s2][1]) + (float)fr[i & 3][0];
+                else oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 3], __builtin_bit_cast(bf16x8, (i & 1) ? hp[s2] : hf[s2]), oacc[ct], 0, 0, 0);
+                if (i + 4 < 24) fr[i & 3] = LD(i + 4);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int i = 0; i < 20; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
-        M384_WAIT_VM(6); M384_WAIT_LGKM0();
-        __builtin_amdgcn_s_barrier();
+        if (p == 8) M384_STAMP(10);
+        if (p + 2 < NP) M384_WAIT_VM(6); else M384_WAIT_VM(0);   // (the last stages have no younger request behind them)
+        M384_WAIT_LGKM0();
+        M384_BARRIER();
+        if (p == 8) M384_STAMP(11);
         slot1 = slot1 == 0 ? 2 : slot1 - 1;     // (2 p) % 3: 0, 2, 1, 0, ...
         slot2 = slot2 == 0 ? 2 : slot2 - 1;     // (2 p + 1) % 3: 1, 0, 2, 1, ...
     }
-    if (team == 0) { M384_WAIT_VM(0); __builtin_amdgcn_s_barrier(); }        // the first half waits out the second half's last interval
+    if (team == 0) { M384_WAIT_VM(0); M384_BARRIER(); }        // the first half waits out the second half's last interval
     __syncthreads();                           // the ring is free: output transposition, row statistics
+    M384_STAMP(3);
     // ---- epilogue (as mlp384_bx_kernel): lane (token, half) holds channels 192 kh + 32 ct + 8 q + 4 half + {0..3} in oacc[ct][4 q ..]
     const rsrc_t rsX = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
     __bf16 *xo = static_cast<__bf16 *>(g.xn_out);
@@ -1287,9 +1348,13 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
             if (ct % 3 == 2) tflush(ct / 3);
         }
     }
+    M384_WAIT_VM(0);
+    M384_STAMP(4);
+#undef M384_STAMP
 }
 
-bool launch_mlp_bx(const BxMlp &g, hipStream_t s) {
+bool launch_mlp_bx(const BxMlp &g_in, hipStream_t s) {
+    const BxMlp &g = g_in;
     if ((!g.xn && !g.att) || !g.x || !g.W1 || !g.b1 || !g.W2 || !g.b2 || g.M < 1 || (g.out_mode && !g.xn_out)) return false;
     const dim3 grid((g.M + 127) / 128), block(256);
     const int mod = !g.mod_aff ? 0 : (g.mod_ld == 0 ? 1 : 2);
@@ -1313,6 +1378,9 @@ bool launch_mlp_bx(const BxMlp &g, hipStream_t s) {
         case 384:
             if (g.wide8 == 1 && g.img) {   // eight waves, pre-arranged weight images streamed by LDS-DMA (mlp384d_bx_kernel)
                 const dim3 block8(512);
+                static const int skew_env = getenv("DSG_M384_SKEW") ? atoi(getenv("DSG_M384_SKEW")) : -1;   // dev knob: stagger step in clocks
+                BxMlp g = g_in;
+                if (skew_env >= 0) g.skew = skew_env;
                 if (proj) {
                     if (mod == 0) DSG_LAUNCH((mlp384d_bx_kernel<0, true>), grid, block8, 0, s, g);
                     else if (mod == 1) DSG_LAUNCH((mlp384d_bx_kernel<1, true>), grid, block8, 0, s, g);

@@ -120,6 +120,9 @@ if __name__ == "__main__":
     print(f"B={B}")
     M2, M1, M0 = B * 100, B * 400, B * 1600
     only = os.environ.get("BX_ONLY", "")
+    if only == "mlp384":   # the LDS-DMA kernel alone (tools/m384_exp.sh)
+        projmlp("L2 proj + MLP (mod, LN), LDS-DMA", M2, 384)
+        sys.exit(0)
     if only == "mlp":   # the fused MLP kernels alone
         mlp("L2 fused MLP (mod, LN), 8 waves LDS-DMA", M2, 384)
         mlp("L2 fused MLP (mod, LN), 8 waves round 3", M2, 384, out_mode=1 + 32)
