@@ -598,6 +598,7 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     if (getenv("DSG_FUSED_MLP_MAXC")) h->opt_fused_mlp_maxc = atoi(getenv("DSG_FUSED_MLP_MAXC"));
     h->opt_gemm_bf16 = env_on("DSG_GEMM_BF16", false);
     h->opt_bf16_pipe = env_on("DSG_BF16_PIPE", true);
+    if (getenv("DSG_BF16_MLP")) h->opt_bf16_mlp = atoi(getenv("DSG_BF16_MLP"));   // dev knob: A/B of the C = 384 MLP kernels (1 LDS-DMA, 4 round 3's)
     h->opt_gemm_split = env_on("DSG_GEMM_SPLIT", false);
     *out = h;
     g_live_handles++;

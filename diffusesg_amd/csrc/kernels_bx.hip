@@ -1039,6 +1039,9 @@ typedef __attribute__((address_space(3))) void *lds_vptr;
 // (the intrinsic alone does not keep the compiler from moving LDS accesses across it)
 #define M384_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
+#ifndef DSG_M384_PRIO
+#define DSG_M384_PRIO 0   // 1: s_setprio 1 in the matrix intervals -- measured SLOWER (chunk-pair loop 168k clk against 145k: profiles/r4/m384_experiments.txt)
+#endif
 #ifndef DSG_M384_EXP
 #define DSG_M384_EXP 0   // timing experiments of tools/m384_exp.sh (wrong results): 1 no LDS-DMA inside the chunk-pair loop, 2 no MFMAs there, 3 no GELU, 5 MFMAs without their LDS fragment reads
 #endif
@@ -1189,8 +1192,11 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
     if (team == 1) { M384_WAIT_VM(6); M384_BARRIER(); }                      // the second half starts one interval late
     int slot1 = 0, slot2 = 1;                                                // ring slots of this pair's W1 / W2 stage
     for (int p = 0; p < NP; p++) {
-        // ---- interval A: fc1 of the own chunk over the whole K (h starts at b1)
+        // ---- interval A: fc1 of the own chunk over the whole K (h starts at b1).  The matrix intervals run at priority 1: the other half
+        // of the block is in its GELU interval on the same SIMDs, and at equal priority its VALU stream takes the issue slots the
+        // fragment reads and MFMAs of this one need (measured: fc1 1560 clk beside a GELU partner, 1070 beside an MFMA partner)
         if (p == 8) M384_STAMP(5);
+        if (DSG_M384_PRIO) __builtin_amdgcn_s_setprio(1);
         {
             const char *a = lds + slot1 * M384_STAGE + w1own, *ax = lds + slot1 * M384_STAGE + w1oth;
             // weight fragments four k-steps ahead of their MFMA (a wave issues in order: a read issued right in front of its MFMA
@@ -1213,6 +1219,7 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
+        if (DSG_M384_PRIO) __builtin_amdgcn_s_setprio(0);
         if (p == 8) M384_STAMP(6);
         // (the second half's request of this interval goes LAST: nothing the compiler waits for -- the b1 loads -- has it behind itself)
         if (DSG_M384_EXP != 1 && team == 1 && p >= 1 && p + 1 < NP) dma_stage(img + M384_W1IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 2) % 3);
@@ -1242,7 +1249,6 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
         M384_BARRIER();
         if (p == 8) M384_STAMP(9);
         // ---- interval C: fc2 on the own 192 output channels over both chunks of the pair
-        if (DSG_M384_EXP != 1 && team == 0 && p + 1 < NP) dma_stage(img + M384_W2IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 3) % 3);
         u32x4 hp[2];
         hp[0] = xch2[(0 * 8 + (wave ^ 1)) * 64 + lane];
         hp[1] = xch2[(1 * 8 + (wave ^ 1)) * 64 + lane];
@@ -1253,6 +1259,7 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
                 h[4 * q] = b4[0]; h[4 * q + 1] = b4[1]; h[4 * q + 2] = b4[2]; h[4 * q + 3] = b4[3];
             }
         }
+        if (DSG_M384_PRIO) __builtin_amdgcn_s_setprio(1);
         {
             const char *ao = lds + slot2 * M384_STAGE + w2own, *ax = lds + slot2 * M384_STAGE + w2oth;
             // MFMA i = 4 ct + 2 s2 + c' (c' = 0: own chunk, 1: the partner's), fragments four ahead as in fc1
@@ -1275,6 +1282,10 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         }
+        if (DSG_M384_PRIO) __builtin_amdgcn_s_setprio(0);
+        // (requests of a matrix interval go out BEHIND its MFMAs: six pieces cost the issuing wave ~600 clk, which it has to spare while the
+        // other half finishes its GELU interval)
+        if (DSG_M384_EXP != 1 && team == 0 && p + 1 < NP) dma_stage(img + M384_W2IMG + (size_t)(p + 1) * M384_STAGE, (2 * p + 3) % 3);
         if (p == 8) M384_STAMP(10);
         if (p + 2 < NP) M384_WAIT_VM(6); else M384_WAIT_VM(0);   // (the last stages have no younger request behind them)
         M384_WAIT_LGKM0();

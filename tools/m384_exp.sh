@@ -12,7 +12,7 @@ fi
 mkdir -p tools/bin/ab
 cd diffusesg_amd/csrc
 for v in ${M384_EXPS:-0 1 2 3 5}; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize -DDSG_M384_EXP=$v -c kernels_bx.hip -o /tmp/kernels_bx_m384exp$v.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize -DDSG_M384_EXP=${v%p*} $( [[ $v == *p0 ]] && echo -DDSG_M384_PRIO=0 ) -c kernels_bx.hip -o /tmp/kernels_bx_m384exp$v.o &
 done
 wait
 for v in ${M384_EXPS:-0 1 2 3 5}; do
