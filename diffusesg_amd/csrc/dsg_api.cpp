@@ -1043,11 +1043,16 @@ BlockOut run_block(dsg_handle h, Workspace *w, const BlockPlan &b, bool premod, 
     else g.ln_stats = w->stats;   // gamma/beta of norm2 are folded into fc1_wf / fc1_bf
     g.W = b.fc1_wf; g.bias = b.fc1_bf; g.act = ACT_GELU;
     g.C = w->hid; g.ldc = Hd;
+    // measurement only (DSG_HID_EXP=1, wrong results): a leading dimension of 0 gives the kernels an empty buffer range -- fc1's stores of the
+    // 4C-wide hidden tensor are dropped and fc2's loads of it return zeros without memory traffic, every instruction still issues: the
+    // upper bound of what a fused fc1 -> GELU -> fc2 kernel could gain by keeping the hidden tensor on the chip (profiles/r4/fp32_upper_bounds.txt)
+    static const bool hid_exp = getenv("DSG_HID_EXP") != nullptr;
+    if (hid_exp) g.ldc = 0;
     const bool hid_bf16 = bf16_tensor_ok(WT(h, p + ".mlp.fc2.weight"), Hd) && bf16_of(h, b.fc1_wf) != nullptr;
     g.c_bf16 = hid_bf16;
     P_GEMM_LP(g);
     g = GemmArgs();
-    g.A = w->hid; g.lda = Hd; g.K1 = Hd; g.K = Hd; g.M = M; g.N = C;
+    g.A = w->hid; g.lda = hid_exp ? 0 : Hd; g.K1 = Hd; g.K = Hd; g.M = M; g.N = C;
     g.a_bf16 = hid_bf16;
     g.W = WT(h, p + ".mlp.fc2.weight"); g.bias = WT(h, p + ".mlp.fc2.bias");
     g.res = w->x; g.ldres = C; g.C = w->x; g.ldc = C;

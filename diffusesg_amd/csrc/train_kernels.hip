@@ -163,21 +163,40 @@ __global__ __launch_bounds__(256) void t_colsum_grouped_kernel(TGemmGroup g) {
 }
 // C[i] = (accumulate ? C[i] : 0) + sum_z part[z][i]   (fixed order); the blocks behind the M N elements add the slices of the
 // column sums that gemm_tn_f32_kernel<true> wrote next to its partial products: cs_out[m] = sum_z cs_part[z][m]
-__global__ void t_splitk_reduce_kernel(const float *part, float *C, int ldc, int M, int N, int S, int accumulate, const float *cs_part, float *cs_out) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, mn = (size_t)M * N, mn_pad = (mn + 255) / 256 * 256;
-    if (i >= mn) {
-        if (cs_out && i >= mn_pad && i - mn_pad < (size_t)M) {
-            const size_t m = i - mn_pad;
-            float v = 0.f;
-            for (int z = 0; z < S; z++) v += cs_part[(size_t)z * M + m];
-            cs_out[m] = v;
-        }
-        return;
+// ZL slice lanes per output (a block = 256 / ZL consecutive outputs x ZL lanes): lane q adds slices q, q + ZL, ... in order, then the ZL lane
+// sums are added in order -- a small weight's 256 slices are no longer walked by one thread (round 3: 36 blocks for a 96 x 96 gradient,
+// 256 dependent strided reads per thread, 25 us a call)
+template <int ZL>
+__global__ __launch_bounds__(256) void t_splitk_reduce_kernel(const float *part, float *C, int ldc, int M, int N, int S, int accumulate, const float *cs_part, float *cs_out) {
+    constexpr int OUT = 256 / ZL;
+    __shared__ float red[ZL][OUT + 1];
+    const int ol = threadIdx.x % OUT, q = threadIdx.x / OUT;
+    const size_t mn = (size_t)M * N, n_blk = (mn + OUT - 1) / OUT;
+    const bool cs = blockIdx.x >= n_blk;                               // the blocks behind the M N outputs: the column sums
+    const size_t i = cs ? (size_t)(blockIdx.x - n_blk) * OUT + ol : (size_t)blockIdx.x * OUT + ol;
+    const size_t lim = cs ? (size_t)M : mn;
+    const float *src = cs ? cs_part : part;
+    float v = 0.f;
+    if (i < lim) for (int z = q; z < S; z += ZL) v += src[(size_t)z * lim + i];
+    red[q][ol] = v;
+    __syncthreads();
+    if (q == 0 && i < lim) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < ZL; k++) t += red[k][ol];
+        if (cs) cs_out[i] = t;
+        else { const size_t m = i / N, n = i % N; C[m * ldc + n] = (accumulate ? C[m * ldc + n] : 0.f) + t; }
     }
-    const int m = i / N, n = i % N;
-    float v = accumulate ? C[(size_t)m * ldc + n] : 0.f;
-    for (int z = 0; z < S; z++) v += part[(size_t)z * mn + i];
-    C[(size_t)m * ldc + n] = v;
+}
+static void t_splitk_reduce(const float *part, float *C, int ldc, int M, int N, int S, bool accumulate, const float *cs_part, float *cs_out, hipStream_t s) {
+    const size_t mn = (size_t)M * N;
+    // slice lanes so that the launch has >= ~1024 blocks' worth of threads where the output is small and the slices are many
+    const int zl = (S >= 64 && mn < ((size_t)1 << 17)) ? 16 : ((S >= 16 && mn < ((size_t)1 << 19)) ? 4 : 1);
+    const int out = 256 / zl;
+    const unsigned rb = (unsigned)((mn + out - 1) / out) + (cs_out ? (unsigned)((M + out - 1) / out) : 0u);
+    if (zl == 16) hipLaunchKernelGGL((t_splitk_reduce_kernel<16>), dim3(rb), dim3(256), 0, s, part, C, ldc, M, N, S, (int)accumulate, cs_part, cs_out);
+    else if (zl == 4) hipLaunchKernelGGL((t_splitk_reduce_kernel<4>), dim3(rb), dim3(256), 0, s, part, C, ldc, M, N, S, (int)accumulate, cs_part, cs_out);
+    else hipLaunchKernelGGL((t_splitk_reduce_kernel<1>), dim3(rb), dim3(256), 0, s, part, C, ldc, M, N, S, (int)accumulate, cs_part, cs_out);
 }
 // [R][Cc] -> [Cc][R] (weights on their way into the MFMA GEMM, which wants both operands K-contiguous)
 __global__ __launch_bounds__(256) void t_transpose_kernel(const float *src, int ld, float *dst, int R, int Cc) {
@@ -360,8 +379,7 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
             const dim3 grid((unsigned)(tiles_m * tiles_n * S));
             if (a_colsum) hipLaunchKernelGGL((gemm_tn_f32_kernel<true>), grid, dim3(256), 0, s, A, lda, B, ldb, buf, M, N, K, kslice, tiles_m, tiles_n, buf + nC);
             else hipLaunchKernelGGL((gemm_tn_f32_kernel<false>), grid, dim3(256), 0, s, A, lda, B, ldb, buf, M, N, K, kslice, tiles_m, tiles_n, nullptr);
-            const unsigned rb = (unsigned)(((size_t)M * N + 255) / 256) + (a_colsum ? (unsigned)((M + 255) / 256) : 0u);
-            hipLaunchKernelGGL(t_splitk_reduce_kernel, dim3(rb), dim3(256), 0, s, buf, C, ldc, M, N, S, (int)accumulate, buf + nC, a_colsum);
+            t_splitk_reduce(buf, C, ldc, M, N, S, accumulate, buf + nC, a_colsum, s);
             if (a_colsum) colsum_done = true;
             return;
         }
@@ -384,9 +402,7 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
     else if (!ta && tb) hipLaunchKernelGGL((t_gemm_kernel<false, true>), grid, block, 0, s, A, lda, B, ldb, bias, Cout, ldo, M, N, K, acc1, kslice);
     else if (ta && !tb) hipLaunchKernelGGL((t_gemm_kernel<true, false>), grid, block, 0, s, A, lda, B, ldb, bias, Cout, ldo, M, N, K, acc1, kslice);
     else hipLaunchKernelGGL((t_gemm_kernel<true, true>), grid, block, 0, s, A, lda, B, ldb, bias, Cout, ldo, M, N, K, acc1, kslice);
-    if (S > 1)
-        hipLaunchKernelGGL(t_splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, ts.sk, C, ldc, M, N, S,
-                           (int)accumulate, (const float *)nullptr, (float *)nullptr);
+    if (S > 1) t_splitk_reduce(ts.sk, C, ldc, M, N, S, accumulate, nullptr, nullptr, s);
 }
 
 void t_gemm_grouped(bool ta, bool tb, bool sum, const TGemmGroup &g, hipStream_t s) {
@@ -495,18 +511,48 @@ __global__ void t_modulate_bwd_final_kernel(const double *part, float *d_aff, in
 }
 
 // LayerNorm with affine: one wave per row (lanes stride over the channels: coalesced), two-pass statistics.  stats[m] = (mean, rstd)
-__global__ __launch_bounds__(256) void t_ln_fwd_kernel(const float *x, const float *gam, const float *bet, float *y, float *stats, int M, int C) {
+// One wave per row, the row read ONCE into registers (KC = ceil(C / 64) values per lane).  With aff != null the row is modulated first --
+// u = shift + x (1 + scale), x_mod = u sigmoid(u) (diffusesg.py:238-243), written to y_mod: the block's shortcut and the tensor LayerNorm-1
+// normalises -- so the modulate pass and its second trip over [M, C] are gone (round 3: t_modulate_fwd + t_ln_fwd, three reads of the row).
+template <int KC>
+__global__ __launch_bounds__(256) void t_ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ aff, float *__restrict__ y_mod,
+                                                        const float *__restrict__ gam, const float *__restrict__ bet, float *__restrict__ y,
+                                                        float *__restrict__ stats, int M, int C, int T) {
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= M) return;
     const float *r = x + (size_t)m * C;
-    float sacc = 0.f;
-    for (int c = lane; c < C; c += 64) sacc += r[c];
+    const float *af = aff ? aff + (size_t)(m / T) * 2 * C : nullptr;
+    float v[KC], sacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < KC; k++) {
+        const int c = lane + 64 * k;
+        v[k] = 0.f;
+        if (c < C) {
+            v[k] = r[c];
+            if (af) { const float u = af[C + c] + v[k] * (af[c] + 1.0f); v[k] = u * t_sigmoid(u); y_mod[(size_t)m * C + c] = v[k]; }
+            sacc += v[k];
+        }
+    }
     const float mean = wave_sum(sacc) / (float)C;
-    float v = 0.f;
-    for (int c = lane; c < C; c += 64) { const float d = r[c] - mean; v = fmaf(d, d, v); }
-    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)C + LN_EPS);
-    for (int c = lane; c < C; c += 64) y[(size_t)m * C + c] = (r[c] - mean) * rstd * gam[c] + bet[c];
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < KC; k++) if (lane + 64 * k < C) { const float d = v[k] - mean; q = fmaf(d, d, q); }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + LN_EPS);
+#pragma unroll
+    for (int k = 0; k < KC; k++) {
+        const int c = lane + 64 * k;
+        if (c < C) y[(size_t)m * C + c] = (v[k] - mean) * rstd * gam[c] + bet[c];
+    }
     if (lane == 0) { stats[2 * (size_t)m] = mean; stats[2 * (size_t)m + 1] = rstd; }
+}
+// x (+ modulate with aff [B, 2C], T tokens per sample -> y_mod) -> LayerNorm -> y, stats
+static void t_ln_fwd_launch(const float *x, const float *aff, float *y_mod, const float *gam, const float *bet, float *y, float *stats, int M, int C, int T,
+                            hipStream_t s) {
+    const int kc = (C + 63) / 64;
+#define T_LNF(KC_) hipLaunchKernelGGL((t_ln_fwd_kernel<KC_>), dim3((M + 3) / 4), dim3(256), 0, s, x, aff, y_mod, gam, bet, y, stats, M, C, T)
+    if (kc <= 2) T_LNF(2); else if (kc <= 3) T_LNF(3); else if (kc <= 6) T_LNF(6); else if (kc <= 12) T_LNF(12); else if (kc <= 24) T_LNF(24);
+    else t_scratch(s).failed = true;   // rows wider than 1536 channels do not occur
+#undef T_LNF
 }
 // dx_out = (dx_in ? dx_in : 0) + rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;  d_gamma = sum_m dy xhat, d_beta = sum_m dy.
 // A block of 4 waves walks a chunk of rows (one wave per row, lanes stride over the channels); every lane keeps the two column sums of
@@ -554,19 +600,20 @@ __global__ __launch_bounds__(256) void t_ln_bwd_kernel(const float *__restrict__
         p[C + c] = ((double)red[0][1][c] + (double)red[1][1][c]) + ((double)red[2][1][c] + (double)red[3][1][c]);
     }
 }
-// (d_gamma | d_beta)[c] = sum over the R block partials, in a fixed order: block = 16 columns x 16 row lanes (lane q adds partials
-// q, q + 16, ...; the 16 lane sums are added in order)
+// (d_gamma | d_beta)[c] = sum over the R block partials, in a fixed order: block = 4 columns x 64 row lanes (lane q adds partials
+// q, q + 64, ...; the 64 lane sums are added in order).  (Round 3 ran 16 columns x 16 row lanes: 12 blocks for C = 96, every thread
+// walking 64 strided partials one after the other -- 67 us per call, 5 % of a training iteration for a 1.5 MB reduction.)
 __global__ __launch_bounds__(256) void t_ln_bwd_final_kernel(const double *part, float *d_gamma, float *d_beta, int C, int R) {
-    __shared__ double red[16][17];
-    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;   // c over 2C
+    __shared__ double red[64][5];
+    const int cl = threadIdx.x & 3, q = threadIdx.x >> 2, c = blockIdx.x * 4 + cl;   // c over 2C
     double sacc = 0.0;
-    if (c < 2 * C) for (int r = q; r < R; r += 16) sacc += part[(size_t)r * 2 * C + c];
+    if (c < 2 * C) for (int r = q; r < R; r += 64) sacc += part[(size_t)r * 2 * C + c];
     red[q][cl] = sacc;
     __syncthreads();
     if (q == 0 && c < 2 * C) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) t += red[k][cl];
+        for (int k = 0; k < 64; k++) t += red[k][cl];
         const float v = (float)t;
         if (c < C) { if (d_gamma) d_gamma[c] = v; } else if (d_beta) d_beta[c - C] = v;
     }
@@ -1006,17 +1053,15 @@ static inline unsigned t_blocks(size_t n) { return (unsigned)((n + 255) / 256); 
 
 bool train_block(const TrainBlockArgs &a, hipStream_t s) {
     const int B = a.B, T = a.res * a.res, C = a.C, M = B * T, H = a.hidden;
-    const size_t nMC = (size_t)M * C;
     TAttnGeom g{a.res, a.ws, a.shift, a.heads, C};
     // ---- forward ----
     if (!a.aff_grouped)   // params = affine(emb); the whole-network step computes all blocks' rows in one grouped launch up front
         t_gemm(false, true, a.emb, NOISE_EMB, a.W.aff_w, NOISE_EMB, a.W.aff_b, a.aff, 2 * C, B, 2 * C, NOISE_EMB, false, s);
-    hipLaunchKernelGGL(t_modulate_fwd_kernel, dim3(t_blocks(nMC)), dim3(256), 0, s, a.x_in, a.aff, a.x_mod, T, C, nMC);
-    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x_mod, a.W.n1_w, a.W.n1_b, a.xn1, a.stats1, M, C);
+    t_ln_fwd_launch(a.x_in, a.aff, a.x_mod, a.W.n1_w, a.W.n1_b, a.xn1, a.stats1, M, C, T, s);   // x_mod = modulate(x_in), xn1 = LayerNorm-1(x_mod): one row pass
     t_gemm(false, true, a.xn1, C, a.W.qkv_w, C, a.W.qkv_b, a.qkv, 3 * C, M, 3 * C, C, false, s);
     if (!t_attn_launch(false, a.qkv, a.W.rpb, a.att, nullptr, nullptr, nullptr, B, g, s)) return false;
     t_gemm(false, true, a.att, C, a.W.proj_w, C, a.W.proj_b, a.x1, C, M, C, C, false, s, nullptr, a.x_mod);                  // x1 = shortcut + proj(att)
-    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, a.x1, a.W.n2_w, a.W.n2_b, a.xn2, a.stats2, M, C);
+    t_ln_fwd_launch(a.x1, nullptr, nullptr, a.W.n2_w, a.W.n2_b, a.xn2, a.stats2, M, C, T, s);
     t_gemm(false, true, a.xn2, C, a.W.fc1_w, C, a.W.fc1_b, a.hid, H, M, H, C, false, s, nullptr, nullptr, ACT_GELU_KEEP, a.pre);   // pre = fc1(xn2), hid = GELU(pre)
     t_gemm(false, true, a.hid, H, a.W.fc2_w, H, a.W.fc2_b, a.x_out, C, M, C, H, false, s, nullptr, a.x1);                    // x_out = x1 + fc2(gelu(fc1(ln2)))
     if (!a.grad_out) return hipGetLastError() == hipSuccess;
@@ -1064,7 +1109,7 @@ void t_gelu(const float *x, const float *dy, float *out, size_t n, bool bwd, hip
 }
 void t_add(float *a, const float *b, size_t n, hipStream_t s) { hipLaunchKernelGGL(t_add_kernel, dim3(t_blocks(n)), dim3(256), 0, s, a, b, n); }
 void t_ln_fwd(const float *x, const float *gam, const float *bet, float *y, float *stats, int M, int C, hipStream_t s) {
-    hipLaunchKernelGGL(t_ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gam, bet, y, stats, M, C);
+    t_ln_fwd_launch(x, nullptr, nullptr, gam, bet, y, stats, M, C, 1, s);
 }
 void t_ln_bwd(const float *x, const float *gam, const float *stats, const float *dy, const float *dx_in, float *dx_out, float *d_gamma, float *d_beta,
               int M, int C, hipStream_t s) {
@@ -1080,7 +1125,7 @@ void t_ln_bwd(const float *x, const float *gam, const float *stats, const float 
     if (kc <= 2) T_LNB(2); else if (kc <= 3) T_LNB(3); else if (kc <= 6) T_LNB(6); else if (kc <= 12) T_LNB(12); else if (kc <= 24) T_LNB(24);
     else { ts.failed = true; return; }   // rows wider than 1536 channels do not occur (4 x 384 is the widest LayerNorm of the networks)
 #undef T_LNB
-    hipLaunchKernelGGL(t_ln_bwd_final_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, part, d_gamma, d_beta, C, blocks);
+    hipLaunchKernelGGL(t_ln_bwd_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, s, part, d_gamma, d_beta, C, blocks);
 }
 void t_modulate(const float *x, const float *aff, const float *dy, float *out, float *d_aff, int B, int T, int C, bool bwd, hipStream_t s) {
     if (bwd) {

@@ -791,9 +791,9 @@ def test_stream_contract_nothing_touches_the_default_stream(name, B, T_):
     results = {}
     for tag in ("A", "B"):            # A: the step graphs are captured during this call and replayed on A; B: replayed on another stream
         st = torch.cuda.Stream()
-        with torch.cuda.stream(st):   # (the caching allocator gives this stream its own blocks: allocate them before parking)
-            scratch = [torch.empty_like(r) for r in ref for _ in range(4)]
-        del scratch
+        with torch.cuda.stream(st):   # (PyTorch's caching allocator keeps separate block pools per stream; a first allocation on a new stream
+            warm = run_all(use_graph=False)   # may reach hipMalloc / hipFree, which can wait for the whole device.  One EAGER pass on this
+        del warm                              # stream fills its pool; no graph is captured by it)
         torch.cuda.synchronize()
         parked = _park_default_stream(4.0)
         t0 = time.perf_counter()
