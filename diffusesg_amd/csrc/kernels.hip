@@ -991,6 +991,46 @@ void launch_fused_attn96(float *x, const float *aff, int aff_ld, int aff_off, co
 // BF (the opt-in bf16 mode's block pipeline only): the two products on v_mfma_f32_32x32x16_bf16 -- 18 + 6 instructions per wave instead
 // of 144 + 48 f32 ones; LN(x) pairs as they stand in the registers are the first product's B operand (k order 16 s + 8 (j >> 2) + 4 half +
 // (j & 3), the packed weights Wfp / W2p follow it: dsg_api.cpp), the GELU'd accumulators the second's.  The pooling stays fp32.
+// -------------------------------------------------------------------------------------------------
+// Row tiles through LDS.  The register-chained C = 96 kernels give a lane ONE token row, so a direct load / store instruction touches
+// 32 rows x 32 bytes: thirty-two cache lines a quarter used, and the texture path (not HBM) bounds the kernel's I/O (round 4:
+// profiles/r4/m384_experiments.txt -- the HBM phases of a block do not speed up when the other CUs are kept off the memory).  A wave's
+// 32 consecutive token rows are ONE contiguous 12-KB piece of the [M, 96] tensor: it is copied linearly (1 KiB per wave-instruction, whole
+// cache lines) and only crosses between "lane = row" and "lane = 16 consecutive bytes" inside the wave's own LDS tile (rows padded to 100
+// floats: conflict-free both ways).  No barrier: only the owning wave touches its tile, and a wave's LDS operations complete in order.
+// -------------------------------------------------------------------------------------------------
+constexpr int T96_LD = 100;                       // floats per padded row
+constexpr int T96_FLOATS = 32 * T96_LD;           // one wave's tile
+// fragment values of the lane's row -> the wave's tile; v(e4) = the f32x4 of channels 4 e4 .. + 3 owned by this lane (e4 = 2 q + half)
+__device__ __forceinline__ void t96_put(float *tile, int lrow, int e4, f32x4 v) { *reinterpret_cast<f32x4 *>(tile + lrow * T96_LD + 4 * e4) = v; }
+__device__ __forceinline__ f32x4 t96_get(const float *tile, int lrow, int e4) { return *reinterpret_cast<const f32x4 *>(tile + lrow * T96_LD + 4 * e4); }
+// the tile's rows [0, rows) -> 32 consecutive rows of a [*, 96] fp32 tensor starting at g (row-contiguous 16-byte pieces, whole lines)
+__device__ __forceinline__ void t96_store_rows(const float *tile, float *g, int rows, int lane) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const int p = 64 * k + lane, r = p / 24, c = p - 24 * r;
+        if (r < rows) *reinterpret_cast<f32x4 *>(g + (size_t)r * 96 + 4 * c) = *reinterpret_cast<const f32x4 *>(tile + r * T96_LD + 4 * c);
+    }
+}
+__device__ __forceinline__ void t96_load_rows(float *tile, const float *g, int rows, int lane) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const int p = 64 * k + lane, r = p / 24, c = p - 24 * r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows) v = *reinterpret_cast<const f32x4 *>(g + (size_t)r * 96 + 4 * c);
+        *reinterpret_cast<f32x4 *>(tile + r * T96_LD + 4 * c) = v;
+    }
+}
+// the same for a bf16 [*, 96] tensor: the tile holds packed pairs in its first 48 floats per row (12 pieces of 16 bytes)
+__device__ __forceinline__ void t96_put_bf16(float *tile, int lrow, int e4, u32x2_c v) { *reinterpret_cast<u32x2_c *>(tile + lrow * T96_LD + 2 * e4) = v; }
+__device__ __forceinline__ void t96_store_rows_bf16(const float *tile, unsigned short *g, int rows, int lane) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const int p = 64 * k + lane, r = p / 12, c = p - 12 * r;
+        if (r < rows) *reinterpret_cast<f32x4 *>(g + (size_t)r * 96 + 8 * c) = *reinterpret_cast<const f32x4 *>(tile + r * T96_LD + 4 * c);
+    }
+}
+
 template <bool BF>
 __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__restrict__ x, const float *__restrict__ gam,
                                                                  const float *__restrict__ bet, const float *__restrict__ Wfp,
@@ -1011,7 +1051,7 @@ __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__
     float sum = 0.f;
 #pragma unroll
     for (int s = 0; s < S; s++) {
-        xn[s] = *reinterpret_cast<const f32x4 *>(xr + 8 * s);
+        xn[s] = *reinterpret_cast<const f32x4 *>(xr + 8 * s);   // (through the wave's LDS row tile instead: measured slower, 1.40 vs 1.38 ms for the six C = 96 launches)
         sum += (xn[s][0] + xn[s][1]) + (xn[s][2] + xn[s][3]);
     }
     sum += __shfl_xor(sum, 32, 64);
@@ -1238,9 +1278,10 @@ __global__ __launch_bounds__(256, 2) void fused_patch_embed96_kernel(const float
         for (int r = 0; r < 16; r++) { const float d = acc[nt][r] - mean; var = fmaf(d, d, var); }
     var += __shfl_xor(var, 32, 64);
     const float rstd = fast_rsqrt(var * (1.0f / C) + LN_EPS);
-    if (!ok) return;
+    __shared__ __attribute__((aligned(16))) float tiles[4 * T96_FLOATS];
+    float *tile = tiles + wave * T96_FLOATS;
+    const int m_w = (blockIdx.x * 4 + wave) * 32, rows_w = min(32, M - m_w);   // this wave's rows (<= 0: a padding wave)
     const float *scale = aff + (size_t)b * aff_ld + aff_off + 4 * lhalf, *shift = scale + C;
-    float *xr = x + (size_t)m * C + 4 * lhalf;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 3; nt++)
@@ -1263,17 +1304,17 @@ __global__ __launch_bounds__(256, 2) void fused_patch_embed96_kernel(const float
 #pragma unroll
                 for (int t = 0; t < 4; t++) o[t] = silu_exact(sh2[t] + o[t] * (sc2[t] + 1.0f));
             }
-            *reinterpret_cast<f32x4 *>(xr + e) = o;
+            t96_put(tile, lrow, (e >> 2) + lhalf, o);
             if (xn) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) { acc[nt][4 * g + t] = o[t]; s1 += o[t]; s2 = fmaf(o[t], o[t], s2); }
             }
         }
+    if (rows_w > 0) t96_store_rows(tile, x + (size_t)m_w * C, rows_w, lane);
     if (xn) {   // bf16 block pipeline: LayerNorm-1 (no affine) of the stored row as the bf16 tensor the first QKV GEMM reads
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         const float mu = s1 * (1.0f / C), rs = fast_rsqrt(fmaxf(fmaf(-mu, mu, s2 * (1.0f / C)), 0.f) + LN_EPS), nmr = -mu * rs;
-        u32x2_c *dst = reinterpret_cast<u32x2_c *>(reinterpret_cast<unsigned short *>(xn) + (size_t)m * C + 4 * lhalf);
 #pragma unroll
         for (int nt = 0; nt < 3; nt++)
 #pragma unroll
@@ -1281,8 +1322,9 @@ __global__ __launch_bounds__(256, 2) void fused_patch_embed96_kernel(const float
                 f32x4 v;
 #pragma unroll
                 for (int t = 0; t < 4; t++) v[t] = fmaf(acc[nt][4 * g + t], rs, nmr);
-                dst[(32 * nt + 8 * g) / 4] = pack_bf16x4(v);
+                t96_put_bf16(tile, lrow, (32 * nt + 8 * g) / 4 + lhalf, pack_bf16x4(v));
             }
+        if (rows_w > 0) t96_store_rows_bf16(tile, reinterpret_cast<unsigned short *>(xn) + (size_t)m_w * C, rows_w, lane);
     }
 }
 
