@@ -1238,8 +1238,8 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
                 hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(h[4 * q + 2], h[4 * q + 3]);
                 continue;
             }
-            hf[q >> 1][2 * (q & 1)] = pack_bf16(gelu_bx4(h[4 * q]), gelu_bx4(h[4 * q + 1]));
-            hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(gelu_bx4(h[4 * q + 2]), gelu_bx4(h[4 * q + 3]));
+            hf[q >> 1][2 * (q & 1)] = pack_bf16(gelu_f(h[4 * q]), gelu_f(h[4 * q + 1]));
+            hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(gelu_f(h[4 * q + 2]), gelu_f(h[4 * q + 3]));
         }
         xch2[(0 * 8 + wave) * 64 + lane] = hf[0];
         xch2[(1 * 8 + wave) * 64 + lane] = hf[1];
