@@ -1098,11 +1098,33 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
                 for (int e = 0; e < 4; e++) oacc[ct][4 * q + e] = rr[e] + b4[e];
             }
         const char *wp = img + M384_WPIMG;
-        const rsrc_t rsAt = make_rsrc(static_cast<const __bf16 *>(g.att) + (size_t)m0 * C, (unsigned)rows * C * 2u);
-        bf16x8 af[24];   // the whole attention row of the lane's token: channels 16 s + 8 half .. + 7 of k-step s
+        dma_stage(wp, 0);
+        // The block's 128 attention rows are ONE contiguous 96-KB piece of att: it comes in by LDS-DMA (whole cache lines; direct
+        // "lane = row" loads take 16 bytes of each of 32 rows per instruction and are bound by the texture path) into ring slots 1 + 2,
+        // 16-byte piece c of row r at piece position 48 r + (c ^ (r & 15)) -- the swizzle is in the SOURCE address, the LDS image of a
+        // DMA instruction is lane-linear -- so that the 16 rows a ds_read_b128 lane group reads hit 16 different bank groups.
+        {
+            const char *asrc = reinterpret_cast<const char *>(static_cast<const __bf16 *>(g.att) + (size_t)m0 * C);
 #pragma unroll
-        for (int s = 0; s < 24; s++) af[s] = __builtin_bit_cast(bf16x8, buf_load_u4(rsAt, (mrow * C + 16u * s + 8u * lhalf) * 2u, 0u));
-        dma_stage(wp, 0); dma_stage(wp + M384_STAGE, 1); dma_stage(wp + 2 * M384_STAGE, 2);
+            for (int k = 0; k < 12; k++) {
+                const int P = (wave * 12 + k) * 64 + lane, r = P / 48, cp = P - 48 * r, c = (cp & 48) | ((cp ^ r) & 15);
+                __builtin_amdgcn_global_load_lds(asrc + ((size_t)min(r, rows - 1) * 48 + c) * 16, (lds_vptr)(lds + M384_STAGE + (wave * 12 + k) * 1024), 16, 0, 0);
+            }
+        }
+        M384_WAIT_VM(0);
+        M384_BARRIER();
+        bf16x8 af[24];   // the whole attention row of the lane's token: channels 16 s + 8 half .. + 7 of k-step s
+        {
+            const char *arow = lds + M384_STAGE + mrow * 768;
+#pragma unroll
+            for (int s = 0; s < 24; s++) {
+                const int c = 2 * s + lhalf;
+                af[s] = *reinterpret_cast<const bf16x8 *>(arow + ((c & 48) | ((c ^ (int)mrow) & 15)) * 16);
+            }
+        }
+        M384_WAIT_LGKM0();
+        M384_BARRIER();               // slots 1 and 2 are free: the next two proj stages
+        dma_stage(wp + M384_STAGE, 1); dma_stage(wp + 2 * M384_STAGE, 2);
 #pragma unroll
         for (int ct = 0; ct < CT; ct++) {
             if (ct < CT - 1) M384_WAIT_VM(12); else M384_WAIT_VM(6);   // stage ct has landed (at most the two younger requests are still out)
@@ -1303,8 +1325,19 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
     const rsrc_t rsO = make_rsrc(xo ? xo + (size_t)m0 * C : nullptr, xo ? (unsigned)rows * C * 2u : 0u);
     const float *aff_row = nullptr;
     if (MOD != 0) aff_row = g.mod_aff + (size_t)(MOD == 2 ? min(m0 + (int)mrow, g.M - 1) / g.mod_T : 0) * g.mod_ld + g.mod_off;
-    __bf16 *T = reinterpret_cast<__bf16 *>(lds) + wave * 32 * TLD;
-    f32x2 *part = reinterpret_cast<f32x2 *>(xchb);   // [128 rows][2]
+    // per wave 19456 B of the (now free) ring: a 32 x 100-float tile through which the fp32 rows leave as whole-line stores (the direct
+    // "lane = row" form stores 16 bytes into each of 32 rows per instruction) and behind it the bf16 transposition tile T
+    float *xt = reinterpret_cast<float *>(lds + wave * 19456);
+    __bf16 *T = reinterpret_cast<__bf16 *>(lds + wave * 19456 + 12800);
+    f32x2 *part = reinterpret_cast<f32x2 *>(lds + 3 * M384_STAGE + 16384 - 2048);   // [128 rows][2], behind every wave's tiles
+    auto xflush = [&](int half96) {               // the wave's 32 x 96 fp32 tile -> x rows, 24 lanes per 384-byte row segment
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int i = lane + 64 * k, r = i / 24, pc = i - 24 * r;
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(xt + r * 100 + 4 * pc);
+            buf_store4(d, rsX, ((unsigned)(32 * ts + r) * C + (unsigned)(192 * kh + 96 * half96 + 4 * pc)) * 4u, 0u);
+        }
+    };
     auto tflush = [&](int half96) {               // the wave's 32 x 96 tile -> row-contiguous 16-byte stores (as gemm_bx_kernel)
 #pragma unroll
         for (int k = 0; k < 6; k++) {
@@ -1332,11 +1365,12 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) v[e] = silu_exact(fmaf(v[e], scl[e] + 1.0f, sft[e]));
             }
-            buf_store4(v, rsX, (mrow * C + (unsigned)c) * 4u, 0u);
+            *reinterpret_cast<f32x4 *>(xt + lrow * 100 + 32 * (ct % 3) + 8 * q + 4 * lhalf) = v;
 #pragma unroll
             for (int e = 0; e < 4; e++) { ssum += v[e]; ssq = fmaf(v[e], v[e], ssq); oacc[ct][4 * q + e] = v[e]; }
             if (g.out_mode == 2) *reinterpret_cast<u32x2 *>(T + lrow * TLD + 32 * (ct % 3) + 8 * q + 4 * lhalf) = pack_bf16x4(v);
         }
+        if (ct % 3 == 2) xflush(ct / 3);
         if (g.out_mode == 2 && ct % 3 == 2) tflush(ct / 3);
     }
     if (g.out_mode == 1) {
