@@ -306,8 +306,10 @@ def worker(args):
         traffic, traffic_src = None, None
         prof_root = os.path.join(ROOT, "profiles")
         # (file, kernel family, condition): the committed PMC passes exist for the headline workload and for configs[4]'s per-GPU share
+        mlp384 = "mlp384d_bx_kernel" if (bx_pipe and h.get_option("bf16_mlp") == 1) else "mlp384_bx_kernel"
         pmc_sets = [("pmc_traffic.json", "gemm4_f32_kernel", args.config == "vg" and B == 64 and mode == "f32"),
-                    ("pmc_traffic_coco_bf16.json", ("mlp384_bx_kernel", "mlp_bx_kernel") if bx_pipe else "gemm_bx_kernel",
+                    ("pmc_traffic_vg_B256.json", "gemm4_f32_kernel", args.config == "vg" and B == 256 and mode == "f32"),
+                    ("pmc_traffic_coco_bf16.json", (mlp384, "mlp_bx_kernel") if bx_pipe else "gemm_bx_kernel",
                      args.config == "coco" and B == 512 and mode == "bf16")]
         for rnd in sorted(os.listdir(prof_root), reverse=True) if os.path.isdir(prof_root) else []:
             for fname, fam, cond in pmc_sets:
@@ -321,7 +323,7 @@ def worker(args):
                         traffic_src = f"profiles/{rnd}/{fname} (committed rocprofv3 --pmc passes of this command from an earlier run of this build's kernels, not this process)"
         # peak of the pipe the dominant kernel runs on, in ALGORITHMIC (2*M*N*K) FLOP/s: the split kernel issues six bf16
         # MFMA products per algorithmic product, so its ceiling is the bf16 dense peak / 6
-        bf16_kern = ("mlp384_bx_kernel + mlp_bx_kernel (proj + MLP half of a Swin block; the class's brackets also hold the PatchEmbed and "
+        bf16_kern = ("mlp384d_bx_kernel + mlp_bx_kernel (proj + MLP half of a Swin block; the class's brackets also hold the PatchEmbed and "
                      "read-out launches, 2 of 20 on COCO)" if bx_pipe else
                      ("gemm_bx_kernel" if (mode == "bf16" and h.get_option("bf16_pipe")) else "gemm_bf16_kernel"))
         kern, peak = {"f32": ("gemm4_f32_kernel", PEAK_F32_MFMA_TFLOPS), "bf16": (bf16_kern, PEAK_BF16_MFMA_TFLOPS),

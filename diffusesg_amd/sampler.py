@@ -87,6 +87,61 @@ class NodeAdjEDMSamplerHip(object):
         return a, x
 
     @torch.no_grad()
+    def _sample_sanity_double(self, model, node_flags, init_adjs, init_nodes, gt_adjs, gt_nodes, flag_interim_adjs, max_num_interim_adjs,
+                              flag_adj_multi_channel, churn_noise, seed):
+        """The float64 known-answer run (flag_use_double=True with sanity_check_gt_*; edm.py:318-445 with the denoiser bypassed): pure
+        elementwise loop algebra on the device in torch float64 -- no network, hence no kernel of libdsg.so, is involved.  Returns
+        float64 CPU tensors like the reference."""
+        net = getattr(model, "module", model).model
+        cfg, dev = net.config, net._dev
+        B, n, T = node_flags.shape[0], cfg.max_node_num, self.num_steps
+        f = node_flags.to(device=dev).bool()
+        fa, fn = (f[:, None, :, None] & f[:, None, None, :]), f[:, :, None]
+        sa, sn = (B, cfg.c_adj, n, n), (B, n, cfg.c_node)
+        D = lambda t, shp: t.to(device=dev, dtype=torch.float64).reshape(shp)
+        ga, gn = D(gt_adjs, sa) * fa, D(gt_nodes, sn) * fn                                   # edm.py:381-382 (masked in place)
+        if init_adjs is None or init_nodes is None:                                          # gen_init_sample, edm.py:257-289
+            gen = torch.Generator(device=dev).manual_seed(int(self.seed if seed is None else seed))
+            init_adjs = torch.randn(sa, generator=gen, device=dev) * fa
+            init_nodes = torch.randn(sn, generator=gen, device=dev) * fn
+        ia, inn = D(init_adjs, sa), D(init_nodes, sn)
+        t_steps = torch.cat([self.sigma_steps.to(torch.float64), torch.zeros(1, dtype=torch.float64)])   # sigma(t) = t, t_N = 0
+        xa, xn = ia * t_steps[0], inn * t_steps[0]
+        snaps_a, snaps_n = [ia.cpu()], [inn.cpu()]
+        ts_snap = np.arange(T) if max_num_interim_adjs is None else np.linspace(0, T, max_num_interim_adjs).astype(int).clip(max=T - 1)
+        for i in range(T):
+            t_cur, t_next = float(t_steps[i]), float(t_steps[i + 1])
+            gamma = min(self.S_churn / T, np.sqrt(2) - 1) if self.S_min <= t_cur <= self.S_max else 0
+            t_hat = t_cur + gamma * t_cur
+            coef = max(t_hat ** 2 - t_cur ** 2, 0.0) ** 0.5 * self.S_noise
+            if churn_noise is not None:
+                ea, en = D(churn_noise[0][i], sa), D(churn_noise[1][i], sn)
+            else:
+                ea, en = torch.randn_like(xa), torch.randn_like(xn)
+            xha, xhn = (xa + coef * ea) * fa, (xn + coef * en) * fn                            # edm.py:356-366
+            h = t_next - t_hat
+            da, dn = ((xha - ga) / t_hat) * fa, ((xhn - gn) / t_hat) * fn                     # edm.py:384-387
+            if self.solver == "euler" or i == T - 1:
+                xa, xn = xha + h * da, xhn + h * dn                                           # edm.py:394-396
+            else:
+                t_prime = t_hat + h
+                dpa, dpn = ((xha + h * da) - ga) / t_prime, ((xhn + h * dn) - gn) / t_prime   # edm.py:414-417 (stage 2 returns the GT again)
+                xa, xn = xha + h * (0.5 * da + 0.5 * dpa), xhn + h * (0.5 * dn + 0.5 * dpn)
+            xa, xn = xa * fa, xn * fn
+            if flag_interim_adjs and i in ts_snap:
+                snaps_a.append(xa.cpu()); snaps_n.append(xn.cpu())
+        self.last_stats = {"precond_calls": 0, "net_forwards": 0, "graph_replays": 0}
+        sq_a = (lambda t: t[:, 0]) if cfg.c_adj == 1 else (lambda t: t)
+        sq_n = (lambda t: t[..., 0]) if cfg.c_node == 1 else (lambda t: t)
+        adjs, nodes = sq_a(xa.cpu()), sq_n(xn.cpu())
+        if flag_interim_adjs:
+            nodes_ls = torch.stack([sq_n(t) for t in snaps_n])
+            if flag_adj_multi_channel:
+                return adjs, nodes, [None], nodes_ls
+            return adjs, nodes, torch.stack([sq_a(t) for t in snaps_a]), nodes_ls
+        return adjs, nodes
+
+    @torch.no_grad()
     def sample(self, model, node_flags, init_adjs=None, init_nodes=None,
                sanity_check_gt_adjs=None, sanity_check_gt_nodes=None,
                flag_interim_adjs=False, max_num_interim_adjs=None, flag_use_double=False,
@@ -96,10 +151,20 @@ class NodeAdjEDMSamplerHip(object):
         `churn_noise=(adj [T,B,..], node [T,B,..])` and `coins` replay recorded randomness (parity tests);
         `seed` seeds the on-device Philox streams (default self.seed; the reference seeds torch per rank,
         arg_parser.py:293-294 -- set `sampler.seed = base_seed + rank`); `return_device=True` skips the final `.cpu()`."""
-        if flag_use_double:
-            raise NotImplementedError("flag_use_double: the HIP path computes in fp32 (the reference default)")
         if isinstance(model, (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel)):
             model = model.module
+        if flag_use_double:
+            # What the reference does with this kwarg (edm.py:320-323, :342-344, :378-380): the loop's state and time steps become float64
+            # and the denoiser's output is cast up.  With a real (fp32) network the reference FAILS in its first preconditioned call --
+            # the float64 state meets float32 weights ("mat1 and mat2 must have the same dtype, but got Double and Float"; checked by
+            # running the reference, DESIGN.md §7) -- so the only form that works there is the sanity check, where the denoiser is
+            # bypassed (edm.py:372-377).  Mirrored: the same RuntimeError without the ground truth, the float64 loop with it.
+            if sanity_check_gt_adjs is None or sanity_check_gt_nodes is None:
+                raise RuntimeError("flag_use_double=True: mat1 and mat2 must have the same dtype, but got Double and Float "
+                                   "(the reference's float64 sampler state cannot be fed to its float32 network either; "
+                                   "only the sanity-check form, which bypasses the network, runs in float64)")
+            return self._sample_sanity_double(model, node_flags, init_adjs, init_nodes, sanity_check_gt_adjs, sanity_check_gt_nodes,
+                                              flag_interim_adjs, max_num_interim_adjs, flag_adj_multi_channel, churn_noise, seed)
         if not isinstance(model, NodeAdjPrecondHip):
             raise TypeError("NodeAdjEDMSamplerHip needs the NodeAdjPrecondHip network returned by build_network()")
         net = model.model

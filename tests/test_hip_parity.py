@@ -984,8 +984,17 @@ def test_host_mirrors_reject_unsupported_reference_options():
     with pytest.raises(NotImplementedError):
         NodeAdjEDMSamplerHip(num_steps=4, dev="cuda", discretization="vp")
     flags = T(W.synth_flags(2, cfg.max_node_num, 5))
-    with pytest.raises(NotImplementedError):
+    # flag_use_double=True with a real network: the reference's float64 state meets its float32 weights and the first preconditioned
+    # call raises RuntimeError (checked by running the reference) -- mirrored
+    with pytest.raises(RuntimeError, match="same dtype"):
         make_sampler(4).sample(net, flags, flag_use_double=True, num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    # ... the one form that runs there is the float64 sanity check (edm.py:372-377): float64 result equal to the ground truth
+    gt_a, gt_n = Y.gt_case(cfg, 2, [8, 5])
+    fl2 = T(W.synth_flags(2, cfg.max_node_num, [8, 5]))
+    da, dn = make_sampler(8).sample(net, fl2, sanity_check_gt_adjs=T(gt_a), sanity_check_gt_nodes=T(gt_n), flag_use_double=True,
+                                    flag_node_multi_channel=True, flag_adj_multi_channel=True, num_node_chan=cfg.c_node, num_edge_chan=cfg.c_adj)
+    assert da.dtype == torch.float64 and dn.dtype == torch.float64 and not da.is_cuda
+    assert float((da - torch.from_numpy(gt_a)).abs().max()) < 1e-12 and float((dn - torch.from_numpy(gt_n)).abs().max()) < 1e-12
     adj = torch.zeros(2, cfg.c_adj, 8, 8, device="cuda"); node = torch.zeros(2, 8, cfg.c_node, device="cuda")
     with pytest.raises(NotImplementedError):   # [B,N,N] node flags = node-only ablation
         net.model(adj, node, torch.ones(2, 8, 8, dtype=torch.bool, device="cuda"), torch.zeros(2, device="cuda"))

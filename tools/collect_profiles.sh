@@ -27,3 +27,10 @@ cp $(ls /tmp/kt5/*/*kernel_stats.csv | head -1) $OUT/coco_B512_T20_bf16_kernel_s
 PMC_BENCH_ARGS="--config coco --batch 512 --precision bf16" PMC_RAW=pmc_traffic_raw_coco_bf16.json bash $R/tools/pmc_traffic.sh > $OUT/pmc_traffic_coco_bf16_summary.txt 2>&1
 cp $R/gpurun_out/pmc_traffic_raw_coco_bf16.json $OUT/ 2>/dev/null
 echo "coco bf16 done"
+# 5. matrix-pipe / LDS counters of the bf16 pipeline's kernels (tools/pmc_lds.sh), and configs[3]'s per-GPU share (VG B = 256) HBM traffic
+bash $R/tools/pmc_lds.sh > $OUT/pmc_lds_mfma_coco_bf16_summary.txt 2>&1
+cp $R/gpurun_out/pmc_lds_coco_bf16.json $OUT/pmc_lds_mfma_coco_bf16.json 2>/dev/null
+echo "coco bf16 counters done"
+PMC_BENCH_ARGS="--batch 256" PMC_RAW=pmc_traffic_raw_vg_B256.json bash $R/tools/pmc_traffic.sh > $OUT/pmc_traffic_vg_B256_summary.txt 2>&1
+cp $R/gpurun_out/pmc_traffic_raw_vg_B256.json $OUT/ 2>/dev/null
+echo "vg B=256 traffic done"
