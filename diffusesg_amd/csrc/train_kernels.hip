@@ -511,93 +511,143 @@ __global__ void t_modulate_bwd_final_kernel(const double *part, float *d_aff, in
 }
 
 // LayerNorm with affine: one wave per row (lanes stride over the channels: coalesced), two-pass statistics.  stats[m] = (mean, rstd)
-// One wave per row, the row read ONCE into registers (KC = ceil(C / 64) values per lane).  With aff != null the row is modulated first --
-// u = shift + x (1 + scale), x_mod = u sigmoid(u) (diffusesg.py:238-243), written to y_mod: the block's shortcut and the tensor LayerNorm-1
-// normalises -- so the modulate pass and its second trip over [M, C] are gone (round 3: t_modulate_fwd + t_ln_fwd, three reads of the row).
-template <int KC>
+// LayerNorm forward, the row read ONCE with 16-byte accesses: LPR lanes share a row (32 for C <= 128, else 64), each with KV float4s
+// (float4 index sub + LPR k), so a wave covers 64 / LPR rows and every load / store instruction moves whole 16-byte pieces along rows
+// (round 3 / early round 4: one wave per row with 4-byte accesses -- a C = 96 row kept 1.5 of 64 lanes' worth busy per load).
+// With aff != null the row is modulated first -- u = shift + x (1 + scale), x_mod = u sigmoid(u) (diffusesg.py:238-243), written to y_mod:
+// the block's shortcut and the tensor LayerNorm-1 normalises -- so the modulate pass and its second trip over [M, C] are gone.
+template <int LPR, int KV>
 __global__ __launch_bounds__(256) void t_ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ aff, float *__restrict__ y_mod,
                                                         const float *__restrict__ gam, const float *__restrict__ bet, float *__restrict__ y,
                                                         float *__restrict__ stats, int M, int C, int T) {
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (m >= M) return;
-    const float *r = x + (size_t)m * C;
-    const float *af = aff ? aff + (size_t)(m / T) * 2 * C : nullptr;
-    float v[KC], sacc = 0.f;
+    constexpr int RW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const int m = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW + lane / LPR;
+    const bool ok = m < M;
+    const int C4 = C >> 2;
+    const f32x4 *r = reinterpret_cast<const f32x4 *>(x + (size_t)(ok ? m : M - 1) * C);
+    const f32x4 *af = aff ? reinterpret_cast<const f32x4 *>(aff + (size_t)((ok ? m : M - 1) / T) * 2 * C) : nullptr;
+    f32x4 v[KV];
+    float sacc = 0.f;
 #pragma unroll
-    for (int k = 0; k < KC; k++) {
-        const int c = lane + 64 * k;
-        v[k] = 0.f;
-        if (c < C) {
-            v[k] = r[c];
-            if (af) { const float u = af[C + c] + v[k] * (af[c] + 1.0f); v[k] = u * t_sigmoid(u); y_mod[(size_t)m * C + c] = v[k]; }
-            sacc += v[k];
+    for (int k = 0; k < KV; k++) {
+        const int q = sub + LPR * k;
+        v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (q < C4) {
+            v[k] = r[q];
+            if (af) {
+                const f32x4 sc = af[q], sh = af[C4 + q];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float u = sh[e] + v[k][e] * (sc[e] + 1.0f); v[k][e] = u * t_sigmoid(u); }
+                if (ok) reinterpret_cast<f32x4 *>(y_mod + (size_t)m * C)[q] = v[k];
+            }
+            sacc += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
         }
     }
-    const float mean = wave_sum(sacc) / (float)C;
-    float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < KC; k++) if (lane + 64 * k < C) { const float d = v[k] - mean; q = fmaf(d, d, q); }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + LN_EPS);
+    for (int o = LPR / 2; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+    const float mean = sacc / (float)C;
+    float qv = 0.f;
 #pragma unroll
-    for (int k = 0; k < KC; k++) {
-        const int c = lane + 64 * k;
-        if (c < C) y[(size_t)m * C + c] = (v[k] - mean) * rstd * gam[c] + bet[c];
+    for (int k = 0; k < KV; k++)
+        if (sub + LPR * k < C4) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const float d = v[k][e] - mean; qv = fmaf(d, d, qv); }
+        }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) qv += __shfl_xor(qv, o, 64);
+    const float rstd = 1.0f / sqrtf(qv / (float)C + LN_EPS);
+    if (!ok) return;
+#pragma unroll
+    for (int k = 0; k < KV; k++) {
+        const int q = sub + LPR * k;
+        if (q < C4) {
+            const f32x4 g4 = reinterpret_cast<const f32x4 *>(gam)[q], b4 = reinterpret_cast<const f32x4 *>(bet)[q];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (v[k][e] - mean) * rstd * g4[e] + b4[e];
+            reinterpret_cast<f32x4 *>(y + (size_t)m * C)[q] = o;
+        }
     }
-    if (lane == 0) { stats[2 * (size_t)m] = mean; stats[2 * (size_t)m + 1] = rstd; }
+    if (sub == 0) { stats[2 * (size_t)m] = mean; stats[2 * (size_t)m + 1] = rstd; }
 }
 // x (+ modulate with aff [B, 2C], T tokens per sample -> y_mod) -> LayerNorm -> y, stats
 static void t_ln_fwd_launch(const float *x, const float *aff, float *y_mod, const float *gam, const float *bet, float *y, float *stats, int M, int C, int T,
                             hipStream_t s) {
-    const int kc = (C + 63) / 64;
-#define T_LNF(KC_) hipLaunchKernelGGL((t_ln_fwd_kernel<KC_>), dim3((M + 3) / 4), dim3(256), 0, s, x, aff, y_mod, gam, bet, y, stats, M, C, T)
-    if (kc <= 2) T_LNF(2); else if (kc <= 3) T_LNF(3); else if (kc <= 6) T_LNF(6); else if (kc <= 12) T_LNF(12); else if (kc <= 24) T_LNF(24);
-    else t_scratch(s).failed = true;   // rows wider than 1536 channels do not occur
+#define T_LNF(LPR_, KV_) hipLaunchKernelGGL((t_ln_fwd_kernel<LPR_, KV_>), dim3((M + 4 * (64 / LPR_) - 1) / (4 * (64 / LPR_))), dim3(256), 0, s, x, aff, y_mod, gam, bet, y, stats, M, C, T)
+    if (C % 4 != 0 || C > 1536) { t_scratch(s).failed = true; return; }   // (every width of the networks is a multiple of 96; 4 x 384 is the widest LayerNorm)
+    if (C <= 128) T_LNF(32, 1); else if (C <= 256) T_LNF(64, 1); else if (C <= 512) T_LNF(64, 2); else if (C <= 768) T_LNF(64, 3); else T_LNF(64, 6);
 #undef T_LNF
 }
 // dx_out = (dx_in ? dx_in : 0) + rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma;  d_gamma = sum_m dy xhat, d_beta = sum_m dy.
-// A block of 4 waves walks a chunk of rows (one wave per row, lanes stride over the channels); every lane keeps the two column sums of
-// its KC channels in registers (fp32 over the <= rows_per / 4 rows of its wave), the block adds its waves and writes
-// part[block][2][C] (double); t_ln_bwd_final_kernel adds the blocks in order.  (Round 2's form wrote dy xhat as a tensor and ran two
-// two-stage column-sum passes over it and dy: 5 launches and 3 more passes over [M, C] per LayerNorm.)
-template <int KC>
+// Same lane layout as the forward (LPR lanes per row, KV float4s each, 16-byte accesses).  A block of 4 waves walks a chunk of rows;
+// every lane keeps the two column sums of its 4 KV channels in registers (fp32 over the rows of its slot), the block adds its
+// 4 x (64 / LPR) slots in order and writes part[block][2][C] (double); t_ln_bwd_final_kernel adds the blocks in order.
+template <int LPR, int KV>
 __global__ __launch_bounds__(256) void t_ln_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gam, const float *__restrict__ stats,
                                                         const float *__restrict__ dy, const float *dx_in, float *dx_out, double *part, int M, int C,
                                                         int rows_per) {
-    __shared__ float red[4][2][KC * 64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int RW = 64 / LPR, SLOTS = 4 * RW, CP = LPR * KV * 4;   // CP: padded channel count
+    __shared__ float red[SLOTS][2][CP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sub = lane % LPR, slot = wave * RW + lane / LPR;
     const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
-    float ag[KC], ab[KC], gm[KC];
+    const int C4 = C >> 2;
+    f32x4 ag[KV], ab[KV], gm[KV];
 #pragma unroll
-    for (int k = 0; k < KC; k++) { ag[k] = 0.f; ab[k] = 0.f; gm[k] = (lane + 64 * k < C) ? gam[lane + 64 * k] : 0.f; }
-    for (int m = r0 + wave; m < r1; m += 4) {
-        const float mean = stats[2 * (size_t)m], rstd = stats[2 * (size_t)m + 1];
-        const float *r = x + (size_t)m * C, *d = dy + (size_t)m * C;
-        float xh[KC], gg[KC], sg = 0.f, sgx = 0.f;
+    for (int k = 0; k < KV; k++) {
+        ag[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; ab[k] = ag[k];
+        gm[k] = (sub + LPR * k < C4) ? reinterpret_cast<const f32x4 *>(gam)[sub + LPR * k] : ag[k];
+    }
+    for (int mb = r0; mb < r1; mb += SLOTS) {     // every lane takes part in the shuffles: rows beyond r1 run with zero weight
+        const int m = mb + slot;
+        const bool ok = m < r1;
+        const size_t mc = (size_t)(ok ? m : r1 - 1);
+        const float mean = stats[2 * mc], rstd = stats[2 * mc + 1];
+        const f32x4 *r = reinterpret_cast<const f32x4 *>(x + mc * C), *d = reinterpret_cast<const f32x4 *>(dy + mc * C);
+        f32x4 xh[KV], gg[KV];
+        float sg = 0.f, sgx = 0.f;
 #pragma unroll
-        for (int k = 0; k < KC; k++) {
-            const int c = lane + 64 * k;
-            xh[k] = 0.f; gg[k] = 0.f;
-            if (c < C) {
-                const float dv = d[c];
-                xh[k] = (r[c] - mean) * rstd; gg[k] = dv * gm[k];
-                sg += gg[k]; sgx = fmaf(gg[k], xh[k], sgx);
-                ag[k] = fmaf(dv, xh[k], ag[k]); ab[k] += dv;
+        for (int k = 0; k < KV; k++) {
+            const int q = sub + LPR * k;
+            xh[k] = (f32x4){0.f, 0.f, 0.f, 0.f}; gg[k] = xh[k];
+            if (q < C4) {
+                const f32x4 dv = d[q], xv = r[q];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    xh[k][e] = (xv[e] - mean) * rstd; gg[k][e] = dv[e] * gm[k][e];
+                    sg += gg[k][e]; sgx = fmaf(gg[k][e], xh[k][e], sgx);
+                    if (ok) { ag[k][e] = fmaf(dv[e], xh[k][e], ag[k][e]); ab[k][e] += dv[e]; }
+                }
             }
         }
-        const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
 #pragma unroll
-        for (int k = 0; k < KC; k++) {
-            const int c = lane + 64 * k;
-            if (c < C) dx_out[(size_t)m * C + c] = (dx_in ? dx_in[(size_t)m * C + c] : 0.f) + rstd * (gg[k] - mg - xh[k] * mgx);
+        for (int o = LPR / 2; o > 0; o >>= 1) { sg += __shfl_xor(sg, o, 64); sgx += __shfl_xor(sgx, o, 64); }
+        const float mg = sg / (float)C, mgx = sgx / (float)C;
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < KV; k++) {
+                const int q = sub + LPR * k;
+                if (q < C4) {
+                    f32x4 o4 = dx_in ? reinterpret_cast<const f32x4 *>(dx_in + mc * C)[q] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) o4[e] += rstd * (gg[k][e] - mg - xh[k][e] * mgx);
+                    reinterpret_cast<f32x4 *>(dx_out + mc * C)[q] = o4;
+                }
+            }
         }
     }
 #pragma unroll
-    for (int k = 0; k < KC; k++) { red[wave][0][lane + 64 * k] = ag[k]; red[wave][1][lane + 64 * k] = ab[k]; }
+    for (int k = 0; k < KV; k++) {
+        *reinterpret_cast<f32x4 *>(&red[slot][0][4 * (sub + LPR * k)]) = ag[k];
+        *reinterpret_cast<f32x4 *>(&red[slot][1][4 * (sub + LPR * k)]) = ab[k];
+    }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
         double *p = part + (size_t)blockIdx.x * 2 * C;
-        p[c] = ((double)red[0][0][c] + (double)red[1][0][c]) + ((double)red[2][0][c] + (double)red[3][0][c]);
-        p[C + c] = ((double)red[0][1][c] + (double)red[1][1][c]) + ((double)red[2][1][c] + (double)red[3][1][c]);
+        double a0 = 0.0, b0 = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; sl++) { a0 += (double)red[sl][0][c]; b0 += (double)red[sl][1][c]; }
+        p[c] = a0; p[C + c] = b0;
     }
 }
 // (d_gamma | d_beta)[c] = sum over the R block partials, in a fixed order: block = 4 columns x 64 row lanes (lane q adds partials
@@ -1120,10 +1170,9 @@ void t_ln_bwd(const float *x, const float *gam, const float *stats, const float 
     TScratch &ts = t_scratch(s);
     double *part = t_scratch_get(s, ts.cs, ts.cs_cap, (size_t)blocks * 2 * C, ts);
     if (!part) return;   // (the stream's scratch is marked failed)
-    const int kc = (C + 63) / 64;
-#define T_LNB(KC_) hipLaunchKernelGGL((t_ln_bwd_kernel<KC_>), dim3(blocks), dim3(256), 0, s, x, gam, stats, dy, dx_in, dx_out, part, M, C, rows_per)
-    if (kc <= 2) T_LNB(2); else if (kc <= 3) T_LNB(3); else if (kc <= 6) T_LNB(6); else if (kc <= 12) T_LNB(12); else if (kc <= 24) T_LNB(24);
-    else { ts.failed = true; return; }   // rows wider than 1536 channels do not occur (4 x 384 is the widest LayerNorm of the networks)
+#define T_LNB(LPR_, KV_) hipLaunchKernelGGL((t_ln_bwd_kernel<LPR_, KV_>), dim3(blocks), dim3(256), 0, s, x, gam, stats, dy, dx_in, dx_out, part, M, C, rows_per)
+    if (C % 4 != 0 || C > 1536) { ts.failed = true; return; }   // (4 x 384 is the widest LayerNorm of the networks)
+    if (C <= 128) T_LNB(32, 1); else if (C <= 256) T_LNB(64, 1); else if (C <= 512) T_LNB(64, 2); else if (C <= 768) T_LNB(64, 3); else T_LNB(64, 6);
 #undef T_LNB
     hipLaunchKernelGGL(t_ln_bwd_final_kernel, dim3((2 * C + 3) / 4), dim3(256), 0, s, part, d_gamma, d_beta, C, blocks);
 }
