@@ -143,6 +143,7 @@ struct dsg_handle_s {
     int opt_bf16_mlp = 1;                                         // in that pipeline: the fused fc1-GELU-fc2 kernels (0: two GEMMs with a bf16 hidden tensor; 1: C <= 192 on 4 waves, C = 384 on 8; 2: C = 384 on the 4-wave kernel too; 3: GEMM pair at C = 384)
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
+    std::map<const float *, void *> w_img2;                       // the same weights chunk-major for mlp384s_bx_kernel (bf16_mlp = 5)
     std::map<const float *, void *> w_img;                        // per C = 384 block (key: its fc1_wf): W1 | W2 | Wp pre-arranged for mlp384d_bx_kernel's LDS-DMA ring
     bool opt_gemm_split = false;                                  // split-bf16 GEMMs (3 planes, 6 products): fp32-accurate, opt-in
     std::map<const float *, void *> w_split;                      // [3][N][K] bf16 planes
@@ -518,6 +519,9 @@ int ensure_bf16_weights(dsg_handle h) {
                     HIP_TRY(h, hipMalloc(&q, mlp384_image_bytes()));
                     launch_mlp384_images(h->w_bf16[b.fc1_wf], h->w_bf16[w2], h->w_bf16[wp], q, nullptr);
                     h->w_img[b.fc1_wf] = q;
+                    HIP_TRY(h, hipMalloc(&q, mlp384_image_bytes()));
+                    launch_mlp384s_images(h->w_bf16[b.fc1_wf], h->w_bf16[w2], h->w_bf16[wp], q, nullptr);
+                    h->w_img2[b.fc1_wf] = q;
                 }
     HIP_TRY(h, hipDeviceSynchronize());
     return 0;
@@ -525,6 +529,10 @@ int ensure_bf16_weights(dsg_handle h) {
 const void *img_of(dsg_handle h, const float *fc1_wf) {
     auto it = h->w_img.find(fc1_wf);
     return it == h->w_img.end() ? nullptr : it->second;
+}
+const void *img2_of(dsg_handle h, const float *fc1_wf) {
+    auto it = h->w_img2.find(fc1_wf);
+    return it == h->w_img2.end() ? nullptr : it->second;
 }
 
 const void *split_of(dsg_handle h, const float *W) {
@@ -610,6 +618,7 @@ void dsg_destroy(dsg_handle h) {
     for (auto &kv : h->w) (void)hipFree(kv.second.p);
     for (auto &kv : h->w_bf16) (void)hipFree(kv.second);
     for (auto &kv : h->w_img) (void)hipFree(kv.second);
+    for (auto &kv : h->w_img2) (void)hipFree(kv.second);
     for (auto &kv : h->w_split) (void)hipFree(kv.second);
     for (void *p : h->derived_allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -838,6 +847,8 @@ int dsg_finalize_weights(dsg_handle h) {
     h->w_bf16.clear();
     for (auto &kv : h->w_img) (void)hipFree(kv.second);
     h->w_img.clear();
+    for (auto &kv : h->w_img2) (void)hipFree(kv.second);
+    h->w_img2.clear();
     for (auto &kv : h->w_split) (void)hipFree(kv.second);
     h->w_split.clear();
     h->gemm_weights.clear();
@@ -1227,7 +1238,7 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
     }
     // the fused MLP kernel can take the proj linear, the residual and LayerNorm-2 in front (x + proj(att) never goes to HBM)
     const bool mlp_fused = h->opt_bf16_mlp && h->cfg.mlp_ratio == 4 && (C == 96 || C == 192 || (C == 384 && h->opt_bf16_mlp != 3));
-    const bool proj_in_mlp = mlp_fused && h->opt_bf16_proj_mlp && h->taps.empty() && (C == 96 || C == 192 || (C == 384 && (h->opt_bf16_mlp == 1 || h->opt_bf16_mlp == 4)));
+    const bool proj_in_mlp = mlp_fused && h->opt_bf16_proj_mlp && h->taps.empty() && (C == 96 || C == 192 || (C == 384 && (h->opt_bf16_mlp == 1 || h->opt_bf16_mlp == 4 || h->opt_bf16_mlp == 5)));
     const bool full = bx_full_row(C);
     if (!proj_in_mlp) {
         g = BxGemm();
@@ -1245,8 +1256,9 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
     if (mlp_fused) {
         BxMlp m;
         // C = 384: 1 -> the LDS-DMA kernel on pre-arranged weight images (round 4), 4 -> round 3's eight-wave kernel, 2 -> the four-wave one
-        m.wide8 = h->opt_bf16_mlp == 2 ? 0 : (h->opt_bf16_mlp == 4 ? 2 : 1);
+        m.wide8 = h->opt_bf16_mlp == 2 ? 0 : (h->opt_bf16_mlp == 4 ? 2 : (h->opt_bf16_mlp == 5 ? 3 : 1));
         m.img = C == 384 ? img_of(h, b.fc1_wf) : nullptr;
+        m.img2 = C == 384 ? img2_of(h, b.fc1_wf) : nullptr;
         if (proj_in_mlp) { m.att = w->att; m.Wp = bf16_of(h, WT(h, p + ".attn.proj.weight")); m.bp = WT(h, p + ".attn.proj.bias"); }
         m.xn = w->xn; m.x = w->x; m.W1 = bf16_of(h, b.fc1_wf); m.b1 = b.fc1_bf;
         m.W2 = bf16_of(h, WT(h, p + ".mlp.fc2.weight")); m.b2 = WT(h, p + ".mlp.fc2.bias"); m.M = M; m.C = C;
@@ -1663,7 +1675,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "loop_graph") h->opt_loop_graph = value != 0;
     else if (n == "bf16_act") h->opt_bf16_act = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "bf16_pipe") h->opt_bf16_pipe = value != 0;
-    else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 4 ? 4 : value);
+    else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 5 ? 5 : value);
     else if (n == "bf16_qkv_attn") h->opt_bf16_qkv_attn = value != 0;
     else if (n == "bf16_proj_mlp") h->opt_bf16_proj_mlp = value != 0;
     else if (n == "bf16_readout") h->opt_bf16_readout = value != 0;
@@ -2077,6 +2089,7 @@ int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const floa
                      const float *mod, int32_t out_mode, float *out_xn, int32_t time_iters, float *out_ms, void *stream) {
     const int narrow384 = (out_mode >> 4) & 1;   // + 16: C = 384 on the one-wave-per-SIMD kernel instead of the eight-wave ones
     const int old384 = (out_mode >> 5) & 1;      // + 32: C = 384 on round 3's eight-wave kernel (register-staged weights) instead of the LDS-DMA one
+    const int solo384 = (out_mode >> 6) & 1;     // + 64: C = 384 on mlp384s_bx_kernel (four waves, chunk-major LDS-DMA ring)
     out_mode &= 15;
     if (M < 1 || !xn || !x || !W1 || !b1 || !W2 || !b2 || (out_mode && !out_xn)) return DSG_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -2090,11 +2103,11 @@ int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const floa
     BxMlp g;
     g.xn = xb; g.x = x; g.W1 = w1b; g.b1 = b1; g.W2 = w2b; g.b2 = b2; g.M = M; g.C = C;
     if (out_mode) { g.xn_out = ob; g.out_mode = out_mode; }
-    g.wide8 = narrow384 ? 0 : (old384 ? 2 : 1);
-    if (C == 384 && g.wide8 == 1) {
+    g.wide8 = narrow384 ? 0 : (old384 ? 2 : (solo384 ? 3 : 1));
+    if (C == 384 && (g.wide8 == 1 || g.wide8 == 3)) {
         if (hipMalloc(&imgb, mlp384_image_bytes()) != hipSuccess) { cleanup(); return DSG_ERR_HIP; }
-        launch_mlp384_images(w1b, w2b, nullptr, imgb, s);
-        g.img = imgb;
+        if (g.wide8 == 1) { launch_mlp384_images(w1b, w2b, nullptr, imgb, s); g.img = imgb; }
+        else { launch_mlp384s_images(w1b, w2b, nullptr, imgb, s); g.img2 = imgb; }
     }
     if (mod) { g.mod_aff = mod; g.mod_ld = 0; g.mod_off = 0; g.mod_T = 1; }
     const bool ok = launch_mlp_bx(g, s);
@@ -2110,6 +2123,7 @@ int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const
                          const float *W2, const float *b2, const float *mod, int32_t out_mode, float *out_xn, int32_t time_iters, float *out_ms,
                          void *stream) {
     const int old384 = (out_mode >> 5) & 1;      // + 32: C = 384 on round 3's eight-wave kernel instead of the LDS-DMA one
+    const int solo384 = (out_mode >> 6) & 1;     // + 64: C = 384 on mlp384s_bx_kernel
     out_mode &= 15;
     if (M < 1 || !att || !x || !Wp || !bp || !W1 || !b1 || !W2 || !b2 || (out_mode && !out_xn)) return DSG_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -2124,11 +2138,11 @@ int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const
     BxMlp g;
     g.att = ab; g.Wp = wpb; g.bp = bp; g.x = x; g.W1 = w1b; g.b1 = b1; g.W2 = w2b; g.b2 = b2; g.M = M; g.C = C;
     if (out_mode) { g.xn_out = ob; g.out_mode = out_mode; }
-    g.wide8 = old384 ? 2 : 1;
-    if (C == 384 && g.wide8 == 1) {
+    g.wide8 = old384 ? 2 : (solo384 ? 3 : 1);
+    if (C == 384 && (g.wide8 == 1 || g.wide8 == 3)) {
         if (hipMalloc(&imgb, mlp384_image_bytes()) != hipSuccess) { cleanup(); return DSG_ERR_HIP; }
-        launch_mlp384_images(w1b, w2b, wpb, imgb, s);
-        g.img = imgb;
+        if (g.wide8 == 1) { launch_mlp384_images(w1b, w2b, wpb, imgb, s); g.img = imgb; }
+        else { launch_mlp384s_images(w1b, w2b, wpb, imgb, s); g.img2 = imgb; }
     }
     if (mod) { g.mod_aff = mod; g.mod_ld = 0; g.mod_off = 0; g.mod_T = 1; }
     const bool ok = launch_mlp_bx(g, s);
@@ -2158,6 +2172,32 @@ int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const
             for (int tm = 0; tm < 2; tm++)
                 fprintf(stderr, "      pair 8, %s half (clk): fc1 %.0f | wait + barrier %.0f | GELU + exchange %.0f | wait + barrier %.0f | fc2 %.0f | wait + barrier %.0f\n",
                         tm ? "second" : "first", iv[tm][0] / (n / 2), iv[tm][1] / (n / 2), iv[tm][2] / (n / 2), iv[tm][3] / (n / 2), iv[tm][4] / (n / 2), iv[tm][5] / (n / 2));
+            (void)hipFree(dbg);
+            g.dbg = nullptr;
+        }
+    }
+    if (ok && C == 384 && g.wide8 == 3 && getenv("DSG_M384_CLK")) {   // dev measurement: phase clocks of one more launch of mlp384s_bx_kernel
+        const int nb = (M + 127) / 128;
+        unsigned long long *dbg = nullptr;
+        if (hipMalloc((void **)&dbg, sizeof(unsigned long long) * nb * 128) == hipSuccess) {
+            (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * nb * 128, s);
+            g.dbg = dbg;
+            (void)launch_mlp_bx(g, s);
+            std::vector<unsigned long long> hb((size_t)nb * 128);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(hb.data(), dbg, sizeof(unsigned long long) * hb.size(), hipMemcpyDeviceToHost);
+            double ph[4] = {0, 0, 0, 0}, tot = 0, iv[3] = {0, 0, 0};
+            for (int b = 0; b < nb; b++)
+                for (int w = 0; w < 4; w++) {
+                    const unsigned long long *t = hb.data() + ((size_t)b * 8 + w) * 16;
+                    for (int k = 0; k < 4; k++) ph[k] += (double)(t[k + 1] - t[k]);
+                    tot += (double)(t[4] - t[0]);
+                    for (int k = 0; k < 3; k++) iv[k] += (double)(t[6 + k] - t[5 + k]);
+                }
+            const double n = (double)nb * 4;
+            fprintf(stderr, "   mlp384s phases (kclk per wave, mean of %d blocks): prologue %.1f | wait %.1f | chunk loop %.1f | epilogue %.1f | block %.1f\n",
+                    nb, ph[0] / n / 1e3, ph[1] / n / 1e3, ph[2] / n / 1e3, ph[3] / n / 1e3, tot / n / 1e3);
+            fprintf(stderr, "      chunk 8 (clk): wait + barrier %.0f | fc1(c+1) + GELU(c) %.0f | fc2(c) %.0f\n", iv[0] / n, iv[1] / n, iv[2] / n);
             (void)hipFree(dbg);
             g.dbg = nullptr;
         }

@@ -1075,9 +1075,13 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
     auto dma_stage = [&](const char *src, int r) {      // src, r: wave-uniform -> scalar base + one 32-bit lane offset
         const char *sbase = src + wave * 6144;
         char *dbase = lds + r * M384_STAGE + wave * 6144;
+        // (inline assembly, not __builtin_amdgcn_global_load_lds: the compiler's wait-count pass books the builtin as a FLAT access that may
+        // touch LDS and memory, and while one is pending every s_waitcnt it inserts -- the fragment reads' lgkmcnt, ordinary loads' vmcnt --
+        // becomes a full drain.  M0 = the LDS address, one wait state between its write and the request.)
+        const unsigned dlds = (unsigned)(size_t)dbase;
 #pragma unroll
         for (int i = 0; i < 6; i++)
-            __builtin_amdgcn_global_load_lds(sbase + i * 1024 + dma_voff, (lds_vptr)(dbase + i * 1024), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dlds + i * 1024), "v"(dma_voff), "s"(sbase + i * 1024) : "memory", "m0");
     };
     // the normalised row of the lane's token as fc1's B operand, k-step s = channels 16 s + 4 half + {0..3, 8..11}: xo = the k-steps
     // 12 kh .. + 11 (the channels this wave's proj / fc2 half owns), xp = the partner's 12 (fc1 walks own, then partner's: the order
@@ -1108,7 +1112,8 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
 #pragma unroll
             for (int k = 0; k < 12; k++) {
                 const int P = (wave * 12 + k) * 64 + lane, r = P / 48, cp = P - 48 * r, c = (cp & 48) | ((cp ^ r) & 15);
-                __builtin_amdgcn_global_load_lds(asrc + ((size_t)min(r, rows - 1) * 48 + c) * 16, (lds_vptr)(lds + M384_STAGE + (wave * 12 + k) * 1024), 16, 0, 0);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"((unsigned)(size_t)lds + M384_STAGE + (wave * 12 + k) * 1024),
+                             "v"(asrc + ((size_t)min(r, rows - 1) * 48 + c) * 16) : "memory", "m0");
             }
         }
         M384_WAIT_VM(0);
@@ -1398,6 +1403,337 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
 #undef M384_STAMP
 }
 
+// -------------------------------------------------------------------------------------------------
+// mlp384s_bx_kernel -- the same fused (proj +) MLP on FOUR waves, one per SIMD, each with the whole 512-entry register file.
+// What mlp384d's clocks showed (profiles/r4/m384_experiments.txt): at two waves per SIMD a matrix interval loses a third to a half of
+// its time to the partner's VALU stream, and the pair structure costs an LDS exchange and three all-wave barriers per 64 hidden units.
+// Here a wave owns 32 tokens COMPLETELY -- all 384 output channels (192 accumulator registers), the whole normalised row (96) -- so
+// nothing crosses between waves but the weight ring, and the overlap of GELU with matrix work is a software pipeline INSIDE the wave:
+// while the 24 MFMAs of fc1(c + 1) run, the VALU instructions of GELU(c) issue in their shadows (an MFMA holds the SIMD's issue for 8 of
+// its 32 cycles), then the 24 MFMAs of fc2(c).  A ring stage is ONE chunk of 32 hidden units, [W1 rows | W2 columns] = 48 KB, in the
+// piece order the fragment reads want (launch_mlp384s_images); twelve LDS-DMA pieces per wave and chunk go out between the MFMAs, one
+// barrier per chunk.  b1 sits in LDS and is the fc1 accumulator's initial value.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlp384s_img_kernel(const unsigned short *__restrict__ W1, const unsigned short *__restrict__ W2,
+                                                          const unsigned short *__restrict__ Wp, unsigned short *__restrict__ img) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int n1 = 48 * 3072, np = 6 * 3072;
+    if (idx >= n1 + (Wp ? np : 0)) return;
+    unsigned short v[8];
+    if (idx < n1) {
+        const int c = idx / 3072, P = idx % 3072;
+        if (P < 1536) {     // W1 rows 32 c .. + 31: piece (s, g, r)
+            const int r = P % 32, sg = P / 32, s = sg >> 1, g = sg & 1;
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = W1[(size_t)(32 * c + r) * 384 + 16 * s + 4 * g + (j & 3) + 8 * (j >> 2)];
+        } else {            // W2 columns 32 c .. + 31: piece (ct, s2, g, row)
+            const int Q = P - 1536, row = Q % 32, q = Q / 32, g = q & 1, s2 = (q >> 1) & 1, ct = q >> 2;
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = W2[(size_t)(32 * ct + row) * 1536 + 32 * c + 16 * s2 + 4 * g + (j & 3) + 8 * (j >> 2)];
+        }
+    } else {                // proj stage st: rows 64 st .. + 63, natural K order
+        const int i3 = idx - n1, st = i3 / 3072, P = i3 % 3072, r = P % 64, sg = P / 64, s = sg >> 1, g = sg & 1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = Wp[(size_t)(64 * st + r) * 384 + 16 * s + 8 * g + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) img[(size_t)idx * 8 + j] = v[j];
+}
+void launch_mlp384s_images(const void *W1b, const void *W2b, const void *Wpb, void *img, hipStream_t s) {
+    const int n = 48 * 3072 + (Wpb ? 6 * 3072 : 0);
+    DSG_LAUNCH(mlp384s_img_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned short *)W1b, (const unsigned short *)W2b,
+               (const unsigned short *)Wpb, (unsigned short *)img);
+}
+
+template <int MOD, bool PROJ = false>
+__global__ __launch_bounds__(256, 1) void mlp384s_bx_kernel(BxMlp g) {
+    constexpr int C = 384, NCH = 48, CT = 12, TLD = 104;
+    __shared__ __attribute__((aligned(16))) char lds[3 * M384_STAGE + 16384];
+    float *b1s = reinterpret_cast<float *>(lds + 3 * M384_STAGE);   // [1536]
+    const int tid = threadIdx.x, lane = tid & 63, lrow = lane & 31, lhalf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * 128;
+    const int rows = min(128, g.M - m0);
+    const unsigned mrow = (unsigned)(32 * wave + lrow);
+    const char *img = static_cast<const char *>(g.img2);
+    const char *chunks = img, *wp = img + (size_t)NCH * M384_STAGE;
+    unsigned long long *dbg = g.dbg ? g.dbg + ((size_t)blockIdx.x * 8 + wave) * 16 : nullptr;
+#define M384_STAMP(i) do { if (dbg && lane == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    M384_STAMP(0);
+    const unsigned dma_voff = (unsigned)lane * 16u;
+    // The LDS-DMA requests are written as inline assembly: the compiler's wait-count pass treats the builtin as a FLAT access that may touch
+    // both LDS and memory, and while one is pending it turns every lgkmcnt / vmcnt wait into a full drain (the fragment reads four ahead
+    // then stall every fourth MFMA).  M0 carries the LDS address (wave-uniform), one wait state between its write and the request.
+    const unsigned lds0 = (unsigned)(size_t)lds;
+    auto glds_s = [&](const char *sbase, unsigned voff, unsigned ldsaddr) {        // uniform base + per-lane 32-bit offset
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory", "m0");
+    };
+    auto glds_v = [&](const char *vptr, unsigned ldsaddr) {                        // per-lane address
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(ldsaddr), "v"(vptr) : "memory", "m0");
+    };
+    auto dma_piece = [&](const char *src, int slot, int i) {   // piece i (0 .. 11) of this wave's share of a stage
+        glds_s(src + wave * 12288 + i * 1024, dma_voff, lds0 + slot * M384_STAGE + wave * 12288 + i * 1024);
+    };
+    auto dma_stage = [&](const char *src, int slot) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) dma_piece(src, slot, i);
+    };
+    for (int i = tid; i < 1536; i += 256) b1s[i] = g.b1[i];
+    bf16x8 xf[24];
+    f32x16 oacc[CT];
+    if (PROJ) {
+        const rsrc_t rsXi = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 rr = buf_load4(rsXi, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.bp + 32 * ct + 8 * q + 4 * lhalf);
+#pragma unroll
+                for (int e = 0; e < 4; e++) oacc[ct][4 * q + e] = rr[e] + b4[e];
+            }
+        dma_stage(wp, 0);
+        {   // the block's 128 attention rows by swizzled LDS-DMA into slots 1 + 2 (see mlp384d_bx_kernel)
+            const char *asrc = reinterpret_cast<const char *>(static_cast<const __bf16 *>(g.att) + (size_t)m0 * C);
+#pragma unroll
+            for (int k = 0; k < 24; k++) {
+                const int P = (wave * 24 + k) * 64 + lane, r = P / 48, cp = P - 48 * r, c = (cp & 48) | ((cp ^ r) & 15);
+                glds_v(asrc + ((size_t)min(r, rows - 1) * 48 + c) * 16, lds0 + M384_STAGE + (wave * 24 + k) * 1024);
+            }
+        }
+        M384_WAIT_VM(0);
+        M384_BARRIER();
+        bf16x8 af[24];
+        {
+            const char *arow = lds + M384_STAGE + mrow * 768;
+#pragma unroll
+            for (int s = 0; s < 24; s++) {
+                const int c = 2 * s + lhalf;
+                af[s] = *reinterpret_cast<const bf16x8 *>(arow + ((c & 48) | ((c ^ (int)mrow) & 15)) * 16);
+            }
+        }
+        M384_WAIT_LGKM0();
+        M384_BARRIER();
+        dma_stage(wp + M384_STAGE, 1); dma_stage(wp + 2 * M384_STAGE, 2);
+#pragma unroll
+        for (int st = 0; st < 6; st++) {
+            if (st < 5) M384_WAIT_VM(24); else M384_WAIT_VM(12);
+            M384_BARRIER();
+            const char *a = lds + (st % 3) * M384_STAGE + lhalf * 1024 + lrow * 16;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int s = 0; s < 24; s++)
+                    oacc[2 * st + t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(a + t * 512 + s * 2048), af[s], oacc[2 * st + t], 0, 0, 0);
+            M384_WAIT_LGKM0();
+            M384_BARRIER();
+            if (st + 3 < 6) dma_stage(wp + (st + 3) * M384_STAGE, st % 3);
+            else if (st < 5) dma_stage(chunks + (size_t)(st - 3) * M384_STAGE, st - 3);     // chunk stages 0, 1 -> slots 0, 1 (chunk 2 goes out in iteration 0)
+        }
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { const float v = oacc[ct][r]; sm += v; sq = fmaf(v, v, sq); }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        const float mean = sm * (1.0f / C), rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * (1.0f / C)), 0.f) + LN_EPS), nmr = -mean * rstd;
+#pragma unroll
+        for (int s = 0; s < 24; s++) {
+            u32x4 pk;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                pk[j] = pack_bf16(fmaf(oacc[s >> 1][8 * (s & 1) + 2 * j], rstd, nmr), fmaf(oacc[s >> 1][8 * (s & 1) + 2 * j + 1], rstd, nmr));
+            xf[s] = __builtin_bit_cast(bf16x8, pk);
+        }
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
+        dma_stage(chunks, 0); dma_stage(chunks + M384_STAGE, 1);
+        const rsrc_t rsXn = make_rsrc(static_cast<const __bf16 *>(g.xn) + (size_t)m0 * C, (unsigned)rows * C * 2u);
+#pragma unroll
+        for (int s = 0; s < 24; s++) {
+            const unsigned ch = 16u * s + 4u * lhalf;
+            const u32x2 lo = __builtin_amdgcn_raw_buffer_load_b64(rsXn, (mrow * C + ch) * 2u, 0u, 0);
+            const u32x2 hi = __builtin_amdgcn_raw_buffer_load_b64(rsXn, (mrow * C + ch + 8u) * 2u, 0u, 0);
+            xf[s] = __builtin_bit_cast(bf16x8, (u32x4){lo[0], lo[1], hi[0], hi[1]});
+        }
+    }
+    M384_STAMP(1);
+    M384_WAIT_VM(0);
+    M384_WAIT_LGKM0();
+    M384_BARRIER();                       // chunk stages 0, 1 and b1 are in LDS
+    M384_STAMP(2);
+    const int w1off = lhalf * 512 + lrow * 16;            // W1 piece (s, g, r): + 1024 s
+    const int w2off = 24576 + lane * 16;                  // W2 piece block (ct, s2): + 1024 (2 ct + s2)
+    const float *b1l = b1s + 4 * lhalf;                   // hidden unit of h[4 q + e]: 8 q + 4 half + e
+    auto b1_init = [&](int c) {
+        f32x16 h;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(b1l + 32 * c + 8 * q);
+            h[4 * q] = b4[0]; h[4 * q + 1] = b4[1]; h[4 * q + 2] = b4[2]; h[4 * q + 3] = b4[3];
+        }
+        return h;
+    };
+    f32x16 h = b1_init(0);
+    {
+        const char *a = lds + w1off;
+#pragma unroll
+        for (int s = 0; s < 24; s++) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(a + s * 1024), xf[s], h, 0, 0, 0);
+    }
+    int slot = 0;                          // ring slot of chunk c
+    for (int c = 0; c < NCH; c++) {
+        const int slot_n = slot == 2 ? 0 : slot + 1, slot_r = slot == 0 ? 2 : slot - 1;   // slots of chunk c + 1 and of chunk c + 2 (= c - 1's)
+        if (c == 8) M384_STAMP(5);
+        if (c >= 1) {                      // every wave has finished chunk c - 1: its slot takes chunk c + 2; chunk c + 1 has landed
+            M384_WAIT_VM(0);
+            M384_WAIT_LGKM0();
+            M384_BARRIER();
+        }
+        if (c == 8) M384_STAMP(6);
+        // (unconditional, so that the half stays one basic block for the scheduler: the last iterations re-fetch chunk 47 into a finished slot)
+        const char *rsrc_stage = chunks + (size_t)min(c + 2, NCH - 1) * M384_STAGE;
+        // ---- the chunk's instruction stream is laid out BY HAND: one segment per MFMA -- the MFMA, the fragment read four ahead, a share
+        // of the GELU arithmetic (which issues in the MFMA's shadow: 32 matrix cycles leave room for seven VALU instructions), every
+        // other time one LDS-DMA piece -- and a sched_barrier(0) after each so that the compiler keeps the segments in this order
+        // (sched_group_barrier pipelines with VALU groups were dropped by the solver on this block).
+        // GELU(c): values 0 .. 11 behind fc1(c + 1)'s MFMAs (one value per two), values 12 .. 15 behind the first twelve MFMAs of fc2(c),
+        // which run s2 = 0 (hidden units 0 .. 15 = hf[0]) first.
+        u32x4 hf[2];
+        float gt[16];
+        auto gelu_a = [&](int v) {             // exponent argument of value v
+            if (DSG_M384_EXP == 3) { gt[v] = h[v]; return; }
+            const float a = fminf(fabsf(h[v]), 6.0f);
+            float pp = fmaf(a, 3.3159643839e-05f, -7.6972447974e-04f);
+            pp = fmaf(a, pp, 8.0821445939e-03f);
+            pp = fmaf(a, pp, -5.3413999628e-02f);
+            pp = fmaf(a, pp, -4.5876976689e-01f);
+            pp = fmaf(a, pp, -1.1512020345f);
+            gt[v] = fmaf(a, pp, -9.9999303260e-01f);
+        };
+        auto gelu_b = [&](int v) {             // value v done; packed with its neighbour when the odd one is
+            if (DSG_M384_EXP == 3) { if (v & 1) hf[v >> 3][(v >> 1) & 3] = pack_bf16(gt[v - 1], gt[v]); return; }
+            gt[v] = fmaf(-fabsf(h[v]), __builtin_amdgcn_exp2f(gt[v]), fmaxf(h[v], 0.0f));
+            if (v & 1) hf[v >> 3][(v >> 1) & 3] = pack_bf16(gt[v - 1], gt[v]);
+        };
+        f32x16 hn = h;
+        if (c + 1 < NCH) {
+            hn = b1_init(c + 1);
+            const char *a = lds + slot_n * M384_STAGE + w1off;
+            bf16x8 fr[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) fr[s] = *reinterpret_cast<const bf16x8 *>(a + s * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 24; s++) {
+                if (DSG_M384_EXP != 2) hn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s & 3], xf[s], hn, 0, 0, 0);
+                if (s + 4 < 24 && DSG_M384_EXP != 5) fr[s & 3] = *reinterpret_cast<const bf16x8 *>(a + (s + 4) * 1024);
+                if (s & 1) { gelu_b(s >> 1); if (DSG_M384_EXP != 1) dma_piece(rsrc_stage, slot_r, s >> 1); }
+                else gelu_a(s >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 12; v++) { gelu_a(v); gelu_b(v); }
+        }
+        if (c == 8) M384_STAMP(7);
+        // ---- fc2 of chunk c on all 384 output channels, s2-major
+        {
+            const char *a = lds + slot * M384_STAGE + w2off;
+            bf16x8 fr[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) fr[i] = *reinterpret_cast<const bf16x8 *>(a + 2 * i * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 24; i++) {
+                const int ct = i % 12, s2 = i / 12;
+                if (DSG_M384_EXP != 2) oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 3], __builtin_bit_cast(bf16x8, hf[s2]), oacc[ct], 0, 0, 0);
+                if (i + 4 < 24 && DSG_M384_EXP != 5) fr[i & 3] = *reinterpret_cast<const bf16x8 *>(a + (2 * ((i + 4) % 12) + (i + 4) / 12) * 1024);
+                if (i < 12) { if (i % 3 == 0) gelu_a(12 + i / 3); else if (i % 3 == 1) gelu_b(12 + i / 3); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (c == 8) M384_STAMP(8);
+        h = hn;
+        slot = slot_n;
+    }
+    M384_STAMP(3);
+    M384_WAIT_VM(0);
+    __syncthreads();                           // the ring is free: row tiles for the stores
+    // ---- epilogue: lane (token, half) holds channels 32 ct + 8 q + 4 half + {0..3} in oacc[ct][4 q ..]; the row's statistics are lane-local
+    const rsrc_t rsX = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
+    __bf16 *xo = static_cast<__bf16 *>(g.xn_out);
+    const rsrc_t rsO = make_rsrc(xo ? xo + (size_t)m0 * C : nullptr, xo ? (unsigned)rows * C * 2u : 0u);
+    const float *aff_row = nullptr;
+    if (MOD != 0) aff_row = g.mod_aff + (size_t)(MOD == 2 ? min(m0 + (int)mrow, g.M - 1) / g.mod_T : 0) * g.mod_ld + g.mod_off;
+    float *xt = reinterpret_cast<float *>(lds + wave * 19456);
+    __bf16 *T = reinterpret_cast<__bf16 *>(lds + wave * 19456 + 12800);
+    auto xflush = [&](int q96) {                  // the wave's 32 x 96 fp32 tile -> x rows
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const int i = lane + 64 * k, r = i / 24, pc = i - 24 * r;
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(xt + r * 100 + 4 * pc);
+            buf_store4(d, rsX, ((unsigned)(32 * wave + r) * C + (unsigned)(96 * q96 + 4 * pc)) * 4u, 0u);
+        }
+    };
+    auto tflush = [&](int q96) {                  // the wave's 32 x 96 bf16 tile -> xn_out rows
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int i = lane + 64 * k, r = i / 12, pc = i - 12 * r;
+            const u32x4 d = *reinterpret_cast<const u32x4 *>(T + r * TLD + 8 * pc);
+            buf_store_u4(d, rsO, ((unsigned)(32 * wave + r) * C + (unsigned)(96 * q96 + 8 * pc)) * 2u, 0u);
+        }
+    };
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        f32x4 rr[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            rr[q] = PROJ ? (f32x4){0.f, 0.f, 0.f, 0.f} : buf_load4(rsX, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int cch = 32 * ct + 8 * q + 4 * lhalf;
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.b2 + cch);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = oacc[ct][4 * q + e] + b4[e] + rr[q][e];
+            if (MOD != 0) {
+                const f32x4 scl = *reinterpret_cast<const f32x4 *>(aff_row + cch), sft = *reinterpret_cast<const f32x4 *>(aff_row + C + cch);
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = silu_exact(fmaf(v[e], scl[e] + 1.0f, sft[e]));
+            }
+            *reinterpret_cast<f32x4 *>(xt + lrow * 100 + 32 * (ct % 3) + 8 * q + 4 * lhalf) = v;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { ssum += v[e]; ssq = fmaf(v[e], v[e], ssq); oacc[ct][4 * q + e] = v[e]; }
+            if (g.out_mode == 2) *reinterpret_cast<u32x2 *>(T + lrow * TLD + 32 * (ct % 3) + 8 * q + 4 * lhalf) = pack_bf16x4(v);
+        }
+        if (ct % 3 == 2) xflush(ct / 3);
+        if (g.out_mode == 2 && ct % 3 == 2) tflush(ct / 3);
+    }
+    if (g.out_mode == 1) {
+        ssum += __shfl_xor(ssum, 32, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        const float mean = ssum * (1.0f / C), rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, ssq * (1.0f / C)), 0.f) + LN_EPS), nmr = -mean * rstd;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = fmaf(oacc[ct][4 * q + e], rstd, nmr);
+                *reinterpret_cast<u32x2 *>(T + lrow * TLD + 32 * (ct % 3) + 8 * q + 4 * lhalf) = pack_bf16x4(v);
+            }
+            if (ct % 3 == 2) tflush(ct / 3);
+        }
+    }
+    M384_STAMP(4);
+#undef M384_STAMP
+}
+
 bool launch_mlp_bx(const BxMlp &g_in, hipStream_t s) {
     const BxMlp &g = g_in;
     if ((!g.xn && !g.att) || !g.x || !g.W1 || !g.b1 || !g.W2 || !g.b2 || g.M < 1 || (g.out_mode && !g.xn_out)) return false;
@@ -1421,7 +1757,18 @@ bool launch_mlp_bx(const BxMlp &g_in, hipStream_t s) {
         case 96: MLP_LAUNCH(96); break;
         case 192: MLP_LAUNCH(192); break;
         case 384:
-            if (g.wide8 == 1 && g.img) {   // eight waves, pre-arranged weight images streamed by LDS-DMA (mlp384d_bx_kernel)
+            if (g.wide8 == 3 && g.img2) {  // four waves, one per SIMD, chunk-major weight images (mlp384s_bx_kernel)
+                const dim3 block4(256);
+                if (proj) {
+                    if (mod == 0) DSG_LAUNCH((mlp384s_bx_kernel<0, true>), grid, block4, 0, s, g_in);
+                    else if (mod == 1) DSG_LAUNCH((mlp384s_bx_kernel<1, true>), grid, block4, 0, s, g_in);
+                    else DSG_LAUNCH((mlp384s_bx_kernel<2, true>), grid, block4, 0, s, g_in);
+                } else {
+                    if (mod == 0) DSG_LAUNCH((mlp384s_bx_kernel<0>), grid, block4, 0, s, g_in);
+                    else if (mod == 1) DSG_LAUNCH((mlp384s_bx_kernel<1>), grid, block4, 0, s, g_in);
+                    else DSG_LAUNCH((mlp384s_bx_kernel<2>), grid, block4, 0, s, g_in);
+                }
+            } else if (g.wide8 == 1 && g.img) {   // eight waves, pre-arranged weight images streamed by LDS-DMA (mlp384d_bx_kernel)
                 const dim3 block8(512);
                 static const int skew_env = getenv("DSG_M384_SKEW") ? atoi(getenv("DSG_M384_SKEW")) : -1;   // dev knob: stagger step in clocks
                 BxMlp g = g_in;

@@ -174,7 +174,8 @@ def test_qkv_attn_bx_vs_torch(B, res, ws, shift, heads):
 
 @pytest.mark.parametrize("M,C,mod,out_mode", [(51200, 384, 1, 1), (20037, 192, 1, 1), (65541, 96, 0, 2), (300, 96, 1, 1), (4096, 384, 0, 0),
                                                (1000, 192, 0, 2), (20037, 384, 0, 2), (51200, 384, 1, 1 + 16), (4100, 384, 0, 2 + 16),
-                                               (51200, 384, 1, 1 + 32), (20037, 384, 0, 2 + 32), (130, 384, 1, 1)])
+                                               (51200, 384, 1, 1 + 32), (20037, 384, 0, 2 + 32), (130, 384, 1, 1),
+                                               (51200, 384, 1, 1 + 64), (20037, 384, 0, 2 + 64), (4096, 384, 0, 0 + 64), (130, 384, 2, 1 + 64)])
 def test_mlp_bx_whole_matrix(M, C, mod, out_mode):
     """the fused fc1 -> GELU -> fc2 -> + residual -> [modulate] -> [LayerNorm | copy] kernel at its three widths against fp64 on the
     bf16-rounded operands, with the hidden activations rounded to bf16 between the two products as the kernel does"""
@@ -213,7 +214,8 @@ def test_mlp_bx_whole_matrix(M, C, mod, out_mode):
 
 @pytest.mark.parametrize("M,C,mod,out_mode", [(20037, 192, 1, 1), (65541, 96, 0, 2), (300, 96, 1, 1), (4096, 192, 0, 0), (51200, 96, 1, 1),
                                                (51200, 384, 1, 1), (20037, 384, 0, 2), (300, 384, 0, 0),
-                                               (51200, 384, 1, 1 + 32), (20037, 384, 0, 2 + 32), (129, 384, 1, 1)])
+                                               (51200, 384, 1, 1 + 32), (20037, 384, 0, 2 + 32), (129, 384, 1, 1),
+                                               (51200, 384, 1, 1 + 64), (20037, 384, 0, 2 + 64), (300, 384, 0, 0 + 64), (129, 384, 1, 1 + 64)])
 def test_projmlp_bx_whole_matrix(M, C, mod, out_mode):
     """proj + residual + LayerNorm-2 + fc1 + GELU + fc2 + residual [+ modulate] [+ LayerNorm | copy] in one kernel against fp64 on the
     bf16-rounded operands: x1 = x + att Wp^T + bp stays in the accumulators (fp32), its LayerNorm is rounded to bf16 as fc1's operand,

@@ -5,7 +5,7 @@ cd "$(dirname "$0")/.."
 if [ "$1" = "run" ]; then
   for v in ${M384_EXPS:-0 1 2 3 5}; do
     echo "=== DSG_M384_EXP=$v"
-    DSG_M384_SKEW=${M384_SKEW:--1} DSG_M384_CLK=1 BX_LIB=$PWD/tools/bin/ab/libdsg_m384exp$v.so BX_ITERS=10 BX_ONLY=mlp384 python tools/bx_bench.py 2>&1 | grep -v "^B=\|amdgpu.ids"
+    DSG_M384_SKEW=${M384_SKEW:--1} DSG_M384_CLK=1 BX_LIB=$PWD/tools/bin/ab/libdsg_m384exp$v.so BX_ITERS=10 BX_ONLY=${M384_ONLY:-mlp384} python tools/bx_bench.py 2>&1 | grep -v "^B=\|amdgpu.ids"
   done
   exit 0
 fi
