@@ -483,14 +483,19 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
         // scheduler cannot interleave with its neighbours
         float v[16];
 #pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = acc[j][r] + bias;
+        if (ACT == ACT_GELU) {   // pairs on the packed-fp32 instructions (gelu_f2)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) { const f32x2_t gg = gelu_f2(v[r], v[r + 1]); v[r] = gg[0]; v[r + 1] = gg[1]; }
+        }
+#pragma unroll
         for (int r = 0; r < 16; r++) {
-            v[r] = acc[j][r] + bias;
-            if (ACT == ACT_GELU) v[r] = gelu_f(v[r]);
-            else if (ACT == ACT_SILU) v[r] = silu_exact(v[r]);
-            if (ACT == ACT_DGELU) {   // (training form) d_pre = d_hid * GELU'(pre), pre read through the residual path: Phi(x) + x phi(x)
-                const float x = rres[r];
-                v[r] *= fmaf(x * 0.3989422804014327f, __expf(-0.5f * x * x), 0.5f * (1.0f + erff(x * 0.70710678118654752f)));
-            } else if (RES) v[r] += rres[r];
+            if (ACT == ACT_SILU) v[r] = silu_exact(v[r]);
+            if (ACT != ACT_DGELU && RES) v[r] += rres[r];
+        }
+        if (ACT == ACT_DGELU) {   // (training form) d_pre = d_hid * GELU'(pre), pre read through the residual path (dgelu_f2: pairs, packed fp32)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) { const f32x2_t dg = dgelu_f2(rres[r], rres[r + 1]); v[r] *= dg[0]; v[r + 1] *= dg[1]; }
         }
         if (g.C2) {
 #pragma unroll
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
         }
         if (ACT == ACT_GELU_KEEP) {   // (training form) C2 just received the pre-activation
 #pragma unroll
-            for (int r = 0; r < 16; r++) v[r] = gelu_f(v[r]);
+            for (int r = 0; r < 16; r += 2) { const f32x2_t gg = gelu_f2(v[r], v[r + 1]); v[r] = gg[0]; v[r + 1] = gg[1]; }
         }
         if (EPI >= 2) {
 #pragma unroll
@@ -723,7 +728,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? 2 : 1)) void fused_mlp_kernel(float
             for (int s = 0; s < S; s++) w1f[s] = buf_load4(rs1, lane16, (unsigned)((nt + 1) * S + s) * 1024u);
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) hacc[r] = gelu_f(hacc[r]);   // closed form: no LDS, no barrier in this kernel (table version: -0.2 % in the A/B)
+        for (int r = 0; r < 16; r += 2) { const f32x2_t gg = gelu_f2(hacc[r], hacc[r + 1]); hacc[r] = gg[0]; hacc[r + 1] = gg[1]; }   // closed form: no LDS, no barrier in this kernel (table version: -0.2 % in the A/B)
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
@@ -1137,7 +1142,7 @@ __global__ __launch_bounds__(256, 2) void fused_readout96_kernel(const float *__
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) hacc[r] = gelu_f(hacc[r]);
+        for (int r = 0; r < 16; r += 2) { const f32x2_t gg = gelu_f2(hacc[r], hacc[r + 1]); hacc[r] = gg[0]; hacc[r + 1] = gg[1]; }
         if (BF) {
 #pragma unroll
             for (int g2 = 0; g2 < 2; g2++) {

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MT == 2 ? 2 : 4)) void gemm_bx_kerne
 #pragma unroll
                 for (int q = 0; q < 2; q++)
 #pragma unroll
-                    for (int t = 0; t < 4; t++) v[q][t] = gelu_f(v[q][t]);
+                    for (int t = 0; t < 4; t += 2) { const f32x2_t gg = gelu_f2(v[q][t], v[q][t + 1]); v[q][t] = gg[0]; v[q][t + 1] = gg[1]; }
             }
             if (RES) {
 #pragma unroll
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
             hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w1s + lrow * LD1 + 16 * s + 8 * lhalf), xf[s], hacc, 0, 0, 0);
         u32x4 hf[2];
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) hf[r >> 3][(r & 7) >> 1] = pack_bf16(gelu_f(hacc[r]), gelu_f(hacc[r + 1]));
+        for (int r = 0; r < 16; r += 2) { const f32x2_t gg = gelu_f2(hacc[r], hacc[r + 1]); hf[r >> 3][(r & 7) >> 1] = pack_bf16(gg[0], gg[1]); }
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
@@ -891,7 +891,11 @@ __global__ __launch_bounds__(512, 1) void mlp384_bx_kernel(BxMlp g) {
                 const f32x4 pp = xch1[(q * 8 + (wave ^ 1)) * 64 + lane], b4 = *reinterpret_cast<const f32x4 *>(bb + 8 * q);
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = DSG_MLP_EXP == 1 ? ho[4 * q + e] + pp[e] + b4[e] : gelu_f(ho[4 * q + e] + pp[e] + b4[e]);
+                for (int e = 0; e < 4; e += 2) {
+                    const float t0 = ho[4 * q + e] + pp[e] + b4[e], t1 = ho[4 * q + e + 1] + pp[e + 1] + b4[e + 1];
+                    const f32x2_t gg = DSG_MLP_EXP == 1 ? (f32x2_t){t0, t1} : gelu_f2(t0, t1);
+                    v[e] = gg[0]; v[e + 1] = gg[1];
+                }
                 hf[q >> 1][2 * (q & 1)] = pack_bf16(v[0], v[1]);
                 hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(v[2], v[3]);
             }
@@ -1265,8 +1269,9 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
                 hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(h[4 * q + 2], h[4 * q + 3]);
                 continue;
             }
-            hf[q >> 1][2 * (q & 1)] = pack_bf16(gelu_f(h[4 * q]), gelu_f(h[4 * q + 1]));
-            hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(gelu_f(h[4 * q + 2]), gelu_f(h[4 * q + 3]));
+            const f32x2_t g01 = gelu_f2(h[4 * q], h[4 * q + 1]), g23 = gelu_f2(h[4 * q + 2], h[4 * q + 3]);
+            hf[q >> 1][2 * (q & 1)] = pack_bf16(g01[0], g01[1]);
+            hf[q >> 1][2 * (q & 1) + 1] = pack_bf16(g23[0], g23[1]);
         }
         xch2[(0 * 8 + wave) * 64 + lane] = hf[0];
         xch2[(1 * 8 + wave) * 64 + lane] = hf[1];
@@ -1600,24 +1605,27 @@ __global__ __launch_bounds__(256, 1) void mlp384s_bx_kernel(BxMlp g) {
         // of the GELU arithmetic (which issues in the MFMA's shadow: 32 matrix cycles leave room for seven VALU instructions), every
         // other time one LDS-DMA piece -- and a sched_barrier(0) after each so that the compiler keeps the segments in this order
         // (sched_group_barrier pipelines with VALU groups were dropped by the solver on this block).
-        // GELU(c): values 0 .. 11 behind fc1(c + 1)'s MFMAs (one value per two), values 12 .. 15 behind the first twelve MFMAs of fc2(c),
+        // GELU(c): values 0 .. 11 behind fc1(c + 1)'s MFMAs (one PAIR per four), values 12 .. 15 behind the first twelve MFMAs of fc2(c),
         // which run s2 = 0 (hidden units 0 .. 15 = hf[0]) first.
         u32x4 hf[2];
-        float gt[16];
-        auto gelu_a = [&](int v) {             // exponent argument of value v
-            if (DSG_M384_EXP == 3) { gt[v] = h[v]; return; }
-            const float a = fminf(fabsf(h[v]), 6.0f);
-            float pp = fmaf(a, 3.3159643839e-05f, -7.6972447974e-04f);
-            pp = fmaf(a, pp, 8.0821445939e-03f);
-            pp = fmaf(a, pp, -5.3413999628e-02f);
-            pp = fmaf(a, pp, -4.5876976689e-01f);
-            pp = fmaf(a, pp, -1.1512020345f);
-            gt[v] = fmaf(a, pp, -9.9999303260e-01f);
+        f32x2_t ga[8], gp[8];
+        auto gelu_a = [&](int v) {             // pair v (values 2 v, 2 v + 1): the exponent arguments (packed fp32: see gelu_f2)
+            if (DSG_M384_EXP == 3) { gp[v] = (f32x2_t){h[2 * v], h[2 * v + 1]}; return; }
+            const f32x2_t a = {__builtin_amdgcn_fmed3f(__builtin_fabsf(h[2 * v]), 0.0f, 6.0f), __builtin_amdgcn_fmed3f(__builtin_fabsf(h[2 * v + 1]), 0.0f, 6.0f)};
+            f32x2_t pp = __builtin_elementwise_fma(a, (f32x2_t){3.3159643839e-05f, 3.3159643839e-05f}, (f32x2_t){-7.6972447974e-04f, -7.6972447974e-04f});
+            pp = __builtin_elementwise_fma(a, pp, (f32x2_t){8.0821445939e-03f, 8.0821445939e-03f});
+            pp = __builtin_elementwise_fma(a, pp, (f32x2_t){-5.3413999628e-02f, -5.3413999628e-02f});
+            pp = __builtin_elementwise_fma(a, pp, (f32x2_t){-4.5876976689e-01f, -4.5876976689e-01f});
+            pp = __builtin_elementwise_fma(a, pp, (f32x2_t){-1.1512020345f, -1.1512020345f});
+            gp[v] = __builtin_elementwise_fma(a, pp, (f32x2_t){-9.9999303260e-01f, -9.9999303260e-01f});
+            ga[v] = a;
         };
-        auto gelu_b = [&](int v) {             // value v done; packed with its neighbour when the odd one is
-            if (DSG_M384_EXP == 3) { if (v & 1) hf[v >> 3][(v >> 1) & 3] = pack_bf16(gt[v - 1], gt[v]); return; }
-            gt[v] = fmaf(-fabsf(h[v]), __builtin_amdgcn_exp2f(gt[v]), fmaxf(h[v], 0.0f));
-            if (v & 1) hf[v >> 3][(v >> 1) & 3] = pack_bf16(gt[v - 1], gt[v]);
+        auto gelu_b = [&](int v) {             // pair v done and packed
+            if (DSG_M384_EXP == 3) { hf[v >> 2][v & 3] = pack_bf16(gp[v][0], gp[v][1]); return; }
+            const f32x2_t e = {__builtin_amdgcn_exp2f(gp[v][0]), __builtin_amdgcn_exp2f(gp[v][1])};
+            const f32x2_t r = {__builtin_amdgcn_fmed3f(h[2 * v], 0.0f, 3.0e38f), __builtin_amdgcn_fmed3f(h[2 * v + 1], 0.0f, 3.0e38f)};
+            const f32x2_t o = __builtin_elementwise_fma(-ga[v], e, r);
+            hf[v >> 2][v & 3] = pack_bf16(o[0], o[1]);
         };
         f32x16 hn = h;
         if (c + 1 < NCH) {
@@ -1631,13 +1639,14 @@ __global__ __launch_bounds__(256, 1) void mlp384s_bx_kernel(BxMlp g) {
             for (int s = 0; s < 24; s++) {
                 if (DSG_M384_EXP != 2) hn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s & 3], xf[s], hn, 0, 0, 0);
                 if (s + 4 < 24 && DSG_M384_EXP != 5) fr[s & 3] = *reinterpret_cast<const bf16x8 *>(a + (s + 4) * 1024);
-                if (s & 1) { gelu_b(s >> 1); if (DSG_M384_EXP != 1) dma_piece(rsrc_stage, slot_r, s >> 1); }
-                else gelu_a(s >> 1);
+                if (s % 4 == 0) gelu_a(s >> 2);
+                if (s % 4 == 2) gelu_b(s >> 2);
+                if ((s & 1) && DSG_M384_EXP != 1) dma_piece(rsrc_stage, slot_r, s >> 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
 #pragma unroll
-            for (int v = 0; v < 12; v++) { gelu_a(v); gelu_b(v); }
+            for (int v = 0; v < 6; v++) { gelu_a(v); gelu_b(v); }
         }
         if (c == 8) M384_STAMP(7);
         // ---- fc2 of chunk c on all 384 output channels, s2-major
@@ -1652,7 +1661,7 @@ __global__ __launch_bounds__(256, 1) void mlp384s_bx_kernel(BxMlp g) {
                 const int ct = i % 12, s2 = i / 12;
                 if (DSG_M384_EXP != 2) oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 3], __builtin_bit_cast(bf16x8, hf[s2]), oacc[ct], 0, 0, 0);
                 if (i + 4 < 24 && DSG_M384_EXP != 5) fr[i & 3] = *reinterpret_cast<const bf16x8 *>(a + (2 * ((i + 4) % 12) + (i + 4) / 12) * 1024);
-                if (i < 12) { if (i % 3 == 0) gelu_a(12 + i / 3); else if (i % 3 == 1) gelu_b(12 + i / 3); }
+                if (i < 12) { if (i % 6 == 0) gelu_a(6 + i / 6); else if (i % 6 == 3) gelu_b(6 + i / 6); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -2044,8 +2053,14 @@ void launch_bias_permute_bx(const float *biasT, void *out, int n_tiles, int Wp, 
     DSG_LAUNCH(bias_permute_bx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, biasT, (_Float16 *)out, n_tiles, Wp);
 }
 
+#ifndef DSG_QA_EXP
+#define DSG_QA_EXP 0   // timing experiments (wrong results): 1 no attention arithmetic, 2 no MFMAs in the K loop, 3 no global loads in the K loop, 4 no LDS staging writes
+#endif
+#ifndef DSG_QA_OCC
+#define DSG_QA_OCC 4
+#endif
 template <int KT, int WS>
-__global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nblk, int U) {
+__global__ __launch_bounds__(256, DSG_QA_OCC) void qkv_attn_bx_kernel(BxQkvAttn a, int nblk, int U) {
     constexpr int KB = 64, LDP = KB + 8, Wp = 32 * KT, Wt = WS * WS, UPB = 4 / KT, KLD = 40, VLD = Wp + 8;
     constexpr int STAGE = (128 + 96) * LDP, OLD = 40;
     static_assert(128 * KLD + UPB * 32 * VLD <= STAGE, "k / v^T live in the tile stage after the K loop");
@@ -2053,22 +2068,30 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
     float *colv = reinterpret_cast<float *>(lds + STAGE);      // the head's 96 bias values (q | k | v)
     __bf16 *kl = lds, *vtl = lds + 128 * KLD;
     const unsigned OOB = 0x7fffffffu;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhalf = lane >> 5;
     const int heads = a.g.heads, C = a.g.C, res = a.g.res, shift = a.g.shift;
     const int nwr = res / WS, nW = nwr * nwr, T = res * res;
     const int t = blockIdx.x, xcd = t & 7, seq = t >> 3;
     const int ub = (seq / heads) * 8 + xcd, head = seq % heads;
     if (ub >= nblk) return;
-    // token of block row `row` (unit ub UPB + row / Wp, window position row % Wp): element offset in xn / out, or -1
-    auto row_token = [&](int row) -> int {
-        const int ul = row / Wp, pos = row % Wp, u = ub * UPB + ul;
-        if (pos >= Wt || u >= U) return -1;
-        const int b = u / nW, w = u % nW, wi = w / nwr, wj = w % nwr;
-        int ti = wi * WS + pos / WS + shift, tj = wj * WS + pos % WS + shift;
+    // A unit's geometry (sample, window row / column -> first token row / column after the cyclic shift) is WAVE-UNIFORM: the two runtime
+    // divisions are done once per unit on scalar values, not once per row and lane (round 4: the kernel ran 16 VALU instructions per MFMA,
+    // a third of them this index arithmetic; tools/mfma_rate.cpp: every VALU instruction beyond two per MFMA costs matrix time).
+    struct Unit { int tb, i0, j0; };
+    auto unit_of = [&](int ul) -> Unit {               // ul: uniform
+        const int u = __builtin_amdgcn_readfirstlane(ub * UPB + ul);
+        if (u >= U) return {-1, 0, 0};
+        const int b = u / nW, w = u - b * nW, wi = w / nwr, wj = w - wi * nwr;
+        return {b * T, wi * WS + shift, wj * WS + shift};
+    };
+    // token of window position pos of a unit: element offset in xn / out, or -1 (padding position / no such unit)
+    auto pos_token = [&](const Unit &un, int pos) -> int {
+        const int pi = pos / WS, pj = pos - pi * WS;   // WS is a template value: multiply + shift
+        int ti = un.i0 + pi, tj = un.j0 + pj;
         if (ti >= res) ti -= res;
         if (tj >= res) tj -= res;
-        return b * T + ti * res + tj;
+        return (pos >= Wt || un.tb < 0) ? -1 : un.tb + ti * res + tj;
     };
     const __bf16 *xn = static_cast<const __bf16 *>(a.xn), *Wq = static_cast<const __bf16 *>(a.W);
     const rsrc_t rsA = make_rsrc(xn, (unsigned)((size_t)a.B * T * C * 2u));
@@ -2076,20 +2099,32 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
     const int sc = tid & 7, sr = tid >> 3;             // this thread's 16-byte piece / first stage row
     unsigned offA[4], offW[3];
 #pragma unroll
-    for (int p = 0; p < 4; p++) { const int tk = row_token(sr + 32 * p); offA[p] = tk < 0 ? OOB : ((unsigned)tk * C + 8u * sc) * 2u; }
+    for (int p = 0; p < 4; p++) {                      // stage row sr + 32 p: unit (32 p) / Wp, window position sr + (32 p) % Wp
+        const Unit un = unit_of((32 * p) / Wp);
+        const int tk = pos_token(un, sr + (32 * p) % Wp);
+        offA[p] = tk < 0 ? OOB : ((unsigned)tk * C + 8u * sc) * 2u;
+    }
 #pragma unroll
     for (int p = 0; p < 3; p++) offW[p] = ((unsigned)(p * C + head * 32 + sr) * C + 8u * sc) * 2u;
     const int nk = (C + KB - 1) / KB;                  // >= 2 (launcher)
     struct Stage { u32x4 a[4], w[3]; };
     auto issue = [&](Stage &st, int kc) {
         const int k0 = kc * KB;
-        const unsigned kmask = (k0 + 8 * sc < C) ? 0u : OOB;   // C = 96: the second chunk is half valid
+        if (k0 + KB > C) {                               // C = 96: the second chunk is half valid (a uniform branch: no mask arithmetic on full chunks)
+            const unsigned kmask = (k0 + 8 * sc < C) ? 0u : OOB;
 #pragma unroll
-        for (int p = 0; p < 4; p++) st.a[p] = buf_load_u4(rsA, offA[p] | kmask, (unsigned)k0 * 2u);
+            for (int p = 0; p < 4; p++) st.a[p] = buf_load_u4(rsA, offA[p] | kmask, (unsigned)k0 * 2u);
 #pragma unroll
-        for (int p = 0; p < 3; p++) st.w[p] = buf_load_u4(rsW, offW[p] | kmask, (unsigned)k0 * 2u);
+            for (int p = 0; p < 3; p++) st.w[p] = buf_load_u4(rsW, offW[p] | kmask, (unsigned)k0 * 2u);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; p++) st.a[p] = buf_load_u4(rsA, offA[p], (unsigned)k0 * 2u);
+#pragma unroll
+            for (int p = 0; p < 3; p++) st.w[p] = buf_load_u4(rsW, offW[p], (unsigned)k0 * 2u);
+        }
     };
     auto write = [&](const Stage &st) {
+        if (DSG_QA_EXP == 4 && st.a[0][0] != 0x12345u) return;
 #pragma unroll
         for (int p = 0; p < 4; p++) *reinterpret_cast<u32x4 *>(lds + (sr + 32 * p) * LDP + 8 * sc) = st.a[p];
 #pragma unroll
@@ -2109,7 +2144,8 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
 #pragma unroll
             for (int nt = 0; nt < 3; nt++) {
                 const bf16x8 wf = *reinterpret_cast<const bf16x8 *>(Wfr + 32 * nt * LDP + 16 * s);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc[nt], 0, 0, 0);
+                if (DSG_QA_EXP != 2) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af, acc[nt], 0, 0, 0);
+                else acc[nt][0] += (float)wf[0] + (float)af[0];
             }
         }
     };
@@ -2121,13 +2157,13 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
     write(s0);
     __syncthreads();
     for (int kc = 0; kc < nk; kc += 2) {   // LDS holds chunk kc, s1 holds chunk kc + 1, s0 is free
-        if (kc + 2 < nk) issue(s0, kc + 2);
+        if (kc + 2 < nk && DSG_QA_EXP != 3) issue(s0, kc + 2);
         compute();
         __syncthreads();
         if (kc + 1 < nk) {
             write(s1);
             __syncthreads();
-            if (kc + 3 < nk) issue(s1, kc + 3);
+            if (kc + 3 < nk && DSG_QA_EXP != 3) issue(s1, kc + 3);
             compute();
             __syncthreads();
             if (kc + 2 < nk) { write(s0); __syncthreads(); }
@@ -2135,7 +2171,7 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
     }
     // ---- this wave's attention unit: window positions 32 wave .. + 31 are query tile qt of unit ul ----
     const int ul = wave / KT, qt = wave % KT;
-    const int u = ub * UPB + ul, w_of_u = (u < U ? u : 0) % nW;
+    const int u = __builtin_amdgcn_readfirstlane(ub * UPB + ul), w_of_u = (u < U ? u : 0) % nW;
     // bias tile of this lane's query in accumulator order (fp16): issued now, consumed after the LDS phase
     const u32x4 *bp = reinterpret_cast<const u32x4 *>(a.biasP) +
                       ((((size_t)(shift > 0 ? w_of_u : 0) * heads + head) * Wp + 32 * qt + lrow) * 2 + lhalf) * (KT * 2);
@@ -2192,12 +2228,12 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
             sacc[kt][r] = (float)pk[0]; sacc[kt][r + 1] = (float)pk[1];
         }
 #pragma unroll
-        for (int s = 0; s < 2; s++) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[s], sacc[kt], 0, 0, 0);
+        for (int s = 0; s < 2; s++) if (DSG_QA_EXP != 1) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[s], sacc[kt], 0, 0, 0);
         // register r holds key 32 kt + (r & 3) + 8 (r >> 2) + 4 half: quads whose first key is beyond the window (the last key tile of a
         // 100-token window keeps 1 quad of 4) are padding on every lane -- no maximum, no exponential, P = 0
 #pragma unroll
         for (int r = 0; r < 16; r++)
-            if (32 * kt + 8 * (r >> 2) < Wt) mx = fmaxf(mx, sacc[kt][r]);
+            if (32 * kt + 8 * (r >> 2) < Wt && DSG_QA_EXP != 1) mx = fmaxf(mx, sacc[kt][r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
@@ -2209,7 +2245,7 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
         u32x4 pf[2];
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            if (32 * kt + 8 * (r >> 2) < Wt) {
+            if (32 * kt + 8 * (r >> 2) < Wt && DSG_QA_EXP != 1) {
                 const float e0 = __builtin_amdgcn_exp2f(sacc[kt][r] - mx), e1 = __builtin_amdgcn_exp2f(sacc[kt][r + 1] - mx);
                 sum += e0 + e1;
                 pf[r >> 3][(r & 7) >> 1] = pack_bf16(e0, e1);
@@ -2219,7 +2255,8 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
         }
 #pragma unroll
         for (int s = 0; s < 2; s++)
-            if (32 * kt + 16 * s < Wt) oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], __builtin_bit_cast(bf16x8, pf[s]), oacc, 0, 0, 0);
+            if (32 * kt + 16 * s < Wt && DSG_QA_EXP != 1) oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], __builtin_bit_cast(bf16x8, pf[s]), oacc, 0, 0, 0);
+            else if (DSG_QA_EXP == 1) oacc[0] += (float)vf[kt][s][0] + (float)kf[kt][s][0] + __uint_as_float(bb[kt][s][0]);
     }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = fast_rcp(sum);
@@ -2234,10 +2271,11 @@ __global__ __launch_bounds__(256, 4) void qkv_attn_bx_kernel(BxQkvAttn a, int nb
         *reinterpret_cast<u32x2 *>(Tq + lrow * OLD + 8 * q + 4 * lhalf) = pack_bf16x4(o);
     }
     const rsrc_t rsO = make_rsrc(a.out, (unsigned)((size_t)a.B * T * C * 2u));
+    const Unit uo = unit_of(ul);
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         const int r = (lane >> 2) + 16 * k, pc = lane & 3;          // token row of the tile, 16-byte piece of its 64 bytes
-        const int tq = row_token(32 * wave + r);
+        const int tq = pos_token(uo, 32 * qt + r);
         const u32x4 d = *reinterpret_cast<const u32x4 *>(Tq + r * OLD + 8 * pc);
         buf_store_u4(d, rsO, tq < 0 ? OOB : ((unsigned)tq * (unsigned)C + (unsigned)(head * 32 + 8 * pc)) * 2u, 0u);
     }

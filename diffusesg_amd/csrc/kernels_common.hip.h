@@ -45,6 +45,45 @@ __device__ __forceinline__ float gelu_f(float x) {
     return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(p), fmaxf(x, 0.0f));
 }
 
+// Two GELUs per call on the packed-fp32 instructions (v_pk_fma_f32: both halves of a register pair per issue, constants from SGPRs):
+// the six polynomial steps and the closing FMA are one instruction per PAIR, |x| clamp and max(x, 0) are one v_med3 each (no NaN
+// canonicalisation in front) -- 7 VALU per element instead of 11.5.  Same arithmetic as gelu_f (an IEEE FMA is an IEEE FMA) except that
+// the closing product uses the clamped a instead of |x|: equal for |x| <= 6, and beyond the subtracted term is < 1e-8 either way.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_f2(float x0, float x1) {
+    const f32x2_t a = {__builtin_amdgcn_fmed3f(__builtin_fabsf(x0), 0.0f, 6.0f), __builtin_amdgcn_fmed3f(__builtin_fabsf(x1), 0.0f, 6.0f)};
+    f32x2_t p = __builtin_elementwise_fma(a, (f32x2_t){3.3159643839e-05f, 3.3159643839e-05f}, (f32x2_t){-7.6972447974e-04f, -7.6972447974e-04f});
+    p = __builtin_elementwise_fma(a, p, (f32x2_t){8.0821445939e-03f, 8.0821445939e-03f});
+    p = __builtin_elementwise_fma(a, p, (f32x2_t){-5.3413999628e-02f, -5.3413999628e-02f});
+    p = __builtin_elementwise_fma(a, p, (f32x2_t){-4.5876976689e-01f, -4.5876976689e-01f});
+    p = __builtin_elementwise_fma(a, p, (f32x2_t){-1.1512020345f, -1.1512020345f});
+    p = __builtin_elementwise_fma(a, p, (f32x2_t){-9.9999303260e-01f, -9.9999303260e-01f});
+    const f32x2_t e = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};
+    const f32x2_t r = {__builtin_amdgcn_fmed3f(x0, 0.0f, 3.0e38f), __builtin_amdgcn_fmed3f(x1, 0.0f, 3.0e38f)};
+    return __builtin_elementwise_fma(-a, e, r);
+}
+
+// GELU'(x) = Phi(x) + x phi(x) for two values (training form: the fc2-backward GEMM's epilogue).  Phi(-|x|) is the same exp2(polynomial)
+// as in gelu_f2 (absolute error <= 2.4e-6, at 0), Phi(x) = 1/2 + copysign(1/2 - Phi(-|x|), x), phi by one more exp2: 10 VALU and two
+// transcendentals per element on the packed-fp32 instructions, against ~45 for the erff / expf form it replaces (round 4: that epilogue made
+// the K = C products of the backward pass 1.5-2x as long as the same shapes without it).
+__device__ __forceinline__ f32x2_t dgelu_f2(float x0, float x1) {
+    const f32x2_t x = {x0, x1};
+    const f32x2_t a = {__builtin_amdgcn_fmed3f(__builtin_fabsf(x0), 0.0f, 6.0f), __builtin_amdgcn_fmed3f(__builtin_fabsf(x1), 0.0f, 6.0f)};
+    f32x2_t p = __builtin_elementwise_fma(a, (f32x2_t){3.3159643839e-05f, 3.3159643839e-05f}, (f32x2_t){-7.6972447974e-04f, -7.6972447974e-04f});
+    p = __builtin_elementwise_fma(a, p, (f32x2_t){8.0821445939e-03f, 8.0821445939e-03f});
+    p = __builtin_elementwise_fma(a, p, (f32x2_t){-5.3413999628e-02f, -5.3413999628e-02f});
+    p = __builtin_elementwise_fma(a, p, (f32x2_t){-4.5876976689e-01f, -4.5876976689e-01f});
+    p = __builtin_elementwise_fma(a, p, (f32x2_t){-1.1512020345f, -1.1512020345f});
+    p = __builtin_elementwise_fma(a, p, (f32x2_t){-9.9999303260e-01f, -9.9999303260e-01f});
+    const f32x2_t t = {__builtin_amdgcn_exp2f(p[0]), __builtin_amdgcn_exp2f(p[1])};                   // Phi(-|x|)
+    const f32x2_t h = (f32x2_t){0.5f, 0.5f} - t;                                                      // >= 0
+    const f32x2_t Phi = (f32x2_t){0.5f, 0.5f} + (f32x2_t){__builtin_copysignf(h[0], x0), __builtin_copysignf(h[1], x1)};
+    const f32x2_t q = (x * x) * (f32x2_t){-0.72134752044f, -0.72134752044f};                           // -x^2 / 2 * log2 e
+    const f32x2_t ph = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1])};
+    return __builtin_elementwise_fma(x * (f32x2_t){0.3989422804f, 0.3989422804f}, ph, Phi);
+}
+
 // The same form with a degree-4 fit (tools/fit_gelu.py, deg 4: max abs error 6.2e-6 against an fp64 GELU over [-12, 12]), 8 VALU instead of
 // 10.  Tried in the bf16 block pipeline (round 4), whose hidden activations are rounded to bf16 right behind it -- NOT used: no measurable
 // gain on COCO B = 512 (1119 graphs/s either way) and the C = 96 whole-matrix kernel test moved from inside to just outside its bar

@@ -136,6 +136,12 @@ if __name__ == "__main__":
         projmlp("L1 proj + MLP fused (mod, LN)", M1, 192)
         projmlp("L0 proj + MLP fused (copy)", M0, 96, mod=0, out_mode=2)
         sys.exit(0)
+    if only == "qa":    # the fused QKV + attention kernel alone
+        qkv_attn("L2 qkv + attn fused", B, 10, 10, 0, 12)
+        qkv_attn("L1 qkv + attn fused", B, 20, 10, 0, 6)
+        qkv_attn("L1 qkv + attn fused, shifted", B, 20, 10, 5, 6)
+        qkv_attn("L0 qkv + attn fused", B, 40, 10, 0, 3)
+        sys.exit(0)
     gemm("L2 qkv", M2, 1152, 384)
     gemm("L2 proj (res, LN)", M2, 384, 384, res=1, ln=1)
     gemm("L2 fc1 (gelu)", M2, 1536, 384, act=1)
