@@ -55,6 +55,7 @@ struct BlockPlan {
     int aff_off;        // offset of this block's (scale,shift) in the concatenated affine output
     float *biasT = nullptr;  // [nWt][heads][Wp][Wp]
     void *biasP = nullptr;   // the same tiles as fp16 in score-accumulator order (qkv_attn_bx_kernel)
+    float *biasF = nullptr;  // ... and as fp32 (qkv_attn_wx_kernel: 10 x 10 windows)
     float *w1p = nullptr, *w2p = nullptr;  // fragment-major packed MLP weights (fused_mlp_kernel), narrow levels only
     float *wqp = nullptr, *wpp = nullptr;  // fragment-major packed qkv / proj weights (fused_attn96_kernel), C == 96 only
     float *bqkv_s = nullptr;               // qkv bias with the q part pre-scaled (fused_attn96_kernel)
@@ -139,10 +140,11 @@ struct dsg_handle_s {
     bool opt_bf16_pipe = true;                                    // in that mode: the bf16 block pipeline of kernels_bx.hip (0: round 2's kernels_lp.hip path)
     bool opt_bf16_readout = true;                                 // in that pipeline: the read-out's two products on the bf16 matrix pipe
     bool opt_bf16_proj_mlp = true;                                // in that pipeline: proj + residual + LayerNorm-2 in front of the fused MLP kernel (0: the proj GEMM)
-    bool opt_bf16_qkv_attn = true;                                // in that pipeline: QKV projection + window attention in one kernel (0: GEMM + attn_bx_kernel through a bf16 qkv tensor)
+    int opt_bf16_qkv_attn = 1;                                    // in that pipeline: QKV projection + window attention in one kernel (0: GEMM + attn_bx_kernel through a bf16 qkv tensor)
     int opt_bf16_mlp = 1;                                         // in that pipeline: the fused fc1-GELU-fc2 kernels (0: two GEMMs with a bf16 hidden tensor; 1: C <= 192 on 4 waves, C = 384 on 8; 2: C = 384 on the 4-wave kernel too; 3: GEMM pair at C = 384)
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
+    std::map<const float *, void *> w_qimg;                       // per block (key: its qkv_wf): the QKV weight in qkv_attn_wx_kernel's streaming order
     std::map<const float *, void *> w_img2;                       // the same weights chunk-major for mlp384s_bx_kernel (bf16_mlp = 5)
     std::map<const float *, void *> w_img;                        // per C = 384 block (key: its fc1_wf): W1 | W2 | Wp pre-arranged for mlp384d_bx_kernel's LDS-DMA ring
     bool opt_gemm_split = false;                                  // split-bf16 GEMMs (3 planes, 6 products): fp32-accurate, opt-in
@@ -395,6 +397,13 @@ int build_bias_table(dsg_handle h, BlockPlan &bp) {
     launch_bias_permute_bx(bp.biasT, pp, nWt * heads, Wp, nullptr);
     HIP_TRY(h, hipStreamSynchronize(nullptr));
     bp.biasP = pp;
+    if (ws == 10) {
+        void *pf;
+        if (int rc = dev_alloc(h, h->derived_allocs, &pf, sizeof(float) * out.size())) return rc;
+        launch_bias_permute_f32(bp.biasT, (float *)pf, nWt * heads, Wp, nullptr);
+        HIP_TRY(h, hipStreamSynchronize(nullptr));
+        bp.biasF = (float *)pf;
+    }
     return 0;
 }
 
@@ -507,6 +516,16 @@ int ensure_bf16_weights(dsg_handle h) {
         launch_f32_to_bf16(pw.first, q, pw.second, nullptr);
         h->w_bf16[pw.first] = q;
     }
+    // every block's QKV weight once more in the fragment order qkv_attn_wx_kernel streams (launch_qkv_image)
+    for (int l = 0; l < h->L; l++)
+        for (auto *vec : {&h->down[l], &h->up[l]})
+            for (auto &b : *vec) {
+                if (!b.qkv_wf || b.ws != 10 || h->w_qimg.count(b.qkv_wf) || !h->w_bf16.count(b.qkv_wf)) continue;
+                void *q;
+                HIP_TRY(h, hipMalloc(&q, (size_t)3 * b.C * b.C * 2));
+                launch_qkv_image(h->w_bf16[b.qkv_wf], q, b.C, b.heads, nullptr);
+                h->w_qimg[b.qkv_wf] = q;
+            }
     // the C = 384 blocks' fc1 / fc2 / proj weights once more, in the piece order the LDS-DMA MLP kernel streams and reads them
     if (h->cfg.mlp_ratio == 4)
         for (int l = 0; l < h->L; l++)
@@ -606,6 +625,7 @@ int dsg_create(const dsg_config *cfg, dsg_handle *out) {
     if (getenv("DSG_FUSED_MLP_MAXC")) h->opt_fused_mlp_maxc = atoi(getenv("DSG_FUSED_MLP_MAXC"));
     h->opt_gemm_bf16 = env_on("DSG_GEMM_BF16", false);
     h->opt_bf16_pipe = env_on("DSG_BF16_PIPE", true);
+    if (getenv("DSG_BF16_QA")) h->opt_bf16_qkv_attn = atoi(getenv("DSG_BF16_QA"));   // dev knob: 2 = the block-per-head QKV + attention kernel
     if (getenv("DSG_BF16_MLP")) h->opt_bf16_mlp = atoi(getenv("DSG_BF16_MLP"));   // dev knob: A/B of the C = 384 MLP kernels (1 LDS-DMA, 4 round 3's)
     h->opt_gemm_split = env_on("DSG_GEMM_SPLIT", false);
     *out = h;
@@ -619,6 +639,7 @@ void dsg_destroy(dsg_handle h) {
     for (auto &kv : h->w_bf16) (void)hipFree(kv.second);
     for (auto &kv : h->w_img) (void)hipFree(kv.second);
     for (auto &kv : h->w_img2) (void)hipFree(kv.second);
+    for (auto &kv : h->w_qimg) (void)hipFree(kv.second);
     for (auto &kv : h->w_split) (void)hipFree(kv.second);
     for (void *p : h->derived_allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -849,6 +870,8 @@ int dsg_finalize_weights(dsg_handle h) {
     h->w_img.clear();
     for (auto &kv : h->w_img2) (void)hipFree(kv.second);
     h->w_img2.clear();
+    for (auto &kv : h->w_qimg) (void)hipFree(kv.second);
+    h->w_qimg.clear();
     for (auto &kv : h->w_split) (void)hipFree(kv.second);
     h->w_split.clear();
     h->gemm_weights.clear();
@@ -1225,6 +1248,10 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
     if (h->opt_bf16_qkv_attn && h->taps.empty()) {   // (the qkv tap wants the tensor)
         BxQkvAttn qa;
         qa.xn = w->xn; qa.W = bf16_of(h, b.qkv_wf); qa.bias = b.qkv_bf; qa.biasP = b.biasP; qa.out = w->att; qa.B = B; qa.g = wg;
+        { auto it = h->w_qimg.find(b.qkv_wf); qa.Wimg = it == h->w_qimg.end() ? nullptr : it->second; }
+        qa.biasF = b.biasF;
+        // 10 x 10 windows: 1 the wave-per-unit kernel, 2 the block-per-head kernel (its A/B), 3 wave-per-unit only where a block lies in one window (heads % 4 == 0)
+        qa.variant = (h->opt_bf16_qkv_attn == 2 || (h->opt_bf16_qkv_attn == 3 && b.heads % 4 != 0)) ? 1 : 0;
         ProfScope ps_(h, s, PK_ATTN, 2.0 * (double)M * 3.0 * C * C + 4.0 * (double)M * (double)(b.ws * b.ws) * (double)C, "qkv_attn_bx");
         fused_qa = launch_qkv_attn_bx(qa, s);
     }
@@ -1676,7 +1703,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "bf16_act") h->opt_bf16_act = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "bf16_pipe") h->opt_bf16_pipe = value != 0;
     else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 5 ? 5 : value);
-    else if (n == "bf16_qkv_attn") h->opt_bf16_qkv_attn = value != 0;
+    else if (n == "bf16_qkv_attn") h->opt_bf16_qkv_attn = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (n == "bf16_proj_mlp") h->opt_bf16_proj_mlp = value != 0;
     else if (n == "bf16_readout") h->opt_bf16_readout = value != 0;
     else if (n == "fused_merge") { h->opt_fused_merge = value != 0; h->opt_fused_merge_small = value > 1; }   // 2: at every size
@@ -1717,7 +1744,7 @@ int dsg_get_option(dsg_handle h, const char *name, int32_t *value) {
     else if (n == "bf16_act") *value = (h->opt_gemm_bf16 && !h->opt_gemm_split && !bx_on(h)) ? h->opt_bf16_act : 0;   // acts whenever round 2's bf16 path is what runs (pipeline off, or a width it does not take)
     else if (n == "bf16_pipe") *value = bx_on(h);   // the bf16 block pipeline runs (bf16 mode only)
     else if (n == "bf16_mlp") *value = bx_on(h) ? h->opt_bf16_mlp : 0;
-    else if (n == "bf16_qkv_attn") *value = (bx_on(h) && h->opt_bf16_qkv_attn) ? 1 : 0;
+    else if (n == "bf16_qkv_attn") *value = bx_on(h) ? h->opt_bf16_qkv_attn : 0;
     else if (n == "bf16_proj_mlp") *value = (bx_on(h) && h->opt_bf16_mlp && h->opt_bf16_proj_mlp) ? 1 : 0;
     else if (n == "bf16_readout") *value = (bx_on(h) && h->opt_bf16_readout && h->opt_fused_readout) ? 1 : 0;
     else if (n == "fused_merge") *value = h->opt_fused_merge ? (h->opt_fused_merge_small ? 2 : 1) : 0;
@@ -2229,6 +2256,8 @@ int dsg_debug_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int32_t
 
 int dsg_debug_qkv_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int32_t heads, const float *xn, const float *W, const float *bias,
                           const float *biasT, float *out, int32_t time_iters, float *out_ms, void *stream) {
+    const int variant = shift >= 1000 ? 1 : 0;   // shift + 1000: 10 x 10 windows on the block-per-head kernel instead of the wave-per-unit one
+    shift %= 1000;
     if (B < 1 || res < 1 || ws < 1 || res % ws != 0 || heads < 1 || !xn || !W || !bias || !biasT || !out) return DSG_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
     const int C = 32 * heads, Wp = (ws * ws + 31) / 32 * 32, nW = (res / ws) * (res / ws), nWt = shift > 0 ? nW : 1;
@@ -2241,11 +2270,43 @@ int dsg_debug_qkv_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int
     launch_bias_permute_bx(biasT, bp, nWt * heads, Wp, s);
     BxQkvAttn qa;
     qa.xn = xb; qa.W = wb; qa.bias = bias; qa.biasP = bp; qa.out = ob; qa.B = B; qa.g = WinGeom{res, ws, shift, heads, C};
+    qa.variant = variant;
+    void *qimg = nullptr;
+    float *bfp = nullptr;
+    if (ws == 10 && variant == 0) {
+        if (hipMalloc(&qimg, (size_t)3 * C * C * 2) != hipSuccess) { (void)hipFree(xb); (void)hipFree(wb); (void)hipFree(ob); (void)hipFree(bp); return DSG_ERR_HIP; }
+        launch_qkv_image(wb, qimg, C, heads, s);
+        qa.Wimg = qimg;
+        if (hipMalloc((void **)&bfp, nb * 4) != hipSuccess) { (void)hipFree(xb); (void)hipFree(wb); (void)hipFree(ob); (void)hipFree(bp); (void)hipFree(qimg); (void)hipFree(bfp); return DSG_ERR_HIP; }
+        launch_bias_permute_f32(biasT, bfp, nWt * heads, Wp, s);
+        qa.biasF = bfp;
+    }
     const bool ok = launch_qkv_attn_bx(qa, s);
     if (ok) launch_bf16_to_f32(ob, out, M * C, s);
     if (ok && time_iters > 0 && out_ms) *out_ms = time_launches(s, time_iters, [&]() { (void)launch_qkv_attn_bx(qa, s); });
+    if (ok && ws == 10 && variant == 0 && getenv("DSG_WX_CLK")) {   // dev measurement: phase clocks of one more launch of qkv_attn_wx_kernel
+        const int nunits = B * nW * heads, nb = (nunits + 3) / 4;
+        unsigned long long *dbg = nullptr;
+        if (hipMalloc((void **)&dbg, sizeof(unsigned long long) * nb * 32) == hipSuccess) {
+            (void)hipMemsetAsync(dbg, 0, sizeof(unsigned long long) * nb * 32, s);
+            qa.dbg = dbg;
+            (void)launch_qkv_attn_bx(qa, s);
+            qa.dbg = nullptr;
+            std::vector<unsigned long long> hb((size_t)nb * 32);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(hb.data(), dbg, sizeof(unsigned long long) * hb.size(), hipMemcpyDeviceToHost);
+            double ph[4] = {0, 0, 0, 0};
+            for (int b = 0; b < nb; b++)
+                for (int w = 0; w < 4; w++)
+                    for (int k = 0; k < 4; k++) ph[k] += (double)(hb[((size_t)b * 4 + w) * 8 + k + 1] - hb[((size_t)b * 4 + w) * 8 + k]);
+            const double n = (double)nb * 4;
+            fprintf(stderr, "   qkv_attn_wx phases (kclk per wave, mean of %d blocks): setup + first DMA %.1f | K loop %.1f | q/k/v conversion %.1f | attention + stores %.1f\n",
+                    nb, ph[0] / n / 1e3, ph[1] / n / 1e3, ph[2] / n / 1e3, ph[3] / n / 1e3);
+            (void)hipFree(dbg);
+        }
+    }
     const hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(xb); (void)hipFree(wb); (void)hipFree(ob); (void)hipFree(bp);
+    (void)hipFree(xb); (void)hipFree(wb); (void)hipFree(ob); (void)hipFree(bp); (void)hipFree(qimg); (void)hipFree(bfp);
     if (!ok) return DSG_ERR_INVALID;
     return (e == hipSuccess && hipGetLastError() == hipSuccess) ? DSG_OK : DSG_ERR_HIP;
 }

@@ -119,7 +119,10 @@ bool launch_attn_bx(const void *qkv, const float *biasT, void *out, int B, const
 // QKV projection + window attention fused (no qkv tensor): xn bf16 [B*T, C] (LayerNorm-1 without affine), W bf16 [3C, C] and bias [3C]
 // (gamma / beta and the q scale folded in), biasP = the block's bias tiles in accumulator order as fp16 (launch_bias_permute_bx of the
 // [nWt][heads][Wp][Wp] table), out bf16 [B*T, C].  false: window size / width not covered.
-struct BxQkvAttn { const void *xn = nullptr, *W = nullptr; const float *bias = nullptr; const void *biasP = nullptr; void *out = nullptr; int B = 0; WinGeom g{0, 0, 0, 0, 0}; };
+struct BxQkvAttn { const void *xn = nullptr, *W = nullptr; const float *bias = nullptr; const void *biasP = nullptr; void *out = nullptr; int B = 0; WinGeom g{0, 0, 0, 0, 0};
+                   int variant = 0; const void *Wimg = nullptr; const float *biasF = nullptr; unsigned long long *dbg = nullptr; };   // Wimg: launch_qkv_image of W (the wave-per-unit kernel streams it)
+void launch_qkv_image(const void *Wb, void *img, int C, int heads, hipStream_t s);
+void launch_bias_permute_f32(const float *biasT, float *out, int n_tiles, int Wp, hipStream_t s);   // biasF: the tiles in accumulator order, fp32   // 10 x 10 windows: 0 one wave per (window, head) (qkv_attn_wx_kernel), 1 one block per (window, head) (qkv_attn_bx_kernel)
 bool launch_qkv_attn_bx(const BxQkvAttn &a, hipStream_t s);
 void launch_bias_permute_bx(const float *biasT, void *out_fp16, int n_tiles, int Wp, hipStream_t s);
 void launch_f32_split3(const float *src, void *dst, size_t n, hipStream_t s);

@@ -17,6 +17,7 @@
 //     softmax in the accumulators; P never leaves the register file (the S^T accumulator is the B operand of O^T = V^T P^T).
 //   * ln_bx_kernel: the row pass where no GEMM produces a level's first tensor (after PatchEmbed; rows wider than a tile).
 #include "kernels_common.hip.h"
+#include <type_traits>
 
 namespace dsg {
 
@@ -2048,6 +2049,23 @@ __global__ __launch_bounds__(256) void bias_permute_bx_kernel(const float *__res
     const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
     out[idx] = (_Float16)fmaxf(biasT[(tile * Wp + key) * Wp + q], -60000.f);
 }
+// The tiles in fp32 for qkv_attn_wx_kernel, which loads them straight into the score accumulators (no conversion, no moves), LANE-INTERLEAVED:
+// out[tile][query tile][key tile][quad q][lane][4] -- one load instruction of a wave is one contiguous KiB (whole cache lines; with a lane's
+// 256 bytes contiguous instead, every instruction touched 64 lines and the loads, not the arithmetic, bounded the attention phase).
+__global__ __launch_bounds__(256) void bias_permute_f32_kernel(const float *__restrict__ biasT, float *__restrict__ out, int n_tiles, int Wp) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)n_tiles * Wp * Wp) return;
+    const int KT = Wp / 32;
+    const int e = idx & 3, lane = (idx >> 2) & 63, q = (idx >> 8) & 3, kt = (idx >> 10) % KT, qt = (idx / ((size_t)1024 * KT)) % KT;
+    const size_t tile = idx / ((size_t)Wp * Wp);
+    const int r = 4 * q + e, half = lane >> 5, query = 32 * qt + (lane & 31);
+    const int key = 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+    out[idx] = biasT[(tile * Wp + key) * Wp + query];
+}
+void launch_bias_permute_f32(const float *biasT, float *out, int n_tiles, int Wp, hipStream_t s) {
+    const size_t n = (size_t)n_tiles * Wp * Wp;
+    DSG_LAUNCH(bias_permute_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, biasT, out, n_tiles, Wp);
+}
 void launch_bias_permute_bx(const float *biasT, void *out, int n_tiles, int Wp, hipStream_t s) {
     const size_t n = (size_t)n_tiles * Wp * Wp;
     DSG_LAUNCH(bias_permute_bx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, biasT, (_Float16 *)out, n_tiles, Wp);
@@ -2281,12 +2299,304 @@ __global__ __launch_bounds__(256, DSG_QA_OCC) void qkv_attn_bx_kernel(BxQkvAttn 
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// qkv_attn_wx_kernel -- the same fused QKV projection + window attention with ONE WAVE PER (window, head) unit (10 x 10 windows).
+// What the block-per-head kernel above pays for (tools/qa_exp.sh: its time is the SUM of global loads, LDS staging, K-loop MFMAs and
+// attention arithmetic, ~1/4 each, and 2 blocks per CU run as fast as 4): every wave reads a fresh 1-KB weight fragment per MFMA, every
+// head's block stages the window's 96-KB xn tile again, and the tiles go global -> registers -> LDS.  Here
+//   * a wave owns all 128 positions of its window and the head's 96 QKV columns: 12 accumulator tiles (192 registers, one wave per
+//     SIMD), a weight fragment feeds FOUR MFMAs (one per row tile) and an xn fragment three: 7 KB of LDS reads per 12 MFMAs instead of 16;
+//   * a block is four consecutive units, head fastest: its (at most two) windows' xn rows are staged once for all of them;
+//   * staging is LDS-DMA (global_load_lds_dwordx4 by inline assembly, see mlp384d_bx_kernel): K chunks of 32 in a three-slot ring, ten
+//     requests per wave and chunk with loop-invariant per-lane offsets on a scalar base, one barrier per chunk; the LDS image of a request
+//     is lane-linear, so the bank swizzle (16-byte piece c of row r at slot c ^ ((r >> 2) & 3)) is applied to the SOURCE address;
+//   * the attention is wave-private: k and v^T go through the wave's own LDS region (no block barrier), their fragments are read once
+//     for the unit's four query tiles.
+// -------------------------------------------------------------------------------------------------
+#ifndef DSG_WX_EXP
+#define DSG_WX_EXP 0
+#endif
+// The QKV weight once more in the order qkv_attn_wx_kernel streams and reads it: per (head, 32-deep K chunk) the 96 rows' 6 KB as six
+// fragment blocks (q | k | v) x (k-step 0 | 1), a block = 64 lanes x 16 bytes exactly as an MFMA operand wants them -- a DMA request is one
+// contiguous KiB (whole cache lines: a row-gathered request of 16 x 64-byte row segments runs at half the rate) and a fragment read is
+// lane-linear (no bank conflicts by construction).
+__global__ __launch_bounds__(256) void qkv_img_kernel(const unsigned short *__restrict__ W, unsigned short *__restrict__ img, int C, int heads) {
+    const int nk = C / 32;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;           // one 16-byte piece
+    if (idx >= (size_t)heads * nk * 6 * 64) return;
+    const int lane = idx & 63, blkf = (idx >> 6) % 6, kc = (idx / (6 * 64)) % nk, head = idx / ((size_t)6 * 64 * nk);
+    const int nt = blkf >> 1, s2 = blkf & 1, lrow = lane & 31, lhalf = lane >> 5;
+    const unsigned short *src = W + (size_t)(nt * C + head * 32 + lrow) * C + kc * 32 + 16 * s2 + 8 * lhalf;
+#pragma unroll
+    for (int j = 0; j < 8; j++) img[idx * 8 + j] = src[j];
+}
+void launch_qkv_image(const void *Wb, void *img, int C, int heads, hipStream_t s) {
+    const size_t n = (size_t)heads * (C / 32) * 6 * 64;
+    DSG_LAUNCH(qkv_img_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const unsigned short *)Wb, (unsigned short *)img, C, heads);
+}
+// TWO: a block's four units may lie in two windows (heads not a multiple of 4): two xn slabs per ring slot, three slots; otherwise one slab
+// and FOUR slots -- three chunks (2300 matrix clocks) in flight, which is what the ~2000-clock request latency under load asks for.
+template <bool TWO>
+__global__ __launch_bounds__(256, 1) void qkv_attn_wx_kernel(BxQkvAttn a, int nblk, int U, int G) {
+    constexpr int KT = 4, WS = 10, Wp = 128, Wt = 100, OLD = 40;
+    constexpr int ASZ = 128 * 64, WSZ = 96 * 64, NA = TWO ? 2 : 1, SLOT = NA * ASZ + 4 * WSZ;   // bytes: the windows' rows, four units' weight rows
+    constexpr int NS = TWO ? 3 : 4;                                                           // ring slots
+    __shared__ __attribute__((aligned(16))) char lds[NS * SLOT + 4 * 32 * OLD * 2];           // the ring | a 32 x 32 output tile per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lhalf = lane >> 5;
+    const int heads = a.g.heads, C = a.g.C, res = a.g.res, shift = a.g.shift;
+    const int nwr = res / WS, nW = nwr * nwr, T = res * res;
+    // blocks of one group of G (= the blocks that share a window) run back to back on one XCD
+    const int t = blockIdx.x, xcd = t & 7, seq = t >> 3;
+    const int blk = ((seq / G) * 8 + xcd) * G + seq % G;
+    if (blk >= nblk) return;
+    const int n_units = U * heads;
+    unsigned long long *dbg = a.dbg ? a.dbg + ((size_t)blk * 4 + wave) * 8 : nullptr;   // measurement launches of the debug entry only
+#define WX_STAMP(i) do { if (dbg && lane == 0) dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    WX_STAMP(0);
+    const int uid = min(blk * 4 + wave, n_units - 1);                     // (a wave beyond the last unit repeats it and stores nothing)
+    const bool live = blk * 4 + wave < n_units;
+    const int u = uid / heads, head = uid - u * heads;
+    const int win0 = (blk * 4) / heads, win1 = min(blk * 4 + 3, n_units - 1) / heads;
+    const int aw = u - win0;                                              // the A slot of this wave's window
+    struct Unit { int tb, i0, j0; };
+    auto unit_of = [&](int uu) -> Unit {
+        const int b = uu / nW, w = uu - b * nW, wi = w / nwr, wj = w - wi * nwr;
+        return {b * T, wi * WS + shift, wj * WS + shift};
+    };
+    auto pos_token = [&](const Unit &un, int pos) -> int {               // pos < Wt
+        const int pi = pos / WS, pj = pos - pi * WS;
+        int ti = un.i0 + pi, tj = un.j0 + pj;
+        if (ti >= res) ti -= res;
+        if (tj >= res) tj -= res;
+        return un.tb + ti * res + tj;
+    };
+    const char *xn = static_cast<const char *>(a.xn), *Wq = static_cast<const char *>(a.Wimg) + (size_t)head * (C / 32) * 6144;
+    const unsigned lds0 = (unsigned)(size_t)lds;
+    auto glds = [&](const char *sbase, unsigned voff, unsigned ldsaddr) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory", "m0");
+    };
+    // ---- this wave's DMA requests per chunk: six for its unit's weight rows, two per staged window for the xn rows (wave w: rows 32 w .. + 31) ----
+    unsigned voffA[2][2];
+    const unsigned voffW = (unsigned)lane * 16u;       // the weight image: chunk kc of this head is one contiguous 6 KB, request i its i-th KiB
+#pragma unroll
+    for (int w2 = 0; w2 < 2; w2++) {
+        const Unit un = unit_of(w2 ? win1 : win0);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int P = (wave * 2 + i) * 64 + lane, row = P >> 2, cp = (P & 3) ^ ((row >> 2) & 3);
+            const int tk = pos_token(un, row < Wt ? row : 0);            // padding positions repeat position 0: finite values, never used
+            voffA[w2][i] = ((unsigned)tk * (unsigned)C) * 2u + (unsigned)cp * 16u;
+        }
+    }
+    const int nk = C / 32;
+    const bool two = TWO && win1 != win0;
+    const int npc = two ? 10 : 8;              // requests per wave and chunk
+    auto wait_vm = [&](int n) {                // s_waitcnt vmcnt(n) for the counts that occur (the immediate is an instruction field)
+        switch (n) { case 0: M384_WAIT_VM(0); break; case 8: M384_WAIT_VM(8); break; case 10: M384_WAIT_VM(10); break;
+                     case 16: M384_WAIT_VM(16); break; default: M384_WAIT_VM(20); break; }
+    };
+    // request i (0 .. 9) of chunk kc: 0-1 first window's rows, 2-3 second window's (when the block has one), 4-9 weight rows
+    auto dma_req = [&](int kc, int i) {
+        const unsigned base = lds0 + (kc % NS) * SLOT;
+        if (i < 2) glds(xn + kc * 64, voffA[0][i], base + (wave * 2 + i) * 1024);
+        else if (i < 4) { if (two) glds(xn + kc * 64, voffA[1][i - 2], base + ASZ + (wave * 2 + i - 2) * 1024); }   // (uniform: the block's second window, if it has one)
+        else glds(Wq + kc * 6144 + (i - 4) * 1024, voffW, base + NA * ASZ + wave * WSZ + (i - 4) * 1024);
+    };
+    // accumulators: q and k as D[feature][position] (lane = position: the B operand of S^T = K Q^T and, for the keys, its A operand --
+    // every key tile of the window belongs to this wave, so k never leaves the registers); v with the operands SWAPPED, D[position][feature]
+    // (lane = feature, registers = positions in exactly the order the probabilities' B operand has its keys): the A operand of O^T = V^T P^T.
+    f32x16 aq[4], ak[4], av[4];                // (written by the first chunk's MFMAs, whose C operand is the constant 0: no initialisation pass)
+#pragma unroll
+    for (int c = 0; c < NS - 1; c++)           // (C >= 96: at least three chunks)
+#pragma unroll
+        for (int i = 0; i < 10; i++) dma_req(c, i);
+    WX_STAMP(1);
+    // fragment addresses: row (32 tile + lrow), k-step s of the chunk -> slot ((2 s + lhalf) ^ ((lrow >> 2) & 3))
+    const int sw = (lrow >> 2) & 3;
+    const int fo0 = lrow * 64 + ((lhalf ^ sw) << 4), fo1 = lrow * 64 + (((2 + lhalf) ^ sw) << 4);
+    struct Frag { bf16x8 w[3], x[4]; };
+    auto fread = [&](Frag &f, int kc, int fo, int s2) {
+        const char *ab = lds + (kc % NS) * SLOT + aw * ASZ + fo, *wb = lds + (kc % NS) * SLOT + NA * ASZ + wave * WSZ + s2 * 1024 + lane * 16;
+#pragma unroll
+        for (int nt = 0; nt < 3; nt++) f.w[nt] = *reinterpret_cast<const bf16x8 *>(wb + nt * 2048);
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++) f.x[rt] = *reinterpret_cast<const bf16x8 *>(ab + rt * 2048);
+    };
+    wait_vm((NS - 2) * npc);                   // chunk 0 has landed (the later chunks' requests may be in flight)
+    M384_BARRIER();
+    Frag f0, f1;
+    fread(f0, 0, fo0, 0);
+    // One chunk: k-step 0 from f0 (read behind the previous barrier) while f1 is being read, then k-step 1 from f1 while the next chunk's f0
+    // is.  FIRST: the accumulators start here (C = 0).  MORE: chunk kc + NS - 1's requests go out between the MFMAs (its slot was chunk
+    // kc - 1's: every wave passed the last barrier behind its reads of it).  Separate instantiations, so that each is one basic block per
+    // half -- a run-time `if` around every request cut the stream into ten pieces and cost a full lgkmcnt(0) at the top.
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto chunk = [&](int kc, auto first_c, auto more_c) {
+        constexpr bool FIRST = decltype(first_c)::value, MORE = decltype(more_c)::value && DSG_WX_EXP != 1;
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++) {
+            if (DSG_WX_EXP != 2) aq[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.w[0], f0.x[rt], FIRST ? zero16 : aq[rt], 0, 0, 0);
+            if (rt == 0) {                     // f1's reads are issued BEHIND the first MFMA: the wait in front of it covers f0 only
+                __builtin_amdgcn_sched_barrier(0);
+                if (DSG_WX_EXP != 3 || kc == 0) fread(f1, kc, fo1, 1);
+            }
+            if (MORE) dma_req(kc + NS - 1, 3 * rt);
+            if (DSG_WX_EXP != 2) ak[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.w[1], f0.x[rt], FIRST ? zero16 : ak[rt], 0, 0, 0);
+            if (MORE && rt < 3) dma_req(kc + NS - 1, 3 * rt + 1);
+            if (DSG_WX_EXP != 2) av[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0.x[rt], f0.w[2], FIRST ? zero16 : av[rt], 0, 0, 0);
+            if (MORE && rt < 3) dma_req(kc + NS - 1, 3 * rt + 2);
+        }
+        if (kc + 1 < nk) {
+            // this wave's share of chunk kc + 1 has landed: at most the requests of the NS - 2 chunks behind it are in flight
+            const int later = min(nk - 1, kc + NS - 1) - (kc + 1);
+            wait_vm(later * npc);
+            M384_WAIT_LGKM0();                 // ... and its reads of chunk kc are complete
+            if (DSG_WX_EXP != 4) M384_BARRIER();
+            if (DSG_WX_EXP != 3) fread(f0, kc + 1, fo0, 0);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++) {
+            if (DSG_WX_EXP != 2) aq[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.w[0], f1.x[rt], aq[rt], 0, 0, 0);
+            if (DSG_WX_EXP != 2) ak[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.w[1], f1.x[rt], ak[rt], 0, 0, 0);
+            if (DSG_WX_EXP != 2) av[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1.x[rt], f1.w[2], av[rt], 0, 0, 0);
+        }
+    };
+    chunk(0, std::true_type{}, std::true_type{});                              // (nk >= NS: chunk 0 always has a request to send)
+    for (int kc = 1; kc + NS - 1 < nk; kc++) chunk(kc, std::false_type{}, std::true_type{});
+    for (int kc = max(1, nk - NS + 1); kc < nk; kc++) chunk(kc, std::false_type{}, std::false_type{});
+    WX_STAMP(2);
+    // ---- bias, then everything the attention needs as bf16 operand fragments, in registers ----
+    bf16x8 qf[4][2], kf[KT][2], vf[KT][2];
+    {   // q | k bias per feature = register pair (packed adds); v's bias per feature = lane
+        f32x4 bq[4], bk[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            bq[q] = *reinterpret_cast<const f32x4 *>(a.bias + head * 32 + 8 * q + 4 * lhalf);
+            bk[q] = *reinterpret_cast<const f32x4 *>(a.bias + C + head * 32 + 8 * q + 4 * lhalf);
+        }
+        const float bv = a.bias[2 * C + head * 32 + lrow];
+        const f32x2_t bv2 = {bv, bv};
+#pragma unroll
+        for (int rt = 0; rt < 4; rt++)
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                u32x4 pq, pk, pv;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) {
+                    const int r = 8 * s + 2 * jj;
+                    const f32x2_t q2 = (f32x2_t){aq[rt][r], aq[rt][r + 1]} + (f32x2_t){bq[r >> 2][r & 3], bq[r >> 2][(r & 3) + 1]};
+                    const f32x2_t k2 = (f32x2_t){ak[rt][r], ak[rt][r + 1]} + (f32x2_t){bk[r >> 2][r & 3], bk[r >> 2][(r & 3) + 1]};
+                    const f32x2_t v2 = (f32x2_t){av[rt][r], av[rt][r + 1]} + bv2;
+                    pq[jj] = pack_bf16(q2[0], q2[1]);
+                    pk[jj] = pack_bf16(k2[0], k2[1]);
+                    pv[jj] = pack_bf16(v2[0], v2[1]);
+                }
+                qf[rt][s] = __builtin_bit_cast(bf16x8, pq);
+                kf[rt][s] = __builtin_bit_cast(bf16x8, pk);
+                vf[rt][s] = __builtin_bit_cast(bf16x8, pv);
+            }
+    }
+    WX_STAMP(3);
+    const int w_of_u = u % nW;
+    const Unit uo = unit_of(u);
+    const rsrc_t rsO = make_rsrc(a.out, (unsigned)((size_t)a.B * T * C * 2u));
+    const unsigned OOB = 0x7fffffffu;
+    __bf16 *Tq = reinterpret_cast<__bf16 *>(lds + NS * SLOT) + wave * 32 * OLD;
+    // the bias tile (fp32, accumulator order, lane-interleaved: bias_permute_f32_kernel) is loaded straight into the score accumulators, one query tile ahead
+    const f32x4 *bp0 = reinterpret_cast<const f32x4 *>(a.biasF) + ((size_t)(shift > 0 ? w_of_u : 0) * heads + head) * (Wp * Wp / 4) + lane;
+    f32x16 sbuf[2][KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const f32x4 v4 = bp0[(4 * kt + q) * 64];
+            sbuf[0][kt][4 * q] = v4[0]; sbuf[0][kt][4 * q + 1] = v4[1]; sbuf[0][kt][4 * q + 2] = v4[2]; sbuf[0][kt][4 * q + 3] = v4[3];
+        }
+#pragma unroll
+    for (int qt = 0; qt < 4; qt++) {
+        if (qt + 1 < 4) {
+            const f32x4 *bp = bp0 + (size_t)(qt + 1) * (KT * 4 * 64);
+#pragma unroll
+            for (int kt = 0; kt < KT; kt++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const f32x4 v4 = bp[(4 * kt + q) * 64];
+                    sbuf[(qt + 1) & 1][kt][4 * q] = v4[0]; sbuf[(qt + 1) & 1][kt][4 * q + 1] = v4[1]; sbuf[(qt + 1) & 1][kt][4 * q + 2] = v4[2]; sbuf[(qt + 1) & 1][kt][4 * q + 3] = v4[3];
+                }
+        }
+        f32x16 sacc[KT];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+            sacc[kt] = sbuf[qt & 1][kt];
+#pragma unroll
+            for (int s = 0; s < 2; s++) sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][s], qf[qt][s], sacc[kt], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (32 * kt + 8 * (r >> 2) < Wt) mx = fmaxf(mx, sacc[kt][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        f32x2_t sum2 = {0.f, 0.f};
+        const f32x2_t mx2 = {mx, mx};
+        f32x16 oacc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) {
+            u32x4 pf[2];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                if (32 * kt + 8 * (r >> 2) < Wt) {
+                    const f32x2_t d = (f32x2_t){sacc[kt][r], sacc[kt][r + 1]} - mx2;          // v_pk_add_f32
+                    const f32x2_t e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+                    sum2 += e;
+                    pf[r >> 3][(r & 7) >> 1] = pack_bf16(e[0], e[1]);
+                } else {
+                    pf[r >> 3][(r & 7) >> 1] = 0u;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+                if (32 * kt + 16 * s < Wt) oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[kt][s], __builtin_bit_cast(bf16x8, pf[s]), oacc, 0, 0, 0);
+        }
+        float sum = sum2[0] + sum2[1];
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = fast_rcp(sum);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = oacc[4 * q + e] * inv;
+            *reinterpret_cast<u32x2 *>(Tq + lrow * OLD + 8 * q + 4 * lhalf) = pack_bf16x4(o);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int r = (lane >> 2) + 16 * k, pc = lane & 3, pos = 32 * qt + r;
+            const int tq = (live && pos < Wt) ? pos_token(uo, pos) : -1;
+            const u32x4 d = *reinterpret_cast<const u32x4 *>(Tq + r * OLD + 8 * pc);
+            buf_store_u4(d, rsO, tq < 0 ? OOB : ((unsigned)tq * (unsigned)C + (unsigned)(head * 32 + 8 * pc)) * 2u, 0u);
+        }
+    }
+    WX_STAMP(4);
+#undef WX_STAMP
+}
+
 bool launch_qkv_attn_bx(const BxQkvAttn &a, hipStream_t s) {
     const WinGeom &g = a.g;
     if (!a.xn || !a.W || !a.bias || !a.biasP || !a.out || a.B < 1) return false;
     if (g.C != 32 * g.heads || g.C % 8 != 0 || g.C < 96 || g.res % g.ws != 0) return false;
     if ((size_t)a.B * g.res * g.res * g.C * 2u >= 0x7fffffffull) return false;   // 32-bit buffer offsets
     const int nW = (g.res / g.ws) * (g.res / g.ws), U = a.B * nW;
+    if (g.ws == 10 && a.variant == 0 && a.Wimg && a.biasF) {   // one wave per (window, head): qkv_attn_wx_kernel
+        if ((size_t)3 * g.C * g.C * 2u >= 0x7fffffffull) return false;
+        const int n_units = U * g.heads, nblk = (n_units + 3) / 4, G = (g.heads + 3) / 4;
+        const int groups = (nblk + G - 1) / G;
+        const dim3 grid((unsigned)(((groups + 7) / 8) * 8 * G)), block(256);
+        if (g.heads % 4 == 0) DSG_LAUNCH(qkv_attn_wx_kernel<false>, grid, block, 0, s, a, nblk, U, G);
+        else DSG_LAUNCH(qkv_attn_wx_kernel<true>, grid, block, 0, s, a, nblk, U, G);
+        return true;
+    }
     int kt;
     switch (g.ws) { case 4: case 5: kt = 1; break; case 8: kt = 2; break; case 10: kt = 4; break; default: return false; }
     const int upb = 4 / kt, nblk = (U + upb - 1) / upb;

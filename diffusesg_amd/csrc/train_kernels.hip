@@ -384,6 +384,8 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
             return;
         }
     }
+    static const bool log_plain = getenv("DSG_TGEMM_LOG") != nullptr;   // dev: which products still run on the plain kernel
+    if (log_plain) fprintf(stderr, "t_gemm plain: ta %d tb %d M %d N %d K %d lda %d ldb %d ldc %d bias %d acc %d act %d\n", (int)ta, (int)tb, M, N, K, lda, ldb, ldc, bias != nullptr, (int)accumulate, act);
     dim3 grid((N + 31) / 32, (M + 31) / 32), block(256);
     // weight gradients (K = tokens, M x N = the weight): few output tiles, long K -> split K over up to 64 slices of >= 1024 and add
     // the partial products in slice order (deterministic)

@@ -127,7 +127,9 @@ def test_attn_bx_vs_torch(B, res, ws, shift, heads):
 
 @pytest.mark.parametrize("B,res,ws,shift,heads", [(3, 10, 10, 0, 12), (5, 20, 10, 5, 6), (2, 40, 10, 0, 3), (4, 16, 8, 4, 12), (3, 8, 8, 0, 24),
                                                   (5, 16, 8, 0, 3), (2, 16, 4, 2, 3), (7, 4, 4, 0, 6), (3, 10, 5, 2, 3),
-                                                  (48, 20, 10, 5, 6), (41, 16, 8, 4, 12)])   # > 512 (window group, head) tiles
+                                                  (48, 20, 10, 5, 6), (41, 16, 8, 4, 12),    # > 512 (window group, head) tiles
+                                                  (3, 10, 10, 1000, 12), (5, 20, 10, 1005, 6), (2, 40, 10, 1000, 3),   # shift + 1000: the block-per-head kernel at 10 x 10
+                                                  (1, 10, 10, 0, 3), (7, 10, 10, 0, 6), (3, 20, 10, 5, 3)])            # units not a multiple of 4, blocks across two windows
 def test_qkv_attn_bx_vs_torch(B, res, ws, shift, heads):
     """QKV projection + window attention in one kernel against fp64 on the bf16-rounded operands: q, k, v are formed in fp32, rounded
     to bf16 (as the kernel hands them to the second and third product) and then follow test_attn_bx_vs_torch's reference.  Odd unit
@@ -135,6 +137,7 @@ def test_qkv_attn_bx_vs_torch(B, res, ws, shift, heads):
     inside a 64-deep chunk) up to 768."""
     from diffusesg_amd import lib as L
     lib = L.load()
+    variant, shift = divmod(shift, 1000)               # 10 x 10 windows: 0 the wave-per-unit kernel, 1 the block-per-head kernel
     Cc, T, Wt = 32 * heads, res * res, ws * ws
     Wp = (Wt + 31) // 32 * 32
     nW = (res // ws) ** 2
@@ -149,15 +152,15 @@ def test_qkv_attn_bx_vs_torch(B, res, ws, shift, heads):
         bias[torch.rand(nWt, 1, Wp, Wp, device="cuda", generator=gen).expand(-1, heads, -1, -1) < 0.2] -= 144.0
     bias[:, :, Wt:, :] = -1.0e30
     out = torch.full((B * T, Cc), float("nan"), device="cuda")
-    rc = lib.dsg_debug_qkv_attn_bx(B, res, ws, shift, heads, _p(xn), _p(W), _p(bqkv), _p(bias.contiguous()), _p(out), 0, None, None)
+    rc = lib.dsg_debug_qkv_attn_bx(B, res, ws, shift + 1000 * variant, heads, _p(xn), _p(W), _p(bqkv), _p(bias.contiguous()), _p(out), 0, None, None)
     assert rc == 0
     qkv = _bf((_bf(xn).double() @ _bf(W).double().t() + bqkv.double()).float())
     tok = torch.from_numpy(_window_tokens(res, ws, shift)).cuda()
     x = qkv.double().view(B, T, 3, heads, 32)
     xw = x[:, tok]
     q, k, v = xw[..., 0, :, :].permute(0, 1, 3, 2, 4), xw[..., 1, :, :].permute(0, 1, 3, 2, 4), xw[..., 2, :, :].permute(0, 1, 3, 2, 4)
-    # the kernel reads the bias tile as fp16
-    bt = bias[:, :, :Wt, :Wt].clamp(min=-60000.0).half().double()
+    # the block-per-head kernel reads the bias tile as fp16, the wave-per-unit one (10 x 10 windows, variant 0) as fp32
+    bt = bias[:, :, :Wt, :Wt].double() if (ws == 10 and variant == 0) else bias[:, :, :Wt, :Wt].clamp(min=-60000.0).half().double()
     s = torch.einsum("bwhkd,bwhqd->bwhkq", k, q) + (bt[None] if shift > 0 else bt[None].expand(1, nW, -1, -1, -1))
     e = torch.exp2(s - s.max(dim=3, keepdim=True).values)
     o = torch.einsum("bwhkq,bwhkd->bwhqd", _bf(e.float()).double(), v) / e.sum(dim=3)[..., None]

@@ -98,7 +98,7 @@ def qkv_attn(tag, B, res, ws, shift, heads):
     g = torch.Generator(device="cuda").manual_seed(4)
     Cc, T = 32 * heads, res * res
     Wp = (ws * ws + 31) // 32 * 32
-    nWt = (res // ws) ** 2 if shift else 1
+    nWt = (res // ws) ** 2 if shift % 1000 else 1
     xn = torch.randn(B * T, Cc, device="cuda", generator=g)
     W = torch.randn(3 * Cc, Cc, device="cuda", generator=g) / Cc ** 0.5
     W[:Cc] *= 0.25
@@ -136,11 +136,20 @@ if __name__ == "__main__":
         projmlp("L1 proj + MLP fused (mod, LN)", M1, 192)
         projmlp("L0 proj + MLP fused (copy)", M0, 96, mod=0, out_mode=2)
         sys.exit(0)
+    if only == "wx":    # the wave-per-unit QKV + attention kernel alone (DSG_WX_CLK=1: phase clocks)
+        qkv_attn("L2 qkv + attn fused", B, 10, 10, 0, 12)
+        qkv_attn("L1 qkv + attn fused, shifted", B, 20, 10, 5, 6)
+        qkv_attn("L0 qkv + attn fused", B, 40, 10, 0, 3)
+        sys.exit(0)
     if only == "qa":    # the fused QKV + attention kernel alone
         qkv_attn("L2 qkv + attn fused", B, 10, 10, 0, 12)
         qkv_attn("L1 qkv + attn fused", B, 20, 10, 0, 6)
         qkv_attn("L1 qkv + attn fused, shifted", B, 20, 10, 5, 6)
         qkv_attn("L0 qkv + attn fused", B, 40, 10, 0, 3)
+        qkv_attn("L2 qkv + attn, block per head", B, 10, 10, 1000, 12)
+        qkv_attn("L1 qkv + attn, block per head", B, 20, 10, 1000, 6)
+        qkv_attn("L1 qkv + attn, block per head, shifted", B, 20, 10, 1005, 6)
+        qkv_attn("L0 qkv + attn, block per head", B, 40, 10, 1000, 3)
         sys.exit(0)
     gemm("L2 qkv", M2, 1152, 384)
     gemm("L2 proj (res, LN)", M2, 384, 384, res=1, ln=1)
