@@ -1080,13 +1080,15 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
     auto dma_stage = [&](const char *src, int r) {      // src, r: wave-uniform -> scalar base + one 32-bit lane offset
         const char *sbase = src + wave * 6144;
         char *dbase = lds + r * M384_STAGE + wave * 6144;
+        // (M0 is not on the clobber list -- the compiler calls it reserved and warns; it only ever writes M0 itself immediately in front of an
+        // instruction that reads it, none of which these kernels contain besides the requests themselves.)
         // (inline assembly, not __builtin_amdgcn_global_load_lds: the compiler's wait-count pass books the builtin as a FLAT access that may
         // touch LDS and memory, and while one is pending every s_waitcnt it inserts -- the fragment reads' lgkmcnt, ordinary loads' vmcnt --
         // becomes a full drain.  M0 = the LDS address, one wait state between its write and the request.)
         const unsigned dlds = (unsigned)(size_t)dbase;
 #pragma unroll
         for (int i = 0; i < 6; i++)
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dlds + i * 1024), "v"(dma_voff), "s"(sbase + i * 1024) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dlds + i * 1024), "v"(dma_voff), "s"(sbase + i * 1024) : "memory");
     };
     // the normalised row of the lane's token as fc1's B operand, k-step s = channels 16 s + 4 half + {0..3, 8..11}: xo = the k-steps
     // 12 kh .. + 11 (the channels this wave's proj / fc2 half owns), xp = the partner's 12 (fc1 walks own, then partner's: the order
@@ -1118,7 +1120,7 @@ __global__ __launch_bounds__(512, 1) void mlp384d_bx_kernel(BxMlp g) {
             for (int k = 0; k < 12; k++) {
                 const int P = (wave * 12 + k) * 64 + lane, r = P / 48, cp = P - 48 * r, c = (cp & 48) | ((cp ^ r) & 15);
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"((unsigned)(size_t)lds + M384_STAGE + (wave * 12 + k) * 1024),
-                             "v"(asrc + ((size_t)min(r, rows - 1) * 48 + c) * 16) : "memory", "m0");
+                             "v"(asrc + ((size_t)min(r, rows - 1) * 48 + c) * 16) : "memory");
             }
         }
         M384_WAIT_VM(0);
@@ -1472,10 +1474,10 @@ __global__ __launch_bounds__(256, 1) void mlp384s_bx_kernel(BxMlp g) {
     // then stall every fourth MFMA).  M0 carries the LDS address (wave-uniform), one wait state between its write and the request.
     const unsigned lds0 = (unsigned)(size_t)lds;
     auto glds_s = [&](const char *sbase, unsigned voff, unsigned ldsaddr) {        // uniform base + per-lane 32-bit offset
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory");
     };
     auto glds_v = [&](const char *vptr, unsigned ldsaddr) {                        // per-lane address
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(ldsaddr), "v"(vptr) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(ldsaddr), "v"(vptr) : "memory");
     };
     auto dma_piece = [&](const char *src, int slot, int i) {   // piece i (0 .. 11) of this wave's share of a stage
         glds_s(src + wave * 12288 + i * 1024, dma_voff, lds0 + slot * M384_STAGE + wave * 12288 + i * 1024);
@@ -2310,6 +2312,10 @@ __global__ __launch_bounds__(256, DSG_QA_OCC) void qkv_attn_bx_kernel(BxQkvAttn 
 //   * staging is LDS-DMA (global_load_lds_dwordx4 by inline assembly, see mlp384d_bx_kernel): K chunks of 32 in a three-slot ring, ten
 //     requests per wave and chunk with loop-invariant per-lane offsets on a scalar base, one barrier per chunk; the LDS image of a request
 //     is lane-linear, so the bank swizzle (16-byte piece c of row r at slot c ^ ((r >> 2) & 3)) is applied to the SOURCE address;
+//   * (tried, not kept: PERSISTENT blocks that request the next set's first chunks during the attention phase -- the per-set setup and first
+//     wait (2.7k clocks) disappear, but every s_waitcnt vmcnt the compiler puts in front of a bias-tile use then also waits for those
+//     ~90 KB of requests, which are younger but counted by the same in-order counter: the attention phase grew by 2.4k clocks, L2 97 -> 107 us.
+//     It needs the bias loads in assembly with hand-counted waits as well.)
 //   * the attention is wave-private: k and v^T go through the wave's own LDS region (no block barrier), their fragments are read once
 //     for the unit's four query tiles.
 // -------------------------------------------------------------------------------------------------
@@ -2374,7 +2380,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_wx_kernel(BxQkvAttn a, int nb
     const char *xn = static_cast<const char *>(a.xn), *Wq = static_cast<const char *>(a.Wimg) + (size_t)head * (C / 32) * 6144;
     const unsigned lds0 = (unsigned)(size_t)lds;
     auto glds = [&](const char *sbase, unsigned voff, unsigned ldsaddr) {
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(ldsaddr), "v"(voff), "s"(sbase) : "memory");
     };
     // ---- this wave's DMA requests per chunk: six for its unit's weight rows, two per staged window for the xn rows (wave w: rows 32 w .. + 31) ----
     unsigned voffA[2][2];
