@@ -2516,7 +2516,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_wx_kernel(BxQkvAttn a, int nb
     for (int kt = 0; kt < KT; kt++)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const f32x4 v4 = bp0[(4 * kt + q) * 64];
+            const f32x4 v4 = 32 * kt + 8 * q < Wt ? bp0[(4 * kt + q) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};   // (quads of padding keys: never looked at)
             sbuf[0][kt][4 * q] = v4[0]; sbuf[0][kt][4 * q + 1] = v4[1]; sbuf[0][kt][4 * q + 2] = v4[2]; sbuf[0][kt][4 * q + 3] = v4[3];
         }
 #pragma unroll
@@ -2527,7 +2527,7 @@ __global__ __launch_bounds__(256, 1) void qkv_attn_wx_kernel(BxQkvAttn a, int nb
             for (int kt = 0; kt < KT; kt++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const f32x4 v4 = bp[(4 * kt + q) * 64];
+                    const f32x4 v4 = 32 * kt + 8 * q < Wt ? bp[(4 * kt + q) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
                     sbuf[(qt + 1) & 1][kt][4 * q] = v4[0]; sbuf[(qt + 1) & 1][kt][4 * q + 1] = v4[1]; sbuf[(qt + 1) & 1][kt][4 * q + 2] = v4[2]; sbuf[(qt + 1) & 1][kt][4 * q + 3] = v4[3];
                 }
         }
