@@ -168,7 +168,13 @@ int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t
  *   "bf16_act" (0 / 1 / 2, default 2; acts only with "gemm_bf16"): 1 -- tensors whose only consumer is the bf16 GEMM (the MLP's
  *       hidden activations, the attention output) are stored as bf16 by their producer; the consumer rounds its A operand to bf16
  *       anyway, so results are bit-identical to 0, with half the bytes and no conversion in the consumer.  2 -- q, k, v are
- *       stored as bf16 as well; the attention arithmetic stays fp32 on the widened values, results move within the mode's bar. */
+ *       stored as bf16 as well; the attention arithmetic stays fp32 on the widened values, results move within the mode's bar.
+ *   "bf16_pipe" (default 1; acts only with "gemm_bf16"): the bf16 block pipeline -- a Swin block is two kernels with bf16 tensors between
+ *       them; its kernel choices (all parity-tested, same bar): "bf16_qkv_attn" 1 QKV projection + window attention in one kernel (10 x 10
+ *       windows: one wave per (window, head)), 2 the block-per-head kernel everywhere, 3 the former only where a block of four units lies in
+ *       one window, 0 GEMM + attention kernel; "bf16_mlp" 1 fused fc1-GELU-fc2 (C = 384: eight waves, weight images streamed by LDS-DMA),
+ *       4 round 3's eight-wave kernel, 5 the one-wave-per-SIMD LDS-DMA kernel, 2 four waves at every width, 3 GEMM pair at C = 384,
+ *       0 GEMM pairs; "bf16_proj_mlp" 1 proj + residual + LayerNorm-2 in front of the MLP kernel; "bf16_readout" 1 the read-out on the bf16 pipe. */
 int dsg_set_option(dsg_handle h, const char *name, int32_t value);
 /* The value an option currently has on this handle (what the next forward will run with), whichever way it was set
  * (dsg_set_option or a DSG_* environment default): measurement code reports the precision mode from here. */
@@ -235,7 +241,8 @@ int dsg_debug_gemm_bx(int32_t M, int32_t N, int32_t K, const float *A, const flo
 int dsg_debug_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int32_t heads, const float *qkv, const float *biasT, float *out,
                       int32_t time_iters, float *out_ms, void *stream);
 /* the fused QKV projection + window attention kernel on caller-provided operands: xn [B*res*res, C] (C = 32 heads), W [3C, C] (q rows
- * pre-scaled by d^-1/2 log2 e), bias [3C], biasT as above; operands are rounded to bf16 on the way in, out is the bf16 result as fp32 */
+ * pre-scaled by d^-1/2 log2 e), bias [3C], biasT as above; operands are rounded to bf16 on the way in, out is the bf16 result as fp32.
+ * Kernel selection for 10 x 10 windows: the wave-per-(window, head) kernel; shift + 1000 selects the block-per-head kernel instead. */
 int dsg_debug_qkv_attn_bx(int32_t B, int32_t res, int32_t ws, int32_t shift, int32_t heads, const float *xn, const float *W, const float *bias,
                           const float *biasT, float *out, int32_t time_iters, float *out_ms, void *stream);
 /* the fused MLP kernel with the attention half's tail in front: x <- [modulate] (x1 + fc2(GELU(fc1(LN(x1))))), x1 = x + att Wp^T + bp;
@@ -245,7 +252,9 @@ int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const
                          void *stream);
 /* dsg_debug_mlp_bx: the fused MLP half of a block, x [M,C] <- [modulate] (x + fc2(GELU(fc1(xn)))) in place, with xn [M,C], W1 [4C,C],
  *   W2 [C,4C] given as fp32 and rounded to bf16 inside; mod = (scale [C] | shift [C]) or NULL; out_mode 0 none, 1 LayerNorm of the
- *   stored row, 2 its plain copy -> out_xn [M,C] (the bf16 store widened).  C in {96, 192, 384}. */
+ *   stored row, 2 its plain copy -> out_xn [M,C] (the bf16 store widened).  C in {96, 192, 384}.
+ *   Kernel selection at C = 384 (both entries): out_mode as is = the LDS-DMA kernel on pre-arranged weight images; + 16 the four-wave
+ *   kernel of the narrower levels (dsg_debug_mlp_bx only); + 32 round 3's eight-wave kernel; + 64 the one-wave-per-SIMD LDS-DMA kernel. */
 int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *mod, int32_t out_mode, float *out_xn, int32_t time_iters, float *out_ms, void *stream);
 
