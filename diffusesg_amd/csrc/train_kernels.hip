@@ -221,6 +221,13 @@ __global__ __launch_bounds__(256) void t_transpose_sliced_kernel(const float *sr
     for (int i = ty; i < 32; i += 8)
         if (c0 + i < Cc && k0 + tx < kslice) dst[((size_t)z * Cc + c0 + i) * kslice + k0 + tx] = tile[tx][i];
 }
+// W [N][K] (pitch ld) -> [N][Kp] with zero columns K .. Kp - 1 (t_gemm: a K that is not a multiple of the GEMM's 32-deep chunk)
+__global__ void t_pad_cols_kernel(const float *__restrict__ W, int ld, float *__restrict__ out, int N, int K, int Kp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)N * Kp) return;
+    const int n = (int)(i / Kp), k = (int)(i % Kp);
+    out[i] = k < K ? W[(size_t)n * ld + k] : 0.f;
+}
 // ---------------------------------------------------------------------------------------------------------------------
 // Weight gradients on the f32 matrix pipe without transposes:  C[M,N] = sum_k A[k][m] B[k][n]  (dW = dy^T x: A = dy [tokens, out],
 // B = x [tokens, in], both as the forward left them, K = tokens).  v_mfma_f32_32x32x2_f32 takes ONE value per lane and operand
@@ -335,10 +342,21 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
     // [N,K]): large ones go to gemm4_f32_kernel (dx after transposing the weight into a scratch tile).  The weight-gradient
     // products (ta: K = tokens) and everything small or oddly shaped stay on the plain kernel below.
     static const bool use_mfma = getenv("DSG_TRAIN_PLAIN_GEMM") == nullptr;
-    if (use_mfma && !ta && M >= 512 && K % 32 == 0 && N % 32 == 0 && lda == K && (size_t)N * K <= ((size_t)32 << 20)) {
+    // (K not a multiple of the 32-deep chunk -- PatchEmbed's 60 input channels: the weight goes into the scratch tile zero-padded to Kp
+    // columns; the activation rows keep their pitch, the chunk's overhang reads the next row's first values (finite) against those zeros,
+    // and past the last row the buffer descriptor returns zeros)
+    const int Kp = (K + 31) / 32 * 32;
+    if (use_mfma && !ta && M >= 512 && N % 32 == 0 && lda == K && (K % 32 == 0 || (tb && lda % 4 == 0 && !res && !accumulate)) && (size_t)N * Kp <= ((size_t)32 << 20)) {
         const float *Wop = B;
         bool ok = true;
-        if (tb) ok = ldb == K;
+        if (tb && K % 32 != 0) {
+            float *wt = t_scratch_get(s, ts.wt, ts.wt_cap, (size_t)N * Kp, ts);
+            ok = wt != nullptr;
+            if (ok) {
+                hipLaunchKernelGGL(t_pad_cols_kernel, dim3((unsigned)(((size_t)N * Kp + 255) / 256)), dim3(256), 0, s, B, ldb, wt, N, K, Kp);
+                Wop = wt;
+            }
+        } else if (tb) ok = ldb == K;
         else {
             float *wt = t_scratch_get(s, ts.wt, ts.wt_cap, (size_t)N * K, ts);
             ok = wt != nullptr;
@@ -349,7 +367,7 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
         }
         if (ok) {
             GemmArgs g;
-            g.A = A; g.lda = K; g.K1 = K; g.K = K; g.M = M; g.N = N; g.W = Wop; g.bias = bias; g.C = C; g.ldc = ldc;
+            g.A = A; g.lda = K; g.K1 = Kp; g.K = Kp; g.M = M; g.N = N; g.W = Wop; g.bias = bias; g.C = C; g.ldc = ldc;
             if (res) { g.res = res; g.ldres = ldc; }
             else if (accumulate) { g.res = C; g.ldres = ldc; }
             g.act = act;
@@ -367,7 +385,10 @@ void t_gemm(bool ta, bool tb, const float *A, int lda, const float *B, int ldb, 
     C = C_plain;
     // Weight gradients dW [M = out, N = in] = dy^T x with K = tokens: gemm_tn_f32_kernel reads both token-major operands as they
     // are (no transposed copies), S slices of K in one launch, partial products added in slice order.
-    if (use_mfma && ta && !tb && !bias && K >= 2048 && M % 4 == 0 && N % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0) {
+    // (M, N, lda, ldb need not be multiples of 4: a 16-byte buffer load wants dword alignment only, what a row's last load reads of the
+    // next row lands in rows / columns >= M / N, which the epilogue drops, and past the slice the descriptor returns zeros -- the
+    // adjacency head's 6-wide layer ran on the plain kernel with 64 blocks for K = 262144)
+    if (use_mfma && ta && !tb && !bias && K >= 2048) {
         const int tiles_m = (M + 127) / 128, tiles_n = (N + 95) / 96;
         int S = std::max(1, std::min(256, 1024 / (tiles_m * tiles_n)));   // ~1024 blocks: two rounds of the chip's 512 slots
         S = std::max(1, std::min(S, K / 512));
