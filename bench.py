@@ -306,7 +306,7 @@ def worker(args):
         traffic, traffic_src = None, None
         prof_root = os.path.join(ROOT, "profiles")
         # (file, kernel family, condition): the committed PMC passes exist for the headline workload and for configs[4]'s per-GPU share
-        mlp384 = "mlp384d_bx_kernel" if (bx_pipe and h.get_option("bf16_mlp") == 1) else "mlp384_bx_kernel"
+        mlp384 = "mlp384d_bx_kernel" if (bx_pipe and h.get_option("bf16_mlp") in (1, 6)) else "mlp384_bx_kernel"
         pmc_sets = [("pmc_traffic.json", "gemm4_f32_kernel", args.config == "vg" and B == 64 and mode == "f32"),
                     ("pmc_traffic_vg_B256.json", "gemm4_f32_kernel", args.config == "vg" and B == 256 and mode == "f32"),
                     ("pmc_traffic_coco_bf16.json", (mlp384, "mlp_bx_kernel") if bx_pipe else "gemm_bx_kernel",

@@ -144,6 +144,7 @@ struct dsg_handle_s {
     int opt_bf16_mlp = 1;                                         // in that pipeline: the fused fc1-GELU-fc2 kernels (0: two GEMMs with a bf16 hidden tensor; 1: C <= 192 on 4 waves, C = 384 on 8; 2: C = 384 on the 4-wave kernel too; 3: GEMM pair at C = 384)
     std::vector<std::pair<const float *, size_t>> gemm_weights;   // every fp32 GEMM weight (pointer, numel)
     std::map<const float *, void *> w_bf16;                       // bf16 copies, built when the mode is switched on
+    std::map<const float *, void *> w_img96;                      // per C = 96 block (key: its fc1_wf): W1 | W2 | Wp in fragment order for mlp96r_bx_kernel
     std::map<const float *, void *> w_qimg;                       // per block (key: its qkv_wf): the QKV weight in qkv_attn_wx_kernel's streaming order
     std::map<const float *, void *> w_img2;                       // the same weights chunk-major for mlp384s_bx_kernel (bf16_mlp = 5)
     std::map<const float *, void *> w_img;                        // per C = 384 block (key: its fc1_wf): W1 | W2 | Wp pre-arranged for mlp384d_bx_kernel's LDS-DMA ring
@@ -516,6 +517,19 @@ int ensure_bf16_weights(dsg_handle h) {
         launch_f32_to_bf16(pw.first, q, pw.second, nullptr);
         h->w_bf16[pw.first] = q;
     }
+    // the C = 96 blocks' fc1 / fc2 / proj weights in fragment order for the LDS-resident MLP kernel (launch_mlp96r_image)
+    if (h->cfg.mlp_ratio == 4)
+        for (int l = 0; l < h->L; l++)
+            for (auto *vec : {&h->down[l], &h->up[l]})
+                for (auto &b : *vec) {
+                    if (b.C != 96 || !b.fc1_wf || h->w_img96.count(b.fc1_wf)) continue;
+                    const float *w2 = WT(h, b.prefix + ".mlp.fc2.weight"), *wp = WT(h, b.prefix + ".attn.proj.weight");
+                    if (!h->w_bf16.count(b.fc1_wf) || !h->w_bf16.count(w2) || !h->w_bf16.count(wp)) continue;
+                    void *q;
+                    HIP_TRY(h, hipMalloc(&q, mlp96r_image_bytes()));
+                    launch_mlp96r_image(h->w_bf16[b.fc1_wf], h->w_bf16[w2], h->w_bf16[wp], q, nullptr);
+                    h->w_img96[b.fc1_wf] = q;
+                }
     // every block's QKV weight once more in the fragment order qkv_attn_wx_kernel streams (launch_qkv_image)
     for (int l = 0; l < h->L; l++)
         for (auto *vec : {&h->down[l], &h->up[l]})
@@ -640,6 +654,7 @@ void dsg_destroy(dsg_handle h) {
     for (auto &kv : h->w_img) (void)hipFree(kv.second);
     for (auto &kv : h->w_img2) (void)hipFree(kv.second);
     for (auto &kv : h->w_qimg) (void)hipFree(kv.second);
+    for (auto &kv : h->w_img96) (void)hipFree(kv.second);
     for (auto &kv : h->w_split) (void)hipFree(kv.second);
     for (void *p : h->derived_allocs) (void)hipFree(p);
     for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -872,6 +887,8 @@ int dsg_finalize_weights(dsg_handle h) {
     h->w_img2.clear();
     for (auto &kv : h->w_qimg) (void)hipFree(kv.second);
     h->w_qimg.clear();
+    for (auto &kv : h->w_img96) (void)hipFree(kv.second);
+    h->w_img96.clear();
     for (auto &kv : h->w_split) (void)hipFree(kv.second);
     h->w_split.clear();
     h->gemm_weights.clear();
@@ -1265,7 +1282,7 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
     }
     // the fused MLP kernel can take the proj linear, the residual and LayerNorm-2 in front (x + proj(att) never goes to HBM)
     const bool mlp_fused = h->opt_bf16_mlp && h->cfg.mlp_ratio == 4 && (C == 96 || C == 192 || (C == 384 && h->opt_bf16_mlp != 3));
-    const bool proj_in_mlp = mlp_fused && h->opt_bf16_proj_mlp && h->taps.empty() && (C == 96 || C == 192 || (C == 384 && (h->opt_bf16_mlp == 1 || h->opt_bf16_mlp == 4 || h->opt_bf16_mlp == 5)));
+    const bool proj_in_mlp = mlp_fused && h->opt_bf16_proj_mlp && h->taps.empty() && (C == 96 || C == 192 || (C == 384 && (h->opt_bf16_mlp == 1 || h->opt_bf16_mlp == 4 || h->opt_bf16_mlp == 5 || h->opt_bf16_mlp == 6)));
     const bool full = bx_full_row(C);
     if (!proj_in_mlp) {
         g = BxGemm();
@@ -1286,6 +1303,7 @@ BxState run_block_bx(dsg_handle h, Workspace *w, const BlockPlan &b, BxState st,
         m.wide8 = h->opt_bf16_mlp == 2 ? 0 : (h->opt_bf16_mlp == 4 ? 2 : (h->opt_bf16_mlp == 5 ? 3 : 1));
         m.img = C == 384 ? img_of(h, b.fc1_wf) : nullptr;
         m.img2 = C == 384 ? img2_of(h, b.fc1_wf) : nullptr;
+        if (C == 96 && h->opt_bf16_mlp == 6) { auto it = h->w_img96.find(b.fc1_wf); m.img96 = it == h->w_img96.end() ? nullptr : it->second; }   // (6: level 0 on the LDS-resident kernel -- measured at par, not the default)
         if (proj_in_mlp) { m.att = w->att; m.Wp = bf16_of(h, WT(h, p + ".attn.proj.weight")); m.bp = WT(h, p + ".attn.proj.bias"); }
         m.xn = w->xn; m.x = w->x; m.W1 = bf16_of(h, b.fc1_wf); m.b1 = b.fc1_bf;
         m.W2 = bf16_of(h, WT(h, p + ".mlp.fc2.weight")); m.b2 = WT(h, p + ".mlp.fc2.bias"); m.M = M; m.C = C;
@@ -1702,7 +1720,7 @@ int dsg_set_option(dsg_handle h, const char *name, int32_t value) {
     else if (n == "loop_graph") h->opt_loop_graph = value != 0;
     else if (n == "bf16_act") h->opt_bf16_act = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "bf16_pipe") h->opt_bf16_pipe = value != 0;
-    else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 5 ? 5 : value);
+    else if (n == "bf16_mlp") h->opt_bf16_mlp = value < 0 ? 0 : (value > 6 ? 6 : value);
     else if (n == "bf16_qkv_attn") h->opt_bf16_qkv_attn = value < 0 ? 0 : (value > 3 ? 3 : value);
     else if (n == "bf16_proj_mlp") h->opt_bf16_proj_mlp = value != 0;
     else if (n == "bf16_readout") h->opt_bf16_readout = value != 0;
@@ -2151,6 +2169,7 @@ int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const
                          void *stream) {
     const int old384 = (out_mode >> 5) & 1;      // + 32: C = 384 on round 3's eight-wave kernel instead of the LDS-DMA one
     const int solo384 = (out_mode >> 6) & 1;     // + 64: C = 384 on mlp384s_bx_kernel
+    const int staged96 = !((out_mode >> 7) & 1); // + 128: C = 96 without modulate on the LDS-resident kernel (mlp96r_bx_kernel) instead of the staged one
     out_mode &= 15;
     if (M < 1 || !att || !x || !Wp || !bp || !W1 || !b1 || !W2 || !b2 || (out_mode && !out_xn)) return DSG_ERR_INVALID;
     hipStream_t s = (hipStream_t)stream;
@@ -2170,6 +2189,11 @@ int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const
         if (hipMalloc(&imgb, mlp384_image_bytes()) != hipSuccess) { cleanup(); return DSG_ERR_HIP; }
         if (g.wide8 == 1) { launch_mlp384_images(w1b, w2b, wpb, imgb, s); g.img = imgb; }
         else { launch_mlp384s_images(w1b, w2b, wpb, imgb, s); g.img2 = imgb; }
+    }
+    if (C == 96 && !mod && !staged96) {
+        if (hipMalloc(&imgb, mlp96r_image_bytes()) != hipSuccess) { cleanup(); return DSG_ERR_HIP; }
+        launch_mlp96r_image(w1b, w2b, wpb, imgb, s);
+        g.img96 = imgb;
     }
     if (mod) { g.mod_aff = mod; g.mod_ld = 0; g.mod_off = 0; g.mod_T = 1; }
     const bool ok = launch_mlp_bx(g, s);

@@ -100,6 +100,7 @@ struct BxMlp {
     int M = 0, C = 0;
     int wide8 = 1;   // C = 384: 1 the eight-wave LDS-DMA kernel (needs img), 2 round 3's eight-wave kernel, 0 mlp_bx_kernel<384> (one wave per SIMD)
     unsigned long long *dbg = nullptr;   // measurement runs of the debug entry: [grid][8 waves][8] s_memtime stamps (mlp384d_bx_kernel)
+    const void *img96 = nullptr; // C = 96 with proj, no modulate: W1 | W2 | Wp in fragment order (launch_mlp96r_image) -> the LDS-resident kernel
     const void *img2 = nullptr;  // C = 384, wide8 = 3: the chunk-major image of mlp384s_bx_kernel (launch_mlp384s_images; same byte count as img)
     int skew = 0;                // mlp384d_bx_kernel: stagger step of the first-round blocks in shader clocks (0: all start together)
     const void *img = nullptr;   // C = 384: W1 | W2 | Wp pre-arranged for mlp384d_bx_kernel (launch_mlp384_images; mlp384_image_bytes())
@@ -111,6 +112,8 @@ bool launch_mlp_bx(const BxMlp &g, hipStream_t s);
 // Wpb [384, 384] (may be null: no proj stage) row-major bf16 -> img (mlp384_image_bytes() bytes)
 size_t mlp384_image_bytes();
 void launch_mlp384_images(const void *W1b, const void *W2b, const void *Wpb, void *img, hipStream_t s);
+size_t mlp96r_image_bytes();
+void launch_mlp96r_image(const void *W1b, const void *W2b, const void *Wpb, void *img, hipStream_t s);
 void launch_mlp384s_images(const void *W1b, const void *W2b, const void *Wpb, void *img, hipStream_t s);
 // x fp32 [B*T, C] -> optional in-place modulate+SiLU (aff != null) -> xn bf16: LayerNorm without affine (ln) or the plain copy
 void launch_ln_bx(float *x, const float *aff, int aff_ld, int aff_off, void *xn, int B, int T, int C, bool ln, hipStream_t s);

@@ -477,6 +477,9 @@ bool launch_gemm_bx(const BxGemm &g, hipStream_t s) {
 // i.e. it is the initial value of the fc2 accumulation: x1 never goes to HBM (unfused: proj writes it, this kernel re-reads it), neither
 // does LayerNorm-2 -- its statistics are lane-local sums of the accumulators and the normalised row, packed pairwise to bf16 AS THE
 // REGISTERS STAND, is fc1's B operand (k order 16 s + 8 (j >> 2) + 4 half + (j & 3); the W1 chunk is laid out in LDS in that order).
+#ifndef DSG_MLPB_EXP
+#define DSG_MLPB_EXP 0   // timing experiments of mlp_bx_kernel (wrong results): 1 no GELU, 2 no MFMAs in the chunk loop, 3 no weight staging in the chunk loop, 4 no fp32 row stores, 5 no fp32 row loads
+#endif
 template <int C, int MOD, bool PROJ = false>
 __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_bx_kernel(BxMlp g) {
     constexpr int H = 4 * C, NCH = H / 32, KS = C / 16, CT = C / 32;
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
         for (int ct = 0; ct < CT; ct++) {
             f32x4 rr[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) rr[q] = buf_load4(rsXi, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+            for (int q = 0; q < 4; q++) rr[q] = DSG_MLPB_EXP == 5 ? (f32x4){0.1f, 0.2f, 0.3f, 0.4f} : buf_load4(rsXi, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4 *>(g.bp + 32 * ct + 8 * q + 4 * lhalf);
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
     for (int hc = 0; hc < NCH; hc++) {
         const int cur = (hc + (PROJ ? CT : 0)) & 1;
         __syncthreads();
-        if (hc + 1 < NCH) {
+        if (hc + 1 < NCH && DSG_MLPB_EXP != 3) {
             write(1 - cur);                     // chunk hc + 1 (requested one item ago; PROJ: chunk 1 by the last proj item)
             if (hc + 2 < NCH) issue(hc + 2);
         }
@@ -621,15 +624,18 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
 #pragma unroll
         for (int r = 0; r < 16; r++) hacc[r] = b1s[(r & 3) + 8 * (r >> 2) + 4 * lhalf];
 #pragma unroll
-        for (int s = 0; s < KS; s++)
+        for (int s = 0; s < KS; s++) {
+            if (DSG_MLPB_EXP == 2) { hacc[s & 15] += (float)xf[s][0]; continue; }
             hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w1s + lrow * LD1 + 16 * s + 8 * lhalf), xf[s], hacc, 0, 0, 0);
+        }
         u32x4 hf[2];
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) { const f32x2_t gg = gelu_f2(hacc[r], hacc[r + 1]); hf[r >> 3][(r & 7) >> 1] = pack_bf16(gg[0], gg[1]); }
+        for (int r = 0; r < 16; r += 2) { const f32x2_t gg = DSG_MLPB_EXP == 1 ? (f32x2_t){hacc[r], hacc[r + 1]} : gelu_f2(hacc[r], hacc[r + 1]); hf[r >> 3][(r & 7) >> 1] = pack_bf16(gg[0], gg[1]); }
 #pragma unroll
         for (int ct = 0; ct < CT; ct++)
 #pragma unroll
             for (int s2i = 0; s2i < 2; s2i++)
+                if (DSG_MLPB_EXP == 2) oacc[ct][s2i] += __uint_as_float(hf[s2i][0]); else
                 oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(w2s + (32 * ct + lrow) * LD2 + 16 * s2i + 8 * lhalf),
                                                                    __builtin_bit_cast(bf16x8, hf[s2i]), oacc[ct], 0, 0, 0);
     }
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
 #pragma unroll
                 for (int t = 0; t < 4; t++) v[t] = silu_exact(fmaf(v[t], scl[t] + 1.0f, sft[t]));
             }
-            buf_store4(v, rsX, (mrow * C + (unsigned)c) * 4u, 0u);
+            if (DSG_MLPB_EXP != 4) buf_store4(v, rsX, (mrow * C + (unsigned)c) * 4u, 0u);
 #pragma unroll
             for (int t = 0; t < 4; t++) { ssum += v[t]; ssq = fmaf(v[t], v[t], ssq); oacc[ct][4 * q + t] = v[t]; }
             if (g.out_mode == 2) tput(ct, q, v);
@@ -1746,6 +1752,182 @@ __global__ __launch_bounds__(256, 1) void mlp384s_bx_kernel(BxMlp g) {
 #undef M384_STAMP
 }
 
+// -------------------------------------------------------------------------------------------------
+// mlp96r_bx_kernel -- the level-0 (C = 96) proj + MLP half of a Swin block with the weights RESIDENT in LDS.
+// tools/mlpb_exp.sh on mlp_bx_kernel<96> (343 us at M = 819200): without the per-block weight staging 247 us -- every 128-token block
+// re-stages all 147 KB of W1 | W2 through registers into a double-buffered LDS stage, twelve barriers per block.  At C = 96 the two MLP
+// weights are 2 x 72 KB as bf16: they fit the CU's 160 KB of LDS whole.  So: ONE persistent block per CU (eight waves, two per SIMD)
+// copies a plan-time fragment-order image of W1 | W2 into LDS once (LDS-DMA, 144 requests), b1 | bp | b2 into the LDS left over, and then
+// every wave walks 32-token tiles on its own: no barrier, no staging, no other wave's data -- a fragment read is base + lane 16 + immediate
+// (the proj weight's 18 fragments do not fit beside them: one contiguous-KiB load each per tile, L2-resident).  (C = 192 would need 590 KB.)
+// -------------------------------------------------------------------------------------------------
+constexpr int R96_W2 = 73728, R96_WP = 147456, R96_IMG = 165888, R96_B = 147456;   // image: W1 frags | W2 frags | Wp frags;  LDS: ... | b1 b p b2 floats
+__global__ __launch_bounds__(256) void mlp96r_img_kernel(const unsigned short *__restrict__ W1, const unsigned short *__restrict__ W2,
+                                                         const unsigned short *__restrict__ Wp, unsigned short *__restrict__ img) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;            // one 16-byte piece
+    if (idx >= R96_IMG / 16) return;
+    const int lane = idx & 63, lrow = lane & 31, lhalf = lane >> 5;
+    unsigned short v[8];
+    if (idx < 4608) {                                          // W1 fragment block (hc, s): hidden units 32 hc + lrow; channels in the ACCUMULATOR order of the
+        const int blk = idx >> 6, hc = blk / 6, sk = blk % 6;  // normalised row that fc1 meets (it is packed straight from the proj accumulators)
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = W1[(size_t)(32 * hc + lrow) * 96 + 16 * sk + 8 * (j >> 2) + 4 * lhalf + (j & 3)];
+    } else if (idx < 9216) {                                   // W2 fragment block (hc, ct, s2): channels 32 ct + lrow, hidden units in accumulator order
+        const int blk = (idx - 4608) >> 6, hc = blk / 6, ct = (blk % 6) >> 1, s2 = blk & 1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = W2[(size_t)(32 * ct + lrow) * 384 + 32 * hc + 16 * s2 + 8 * (j >> 2) + 4 * lhalf + (j & 3)];
+    } else {                                                   // Wp fragment block (ct, s)
+        const int blk = (idx - 9216) >> 6, ct = blk / 6, sk = blk % 6;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = Wp[(size_t)(32 * ct + lrow) * 96 + 16 * sk + 8 * lhalf + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) img[(size_t)idx * 8 + j] = v[j];
+}
+size_t mlp96r_image_bytes() { return R96_IMG; }
+void launch_mlp96r_image(const void *W1b, const void *W2b, const void *Wpb, void *img, hipStream_t s) {
+    DSG_LAUNCH(mlp96r_img_kernel, dim3((R96_IMG / 16 + 255) / 256), dim3(256), 0, s, (const unsigned short *)W1b, (const unsigned short *)W2b,
+               (const unsigned short *)Wpb, (unsigned short *)img);
+}
+
+__global__ __launch_bounds__(512, 1) void mlp96r_bx_kernel(BxMlp g, int ntiles) {
+    constexpr int C = 96, KS = 6, CT = 3, NCH = 12;
+    __shared__ __attribute__((aligned(16))) char lds[R96_B + (384 + 96 + 96) * 4];
+    float *b1s = reinterpret_cast<float *>(lds + R96_B), *bps = b1s + 384, *b2s = bps + 96;
+    const int tid = threadIdx.x, lane = tid & 63, lrow = lane & 31, lhalf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const char *img = static_cast<const char *>(g.img96);
+    {   // W1 | W2 image -> LDS, 144 KiB: eighteen 1-KiB requests per wave (inline assembly: see mlp384d_bx_kernel)
+        const unsigned lds0 = (unsigned)(size_t)lds, voff = (unsigned)lane * 16u;
+#pragma unroll
+        for (int i = 0; i < 18; i++)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds0 + (wave * 18 + i) * 1024), "v"(voff), "s"(img + (wave * 18 + i) * 1024) : "memory");
+    }
+    for (int i = tid; i < 384 + 96 + 96; i += 512) b1s[i] = i < 384 ? g.b1[i] : (i < 480 ? g.bp[i - 384] : g.b2[i - 480]);
+    M384_WAIT_VM(0);
+    __syncthreads();
+    const char *w1l = lds + lane * 16, *w2l = lds + R96_W2 + lane * 16;
+    __bf16 *xo = static_cast<__bf16 *>(g.xn_out);
+    for (int wt = blockIdx.x * 8 + wave; wt < ntiles; wt += (int)gridDim.x * 8) {
+        const int m0 = wt * 32, rows = min(32, g.M - m0);
+        const rsrc_t rsA = make_rsrc(static_cast<const __bf16 *>(g.att) + (size_t)m0 * C, (unsigned)rows * C * 2u);
+        const rsrc_t rsX = make_rsrc(g.x + (size_t)m0 * C, (unsigned)rows * C * 4u);
+        const rsrc_t rsO = make_rsrc(xo ? xo + (size_t)m0 * C : nullptr, xo ? (unsigned)rows * C * 2u : 0u);
+        bf16x8 xf[KS];
+#pragma unroll
+        for (int sk = 0; sk < KS; sk++) xf[sk] = __builtin_bit_cast(bf16x8, buf_load_u4(rsA, ((unsigned)lrow * C + 16u * sk + 8u * lhalf) * 2u, 0u));
+        bf16x8 wpf[CT][KS];                    // the proj weight's 18 fragments (L2-resident, one contiguous KiB per load; they do not fit the LDS
+#pragma unroll                                 // beside W1 | W2, and held for the block's lifetime they cost 72 registers through the chunk loop)
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int sk = 0; sk < KS; sk++) wpf[ct][sk] = *reinterpret_cast<const bf16x8 *>(img + R96_WP + (ct * 6 + sk) * 1024 + lane * 16);
+        f32x4 rr[CT][4];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) rr[ct][q] = buf_load4(rsX, ((unsigned)lrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);
+        // x1 = x + att Wp^T + bp: the shortcut and fc2's initial value; LayerNorm-2 of it -> fc1's B operand
+        f32x16 oacc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[ct][r] = 0.f;
+#pragma unroll
+            for (int sk = 0; sk < KS; sk++) oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wpf[ct][sk], xf[sk], oacc[ct], 0, 0, 0);
+        }
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bps + 32 * ct + 8 * q + 4 * lhalf);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float v = oacc[ct][4 * q + e] + b4[e] + rr[ct][q][e];
+                    oacc[ct][4 * q + e] = v; sm += v; sq = fmaf(v, v, sq);
+                }
+            }
+        sm += __shfl_xor(sm, 32, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        {
+            const float mean = sm * (1.0f / C), rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, sq * (1.0f / C)), 0.f) + LN_EPS), nmr = -mean * rstd;
+#pragma unroll
+            for (int sk = 0; sk < KS; sk++) {
+                u32x4 pk;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    pk[j] = pack_bf16(fmaf(oacc[sk >> 1][8 * (sk & 1) + 2 * j], rstd, nmr), fmaf(oacc[sk >> 1][8 * (sk & 1) + 2 * j + 1], rstd, nmr));
+                xf[sk] = __builtin_bit_cast(bf16x8, pk);
+            }
+        }
+        // (xf's k order: k-step s, half g, element e <-> channel 16 s + 8 (e >> 2) + 4 g + (e & 3) -- the proj accumulators' register order;
+        //  W1's image has the same order)
+        // The chunk loop is software-pipelined by hand and pinned with sched_barrier(0): left to itself the compiler reads every fragment
+        // immediately in front of its MFMA (one register quad for all of them, a full LDS latency per MFMA).  fc2's six fragments are
+        // requested before fc1's MFMAs, the next chunk's fc1 fragments before the GELU.
+        bf16x8 f1[KS], f2[2 * CT];
+#pragma unroll
+        for (int sk = 0; sk < KS; sk++) f1[sk] = *reinterpret_cast<const bf16x8 *>(w1l + sk * 1024);
+        for (int hc = 0; hc < NCH; hc++) {
+            f32x16 hacc;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(b1s + 32 * hc + 8 * q + 4 * lhalf);
+                hacc[4 * q] = b4[0]; hacc[4 * q + 1] = b4[1]; hacc[4 * q + 2] = b4[2]; hacc[4 * q + 3] = b4[3];
+            }
+#pragma unroll
+            for (int i = 0; i < 2 * CT; i++) f2[i] = *reinterpret_cast<const bf16x8 *>(w2l + (hc * 6 + i) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sk = 0; sk < KS; sk++) hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[sk], xf[sk], hacc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (hc + 1 < NCH) {
+#pragma unroll
+                for (int sk = 0; sk < KS; sk++) f1[sk] = *reinterpret_cast<const bf16x8 *>(w1l + ((hc + 1) * 6 + sk) * 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4 hf[2];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) { const f32x2_t gg = gelu_f2(hacc[r], hacc[r + 1]); hf[r >> 3][(r & 7) >> 1] = pack_bf16(gg[0], gg[1]); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; s2++)
+                    oacc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[2 * ct + s2], __builtin_bit_cast(bf16x8, hf[s2]), oacc[ct], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue: lane (token, half) holds channels 32 ct + 8 q + 4 half + {0..3} in oacc[ct][4 q ..]
+        float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c = 32 * ct + 8 * q + 4 * lhalf;
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(b2s + c);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { v[e] = oacc[ct][4 * q + e] + b4[e]; ssum += v[e]; ssq = fmaf(v[e], v[e], ssq); oacc[ct][4 * q + e] = v[e]; }
+                buf_store4(v, rsX, ((unsigned)lrow * C + (unsigned)c) * 4u, 0u);
+                if (g.out_mode == 2) __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), rsO, ((unsigned)lrow * C + (unsigned)c) * 2u, 0u, 0);
+            }
+        if (g.out_mode == 1) {
+            ssum += __shfl_xor(ssum, 32, 64);
+            ssq += __shfl_xor(ssq, 32, 64);
+            const float mean = ssum * (1.0f / C), rstd = fast_rsqrt(fmaxf(fmaf(-mean, mean, ssq * (1.0f / C)), 0.f) + LN_EPS), nmr = -mean * rstd;
+#pragma unroll
+            for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = fmaf(oacc[ct][4 * q + e], rstd, nmr);
+                    __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), rsO, ((unsigned)lrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 2u, 0u, 0);
+                }
+        }
+    }
+}
+
 bool launch_mlp_bx(const BxMlp &g_in, hipStream_t s) {
     const BxMlp &g = g_in;
     if ((!g.xn && !g.att) || !g.x || !g.W1 || !g.b1 || !g.W2 || !g.b2 || g.M < 1 || (g.out_mode && !g.xn_out)) return false;
@@ -1765,6 +1947,11 @@ bool launch_mlp_bx(const BxMlp &g_in, hipStream_t s) {
             else DSG_LAUNCH((mlp_bx_kernel<C_, 2>), grid, block, 0, s, g);                       \
         }                                                                                                \
     } while (0)
+    if (g.C == 96 && proj && mod == 0 && g.img96) {   // level 0: weights resident in LDS, persistent blocks (mlp96r_bx_kernel)
+        const int ntiles = (g.M + 31) / 32, nb = std::max(1, std::min(bx_cu_count(), (ntiles + 7) / 8));
+        DSG_LAUNCH(mlp96r_bx_kernel, dim3(nb), dim3(512), 0, s, g, ntiles);
+        return true;
+    }
     switch (g.C) {
         case 96: MLP_LAUNCH(96); break;
         case 192: MLP_LAUNCH(192); break;

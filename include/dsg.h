@@ -173,7 +173,7 @@ int dsg_sigma_schedule(const dsg_sampler_cfg *cfg, double *sigma_steps, float *t
  *       them; its kernel choices (all parity-tested, same bar): "bf16_qkv_attn" 1 QKV projection + window attention in one kernel (10 x 10
  *       windows: one wave per (window, head)), 2 the block-per-head kernel everywhere, 3 the former only where a block of four units lies in
  *       one window, 0 GEMM + attention kernel; "bf16_mlp" 1 fused fc1-GELU-fc2 (C = 384: eight waves, weight images streamed by LDS-DMA),
- *       4 round 3's eight-wave kernel, 5 the one-wave-per-SIMD LDS-DMA kernel, 2 four waves at every width, 3 GEMM pair at C = 384,
+ *       4 round 3's eight-wave kernel, 5 the one-wave-per-SIMD LDS-DMA kernel, 6 = 1 with level 0 on the LDS-resident kernel, 2 four waves at every width, 3 GEMM pair at C = 384,
  *       0 GEMM pairs; "bf16_proj_mlp" 1 proj + residual + LayerNorm-2 in front of the MLP kernel; "bf16_readout" 1 the read-out on the bf16 pipe. */
 int dsg_set_option(dsg_handle h, const char *name, int32_t value);
 /* The value an option currently has on this handle (what the next forward will run with), whichever way it was set
@@ -254,7 +254,8 @@ int dsg_debug_projmlp_bx(int32_t M, int32_t C, const float *att, float *x, const
  *   W2 [C,4C] given as fp32 and rounded to bf16 inside; mod = (scale [C] | shift [C]) or NULL; out_mode 0 none, 1 LayerNorm of the
  *   stored row, 2 its plain copy -> out_xn [M,C] (the bf16 store widened).  C in {96, 192, 384}.
  *   Kernel selection at C = 384 (both entries): out_mode as is = the LDS-DMA kernel on pre-arranged weight images; + 16 the four-wave
- *   kernel of the narrower levels (dsg_debug_mlp_bx only); + 32 round 3's eight-wave kernel; + 64 the one-wave-per-SIMD LDS-DMA kernel. */
+ *   kernel of the narrower levels (dsg_debug_mlp_bx only); + 32 round 3's eight-wave kernel; + 64 the one-wave-per-SIMD LDS-DMA kernel.
+ *   dsg_debug_projmlp_bx at C = 96 without modulate: + 128 the LDS-resident persistent kernel (mlp96r_bx_kernel). */
 int dsg_debug_mlp_bx(int32_t M, int32_t C, const float *xn, float *x, const float *W1, const float *b1, const float *W2, const float *b2,
                      const float *mod, int32_t out_mode, float *out_xn, int32_t time_iters, float *out_ms, void *stream);
 

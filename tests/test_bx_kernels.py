@@ -218,7 +218,9 @@ def test_mlp_bx_whole_matrix(M, C, mod, out_mode):
 @pytest.mark.parametrize("M,C,mod,out_mode", [(20037, 192, 1, 1), (65541, 96, 0, 2), (300, 96, 1, 1), (4096, 192, 0, 0), (51200, 96, 1, 1),
                                                (51200, 384, 1, 1), (20037, 384, 0, 2), (300, 384, 0, 0),
                                                (51200, 384, 1, 1 + 32), (20037, 384, 0, 2 + 32), (129, 384, 1, 1),
-                                               (51200, 384, 1, 1 + 64), (20037, 384, 0, 2 + 64), (300, 384, 0, 0 + 64), (129, 384, 1, 1 + 64)])
+                                               (51200, 384, 1, 1 + 64), (20037, 384, 0, 2 + 64), (300, 384, 0, 0 + 64), (129, 384, 1, 1 + 64),
+                                               (65541, 96, 0, 2 + 128), (4096, 96, 0, 0 + 128), (129, 96, 0, 1 + 128), (100003, 96, 0, 1 + 128), (31, 96, 0, 2 + 128),   # + 128: C = 96 on the LDS-resident kernel
+                                               (4096, 96, 0, 0), (129, 96, 0, 1)])
 def test_projmlp_bx_whole_matrix(M, C, mod, out_mode):
     """proj + residual + LayerNorm-2 + fc1 + GELU + fc2 + residual [+ modulate] [+ LayerNorm | copy] in one kernel against fp64 on the
     bf16-rounded operands: x1 = x + att Wp^T + bp stays in the accumulators (fp32), its LayerNorm is rounded to bf16 as fc1's operand,

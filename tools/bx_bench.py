@@ -126,6 +126,12 @@ if __name__ == "__main__":
     if only == "mlp384s":  # the one-wave-per-SIMD LDS-DMA kernel alone
         projmlp("L2 proj + MLP (mod, LN), 4 waves solo", M2, 384, out_mode=1 + 64)
         sys.exit(0)
+    if only == "mlpb":  # the level-0 / level-1 fused (proj +) MLP kernels alone (tools/mlpb_exp.sh)
+        projmlp("L1 proj + MLP fused (mod, LN)", M1, 192)
+        projmlp("L1 proj + MLP fused (copy)", M1, 192, mod=0, out_mode=2)
+        projmlp("L0 proj + MLP fused (copy)", M0, 96, mod=0, out_mode=2)
+        projmlp("L0 proj + MLP fused (copy), LDS-resident", M0, 96, mod=0, out_mode=2 + 128)
+        sys.exit(0)
     if only == "mlp":   # the fused MLP kernels alone
         mlp("L2 fused MLP (mod, LN), 8 waves LDS-DMA", M2, 384)
         mlp("L2 fused MLP (mod, LN), 8 waves round 3", M2, 384, out_mode=1 + 32)
