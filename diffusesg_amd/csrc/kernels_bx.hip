@@ -660,13 +660,18 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
             buf_store_u4(d, rsO, ((unsigned)(32 * wave + r) * C + (unsigned)(96 * third + 8 * pc)) * 2u, 0u);
         }
     };
+    // The fp32 rows leave through a wave-private 32 x 32 tile as well (round 4: tools/mlpb_exp.sh -- the direct form, where a store
+    // instruction touches 32 rows x 32 bytes, cost 36 of 343 us at C = 96): a store instruction then writes 8 rows x one whole 128-byte
+    // line.  The tile aliases T (used after this loop: the bf16 output is formed from the values kept in oacc).
+    constexpr int XLD = 36;
+    float *xt = reinterpret_cast<float *>(T);
     float ssum = 0.f, ssq = 0.f;
 #pragma unroll
     for (int ct = 0; ct < CT; ct++) {
         f32x4 rr[4];
 #pragma unroll
         for (int q = 0; q < 4; q++)
-            rr[q] = PROJ ? (f32x4){0.f, 0.f, 0.f, 0.f} : buf_load4(rsX, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u);   // (PROJ: x1 is in oacc)
+            rr[q] = PROJ ? (f32x4){0.f, 0.f, 0.f, 0.f} : (DSG_MLPB_EXP == 5 ? (f32x4){0.1f, 0.2f, 0.3f, 0.4f} : buf_load4(rsX, (mrow * C + (unsigned)(32 * ct + 8 * q + 4 * lhalf)) * 4u, 0u));   // (PROJ: x1 is in oacc)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int c = 32 * ct + 8 * q + 4 * lhalf;
@@ -679,12 +684,30 @@ __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_b
 #pragma unroll
                 for (int t = 0; t < 4; t++) v[t] = silu_exact(fmaf(v[t], scl[t] + 1.0f, sft[t]));
             }
-            if (DSG_MLPB_EXP != 4) buf_store4(v, rsX, (mrow * C + (unsigned)c) * 4u, 0u);
+            *reinterpret_cast<f32x4 *>(xt + lrow * XLD + 8 * q + 4 * lhalf) = v;
 #pragma unroll
             for (int t = 0; t < 4; t++) { ssum += v[t]; ssq = fmaf(v[t], v[t], ssq); oacc[ct][4 * q + t] = v[t]; }
-            if (g.out_mode == 2) tput(ct, q, v);
         }
-        if (g.out_mode == 2 && ct % 3 == 2) tflush(ct / 3);
+        if (DSG_MLPB_EXP != 4) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = 8 * k + (lane >> 3), pc = lane & 7;
+                const f32x4 d = *reinterpret_cast<const f32x4 *>(xt + r * XLD + 4 * pc);
+                buf_store4(d, rsX, ((unsigned)(32 * wave + r) * C + (unsigned)(32 * ct + 4 * pc)) * 4u, 0u);
+            }
+        }
+    }
+    if (g.out_mode == 2) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x4 v;
+#pragma unroll
+                for (int t = 0; t < 4; t++) v[t] = oacc[ct][4 * q + t];
+                tput(ct, q, v);
+                if (ct % 3 == 2 && q == 3) tflush(ct / 3);
+            }
     }
     if (g.out_mode == 1) {
         ssum += __shfl_xor(ssum, 32, 64);
