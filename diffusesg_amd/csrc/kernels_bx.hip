@@ -480,6 +480,9 @@ bool launch_gemm_bx(const BxGemm &g, hipStream_t s) {
 #ifndef DSG_MLPB_EXP
 #define DSG_MLPB_EXP 0   // timing experiments of mlp_bx_kernel (wrong results): 1 no GELU, 2 no MFMAs in the chunk loop, 3 no weight staging in the chunk loop, 4 no fp32 row stores, 5 no fp32 row loads
 #endif
+// (Tried in round 4, not kept: C = 192 as ONE eight-wave block of 256 tokens per CU instead of two four-wave blocks of 128 -- the same eight
+//  waves, half the weight staging per token: 272 us against 238 (copy), 301 against 242 (modulate + LayerNorm).  Two independent blocks
+//  overlap their barriers and HBM phases; one block of eight waves marches in step.)
 template <int C, int MOD, bool PROJ = false>
 __global__ __launch_bounds__(256, (C <= 96 ? 3 : (C <= 192 ? 2 : 1))) void mlp_bx_kernel(BxMlp g) {
     constexpr int H = 4 * C, NCH = H / 32, KS = C / 16, CT = C / 32;
