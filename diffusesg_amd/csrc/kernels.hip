@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
         // scheduler cannot interleave with its neighbours
         float v[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = acc[j][r] + bias;
+        for (int r = 0; r < 16; r += 2) { const f32x2_t t2 = (f32x2_t){acc[j][r], acc[j][r + 1]} + (f32x2_t){bias, bias}; v[r] = t2[0]; v[r + 1] = t2[1]; }
         if (ACT == ACT_GELU) {   // pairs on the packed-fp32 instructions (gelu_f2)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) { const f32x2_t gg = gelu_f2(v[r], v[r + 1]); v[r] = gg[0]; v[r + 1] = gg[1]; }
@@ -491,7 +491,10 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             if (ACT == ACT_SILU) v[r] = silu_exact(v[r]);
-            if (ACT != ACT_DGELU && RES) v[r] += rres[r];
+        }
+        if (ACT != ACT_DGELU && RES) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) { const f32x2_t t2 = (f32x2_t){v[r], v[r + 1]} + (f32x2_t){rres[r], rres[r + 1]}; v[r] = t2[0]; v[r + 1] = t2[1]; }
         }
         if (ACT == ACT_DGELU) {   // (training form) d_pre = d_hid * GELU'(pre), pre read through the residual path (dgelu_f2: pairs, packed fp32)
 #pragma unroll
@@ -517,7 +520,11 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
         }
         if (EPI >= 1 && nok) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) { st_s[r] += v[r]; st_q[r] = fmaf(v[r], v[r], st_q[r]); }
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2_t v2 = {v[r], v[r + 1]};
+                const f32x2_t s2 = (f32x2_t){st_s[r], st_s[r + 1]} + v2, q2 = __builtin_elementwise_fma(v2, v2, (f32x2_t){st_q[r], st_q[r + 1]});
+                st_s[r] = s2[0]; st_s[r + 1] = s2[1]; st_q[r] = q2[0]; st_q[r + 1] = q2[1];
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; r++) buf_store1(v[r], rsC, vC, (unsigned)((r & 3) + 8 * (r >> 2)) * g.ldc * 4u);
