@@ -404,14 +404,18 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             float sum = 0.f;
+            f32x2_t sum2 = {0.f, 0.f};
+            const f32x2_t mx2 = {mx, mx};
 #pragma unroll
             for (int kt = 0; kt < A_KT; kt++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float e = __builtin_amdgcn_exp2f(sacc[kt][r] - mx);   // scores carry the log2(e) factor
-                    sacc[kt][r] = e;
-                    sum += e;
+                for (int r = 0; r < 16; r += 2) {   // (subtract and sum on packed fp32; the sum's association changes: pairs of lanes' partials)
+                    const f32x2_t d2 = (f32x2_t){sacc[kt][r], sacc[kt][r + 1]} - mx2;
+                    const f32x2_t e2 = {__builtin_amdgcn_exp2f(d2[0]), __builtin_amdgcn_exp2f(d2[1])};   // scores carry the log2(e) factor
+                    sacc[kt][r] = e2[0]; sacc[kt][r + 1] = e2[1];
+                    sum2 += e2;
                 }
+            sum = sum2[0] + sum2[1];
             sum += __shfl_xor(sum, 32, 64);
             const float inv = fast_rcp(sum);
             f32x16 oacc;
@@ -423,7 +427,11 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
 #pragma unroll
                 for (int r = 0; r < 16; r++) vf[r] = Vs[(wbase + 32 * kt + (r & 3) + 8 * (r >> 2) + 4 * lhalf) * GLD + lrow];
 #pragma unroll
-                for (int r = 0; r < 16; r++) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sacc[kt][r] * inv, vf[r], oacc, 0, 0, 0);
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2_t p2 = (f32x2_t){sacc[kt][r], sacc[kt][r + 1]} * (f32x2_t){inv, inv};
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(p2[0], vf[r], oacc, 0, 0, 0);
+                    oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(p2[1], vf[r + 1], oacc, 0, 0, 0);
+                }
             }
             // O tile: column d = lrow of head tn, row = query (r&3)+8(r>>2)+4*half of this wave's 32 tokens
             const rsrc_t rsO = make_rsrc(g.C, (unsigned)g.M * g.ldc * 4u);
@@ -508,14 +516,18 @@ __global__ __launch_bounds__(256, 2) void gemm4_f32_kernel(GemmArgs g, int tiles
 #pragma unroll
             for (int r = 0; r < 16; r += 2) { const f32x2_t gg = gelu_f2(v[r], v[r + 1]); v[r] = gg[0]; v[r + 1] = gg[1]; }
         }
-        if (EPI >= 2) {
+        if (EPI >= 2) {   // silu(shift + x (1 + scale)) = a / (1 + exp(-a)): the FMA, the add and the product on packed fp32 (same arithmetic per element)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
+            for (int r = 0; r < 16; r += 2) {
+                f32x2_t sc2 = {msc, msc}, sh2 = {msh, msh};
                 if (EPI == 3 && nok) {
-                    const float *ar = g.mod_aff + (size_t)brow[r] * g.mod_ld + g.mod_off + n;
-                    msc = ar[0] + 1.0f; msh = ar[g.N];
+                    const float *ar0 = g.mod_aff + (size_t)brow[r] * g.mod_ld + g.mod_off + n, *ar1 = g.mod_aff + (size_t)brow[r + 1] * g.mod_ld + g.mod_off + n;
+                    sc2 = (f32x2_t){ar0[0], ar1[0]} + (f32x2_t){1.0f, 1.0f}; sh2 = (f32x2_t){ar0[g.N], ar1[g.N]};
                 }
-                v[r] = silu_exact(fmaf(v[r], msc, msh));
+                const f32x2_t a2 = __builtin_elementwise_fma((f32x2_t){v[r], v[r + 1]}, sc2, sh2);
+                const f32x2_t d2 = (f32x2_t){1.0f, 1.0f} + (f32x2_t){__expf(-a2[0]), __expf(-a2[1])};
+                const f32x2_t o2 = a2 * (f32x2_t){fast_rcp(d2[0]), fast_rcp(d2[1])};
+                v[r] = o2[0]; v[r + 1] = o2[1];
             }
         }
         if (EPI >= 1 && nok) {
